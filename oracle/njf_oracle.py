@@ -1,0 +1,632 @@
+"""CPU oracle for the neural-jacobian-field volumetric-rendering hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain-torch (fp32, CPU) functional
+restatement of the reference algorithm.  It is the *checker* for the HIP path:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  The product package (``neural-jacobian-field_amd/``) never
+imports anything from ``oracle/`` and has no CPU fallback.
+
+Pinning status
+--------------
+* Everything that lives in the reference tree (geometry, samplers, ResnetFC,
+  pixel-aligned sampling, activations, transformer head, compositing, Model
+  orchestration) is pinned against golden vectors produced by importing the
+  reference itself in the build container (``tests/golden/make_golden.py``);
+  ``tests/test_oracle_golden.py`` checks this file against them.
+* Three pieces of arithmetic live in un-vendored, un-pinned third-party
+  packages and are restated from their published algorithms -- **parity
+  unpinned** for exactly these:
+    - nerfstudio ``NeRFEncoding``   -> :func:`nerf_positional_encoding`
+    - tiny-cuda-nn ``SphericalHarmonics`` degree 4 -> :func:`sh4_encoding`
+    - torchvision ``resnet34`` trunk -> :func:`encoder_features`
+
+All ``file:line`` citations are relative to ``/root/reference/project/neural_jacobian_field``
+(abbreviated ``NJF/``).  Weights are passed as a flat ``dict[str, Tensor]`` that uses
+the reference's state-dict names (``decoder.density_head.lin_in.weight`` ...).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+def _sub(params: Params, prefix: str) -> Params:
+    """View of ``params`` with ``prefix`` stripped (prefix must end with '.')."""
+    n = len(prefix)
+    return {k[n:]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+def _affine(params: Params, name: str, x: Tensor) -> Tensor:
+    return F.linear(x, params[name + ".weight"], params.get(name + ".bias"))
+
+
+def _with_one(p: Tensor) -> Tensor:
+    # NJF/rendering/geometry.py:32-34 (homogenize_points)
+    return torch.cat([p, torch.ones_like(p[..., :1])], dim=-1)
+
+
+def _with_zero(v: Tensor) -> Tensor:
+    # NJF/rendering/geometry.py:37-39 (homogenize_vecs)
+    return torch.cat([v, torch.zeros_like(v[..., :1])], dim=-1)
+
+
+def _matvec(mat: Tensor, vec: Tensor) -> Tensor:
+    # NJF/rendering/geometry.py:76-81 (transform_rigid) -- einsum "... i j, ... j -> ... i"
+    return torch.einsum("...ij,...j->...i", mat, vec)
+
+
+# --------------------------------------------------------------------------------------
+# a1 / a2: pixel grid and ray generation
+# --------------------------------------------------------------------------------------
+def pixel_grid(height: int, width: int) -> Tuple[Tensor, Tensor]:
+    """NJF/rendering/geometry.py:117-134 (get_pixel_coordinates).
+
+    Returns normalised pixel-centre xy coordinates [H,W,2] and the int64 (row,col) selector.
+    """
+    rows = torch.arange(height)
+    cols = torch.arange(width)
+    selector = torch.stack(torch.meshgrid(rows, cols, indexing="ij"), dim=-1)
+    xs = (cols + 0.5) / width
+    ys = (rows + 0.5) / height
+    coords = torch.stack(torch.meshgrid(xs, ys, indexing="xy"), dim=-1)
+    return coords, selector
+
+
+def world_rays_with_z(coords_xy: Tensor, k_norm: Tensor, c2w: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """NJF/rendering/geometry.py:170-203 (get_world_rays_with_z) with unproject (:42-56).
+
+    coords_xy [B,R,2] normalised, k_norm [B,3,3] normalised intrinsics, c2w [B,4,4].
+    Returns origins [B,R,3], unit directions [B,R,3] (world), z [B,R,1] (camera-space z of the unit dir).
+    """
+    hom = _with_one(coords_xy)
+    cam = torch.einsum("cij,crj->cri", k_norm.inverse(), hom)
+    cam = cam * torch.ones_like(coords_xy[..., 0])[..., None]
+    cam = cam / cam.norm(dim=-1, keepdim=True)
+    z = cam[..., -1:]
+    world = _matvec(c2w[:, None], _with_zero(cam))
+    origins = c2w[..., :3, 3][:, None, :].expand(-1, world.shape[1], -1)
+    return origins, world[..., :3], z
+
+
+def denormalize_intrinsics(k_norm: Tensor, width: int, height: int) -> Tensor:
+    """NJF/utils/convention.py:110-125."""
+    k = k_norm.clone()
+    k[..., 0, :] *= width
+    k[..., 1, :] *= height
+    return k
+
+
+# --------------------------------------------------------------------------------------
+# a3 / a4 / a10 / a11 / a12: samples along rays
+# --------------------------------------------------------------------------------------
+class Samples:
+    """Plain container mirroring NJF/rendering/ray_samplers.py:28-45 (RaySamples) fields."""
+
+    def __init__(self, origins, directions, starts, ends, spacing_starts, spacing_ends, near, far):
+        self.origins = origins  # [..., 1, 3]
+        self.directions = directions  # [..., 1, 3]
+        self.starts = starts  # [..., S, 1]
+        self.ends = ends
+        self.deltas = ends - starts  # ray_samplers.py:136
+        self.spacing_starts = spacing_starts
+        self.spacing_ends = spacing_ends
+        self.near = near  # [..., 1]
+        self.far = far
+
+    def positions(self) -> Tensor:
+        # ray_samplers.py:48-55 (get_positions): o + d * (s + e) / 2
+        return self.origins + self.directions * (self.starts + self.ends) / 2
+
+    def to_euclid(self, x: Tensor) -> Tensor:
+        # ray_samplers.py:240-243 with identity spacing_fn (UniformSampler, :269-276)
+        return x * self.far + (1 - x) * self.near
+
+
+def _samples_from_bins(origins, directions, near, far, bins) -> Samples:
+    # ray_samplers.py:244-252 / :445-451 + RayBundle.get_ray_samples (:118-147)
+    euclid = bins * far + (1 - bins) * near
+    return Samples(
+        origins[..., None, :],
+        directions[..., None, :],
+        euclid[..., :-1, None],
+        euclid[..., 1:, None],
+        bins[..., :-1, None],
+        bins[..., 1:, None],
+        near,
+        far,
+    )
+
+
+def uniform_samples(origins, directions, near, far, num_samples: int, training: bool = False,
+                    single_jitter: bool = False) -> Samples:
+    """NJF/rendering/ray_samplers.py:197-253 (SpacedSampler) specialised to UniformSampler (:256-276).
+
+    In training mode the stratified jitter draws from the global torch RNG with the same shapes
+    and order as the reference, so a shared ``torch.manual_seed`` reproduces it on CPU.
+    """
+    batch_shape = origins.shape[:-1]
+    bins = torch.linspace(0.0, 1.0, num_samples + 1)[None, ...]
+    if training:
+        if single_jitter:
+            t_rand = torch.rand((*batch_shape, 1), dtype=bins.dtype)
+        else:
+            t_rand = torch.rand((*batch_shape, num_samples + 1), dtype=bins.dtype)
+        centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
+        upper = torch.cat([centers, bins[..., -1:]], -1)
+        lower = torch.cat([bins[..., :1], centers], -1)
+        bins = lower + (upper - lower) * t_rand
+    else:
+        bins = bins.repeat(*batch_shape, 1)
+    return _samples_from_bins(origins, directions, near, far, bins)
+
+
+def alpha_weights(deltas: Tensor, densities: Tensor) -> Tensor:
+    """NJF/rendering/ray_samplers.py:77-101 (RaySamples.get_weights).
+
+    w_i = (1 - exp(-d_i s_i)) * exp(-sum_{j<i} d_j s_j), with d_i s_i forced to 0 where d_i <= 0.
+    """
+    mask = deltas > 0
+    ds = torch.zeros_like(densities)
+    ds[mask] = deltas[mask] * densities[mask]
+    alphas = 1 - torch.exp(-ds)
+    acc = torch.cumsum(ds[..., :-1, :], dim=-2)
+    acc = torch.cat([torch.zeros((*acc.shape[:-2], 1, 1)), acc], dim=-2)
+    return alphas * torch.exp(-acc)
+
+
+def pdf_resample(prev: Samples, weights: Tensor, num_samples: int, training: bool = False,
+                 single_jitter: bool = False, histogram_padding: float = 0.01, eps: float = 1e-5) -> Samples:
+    """NJF/rendering/ray_samplers.py:351-451 (PDFSampler, include_original=False)."""
+    num_bins = num_samples + 1
+    w = weights[..., 0] + histogram_padding
+    w_sum = torch.sum(w, dim=-1, keepdim=True)
+    pad = torch.relu(eps - w_sum)
+    w = w + pad / w.shape[-1]
+    w_sum = w_sum + pad
+    pdf = w / w_sum
+    cdf = torch.min(torch.ones_like(pdf), torch.cumsum(pdf, dim=-1))
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
+
+    u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins)
+    if training:
+        u = u.expand((*cdf.shape[:-1], num_bins))
+        if single_jitter:
+            rand = torch.rand((*cdf.shape[:-1], 1)) / num_bins
+        else:
+            rand = torch.rand((*cdf.shape[:-1], num_samples + 1)) / num_bins
+        u = u + rand
+    else:
+        u = u + 1.0 / (2 * num_bins)
+        u = u.expand(size=(*cdf.shape[:-1], num_bins))
+    u = u.contiguous()
+
+    old_bins = torch.cat([prev.spacing_starts[..., 0], prev.spacing_ends[..., -1:, 0]], dim=-1)
+    last = old_bins.shape[-1] - 1
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo = torch.clamp(idx - 1, 0, last)
+    hi = torch.clamp(idx, 0, last)
+    cdf_lo, bin_lo = torch.gather(cdf, -1, lo), torch.gather(old_bins, -1, lo)
+    cdf_hi, bin_hi = torch.gather(cdf, -1, hi), torch.gather(old_bins, -1, hi)
+    t = torch.clip(torch.nan_to_num((u - cdf_lo) / (cdf_hi - cdf_lo), 0), 0, 1)
+    bins = (bin_lo + t * (bin_hi - bin_lo)).detach()
+    return _samples_from_bins(prev.origins[..., 0, :], prev.directions[..., 0, :], prev.near, prev.far, bins)
+
+
+def proposal_sampling(origins, directions, near, far, density_fns: Sequence[Callable[[Tensor], Tensor]],
+                      num_proposal_samples: Sequence[int], num_nerf_samples: int, anneal: float = 1.0,
+                      training: bool = False, single_jitter: bool = False):
+    """NJF/rendering/ray_samplers.py:497-552 (ProposalNetworkSampler.generate_ray_samples).
+
+    The grad/no-grad ``updated`` schedule (:512-549) only affects autograd, not values, and is
+    not modelled here.  Returns (final samples, weights_list, samples_list).
+    """
+    n = len(density_fns)
+    weights_list: List[Tensor] = []
+    samples_list: List[Samples] = []
+    weights = None
+    samples = None
+    for level in range(n + 1):
+        is_prop = level < n
+        count = num_proposal_samples[level] if is_prop else num_nerf_samples
+        if level == 0:
+            samples = uniform_samples(origins, directions, near, far, count, training, single_jitter)
+        else:
+            annealed = torch.pow(weights, anneal)
+            samples = pdf_resample(samples, annealed, count, training, single_jitter)
+        if is_prop:
+            density = density_fns[level](samples.positions())
+            weights = alpha_weights(samples.deltas, density)
+            weights_list.append(weights)
+            samples_list.append(samples)
+    return samples, weights_list, samples_list
+
+
+def anneal_value(step: int, max_iters: int, slope: float) -> float:
+    """NJF/models/model.py:201-209 (step_before_iter): mip-NeRF-360 eq. 18 bias schedule."""
+    frac = min(max(step / max_iters, 0.0), 1.0)
+    return (slope * frac) / ((slope - 1) * frac + 1)
+
+
+# --------------------------------------------------------------------------------------
+# a5: pixel-aligned bilinear feature sampling
+# --------------------------------------------------------------------------------------
+def project_points(xyz_cam_hom: Tensor, intrinsics: Tensor) -> Tuple[Tensor, Tensor]:
+    """NJF/rendering/geometry.py:137-154 (deprecated_project): K x / (z + 1e-9)."""
+    xyw = torch.einsum("...ij,...j->...i", intrinsics, xyz_cam_hom[..., :3])
+    z = xyw[..., -1:]
+    return (xyw / (z + 1e-9))[..., :3], z
+
+
+def pixel_aligned(xyz_world: Tensor, c2w: Tensor, k_norm: Tensor, feats: Tensor):
+    """NJF/model_components/pixel_aligned_features.py:11-35.
+
+    xyz_world [B,N,3]; c2w [B,4,4]; k_norm [B,3,3]; feats [B,C,Hf,Wf].
+    Returns (features [B,N,C], camera-space xyz [B,N,3], uv [B,N,3]).
+    """
+    cam_hom = _matvec(torch.inverse(c2w[:, None]), _with_one(xyz_world))  # geometry.py:59-65
+    uv, _ = project_points(cam_hom, k_norm.unsqueeze(1))
+    grid = ((uv - 0.5) * 2)[..., None, :][..., :2]
+    sampled = F.grid_sample(feats, grid, align_corners=True, padding_mode="border", mode="bilinear")
+    return sampled.squeeze(-1).permute(0, 2, 1), cam_hom[..., :3], uv
+
+
+def world_to_pixels(xyz_world: Tensor, c2w: Tensor, k_pix: Tensor) -> Tensor:
+    """NJF/rendering/geometry.py:206-215 (project_world_coords_to_camera)."""
+    cam_hom = _matvec(torch.inverse(c2w[..., None, :, :]), _with_one(xyz_world))
+    uv, _ = project_points(cam_hom, k_pix.unsqueeze(1))
+    return uv[..., :2]
+
+
+# --------------------------------------------------------------------------------------
+# a6 / a16: third-party encodings (restated; parity unpinned)
+# --------------------------------------------------------------------------------------
+def nerf_positional_encoding(x: Tensor, num_frequencies: int = 10) -> Tensor:
+    """nerfstudio ``NeRFEncoding(in_dim=3, num_frequencies=F, min_freq_exp=0, max_freq_exp=F-1,
+    include_input=True, implementation="torch")`` as constructed at
+    NJF/models/decoder/density_decoder.py:31-38 and action_decoder_jacobian.py:275-282.
+
+    Published algorithm (nerfstudio/field_components/encodings.py, un-pinned fork
+    ``git+https://github.com/sizhe-li/nerfstudio.git``): s = (2*pi*x)[..., None] * 2**linspace(0, F-1, F),
+    flattened dimension-major; out = cat[sin(s), sin(s + pi/2), x].  PARITY UNPINNED.
+    """
+    scaled = 2 * torch.pi * x
+    freqs = 2 ** torch.linspace(0.0, num_frequencies - 1, num_frequencies)
+    s = (scaled[..., None] * freqs).reshape(*scaled.shape[:-1], -1)
+    enc = torch.sin(torch.cat([s, s + torch.pi / 2.0], dim=-1))
+    return torch.cat([enc, x], dim=-1)
+
+
+def sh4_encoding(dirs01: Tensor) -> Tensor:
+    """tiny-cuda-nn ``SphericalHarmonics`` degree 4 behind nerfstudio ``SHEncoding(levels=4,
+    implementation="tcnn")`` (NJF/models/decoder/action_decoder_jacobian.py:284).
+
+    Input is the direction mapped to [0,1] (action_decoder_jacobian.py:24-30); tcnn maps it back
+    with v = 2x-1 and evaluates 16 real SH basis functions with its sign convention.  The reference
+    has no CPU form of this op (CUDA only) and tcnn emits fp16 by default; this restatement is fp32.
+    PARITY UNPINNED (tiny-cuda-nn git HEAD, un-pinned; install.sh:23).
+    """
+    v = dirs01 * 2.0 - 1.0
+    x, y, z = v[..., 0], v[..., 1], v[..., 2]
+    xy, xz, yz = x * y, x * z, y * z
+    x2, y2, z2 = x * x, y * y, z * z
+    out = [
+        torch.full_like(x, 0.28209479177387814),
+        -0.48860251190291987 * y,
+        0.48860251190291987 * z,
+        -0.48860251190291987 * x,
+        1.0925484305920792 * xy,
+        -1.0925484305920792 * yz,
+        0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz,
+        0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * y * (-3.0 * x2 + y2),
+        2.8906114426405538 * xy * z,
+        0.45704579946446572 * y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * z * (5.0 * z2 - 3.0),
+        0.45704579946446572 * x * (1.0 - 5.0 * z2),
+        1.4453057213202769 * z * (x2 - y2),
+        0.59004358992664352 * x * (-x2 + 3.0 * y2),
+    ]
+    return torch.stack(out, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# a7 / a8: ResnetFC and the density activation
+# --------------------------------------------------------------------------------------
+def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_layer: int = 3) -> Tensor:
+    """NJF/model_components/resnet_fc.py:130-154 (ResnetFC.forward) with ResnetBlockFC (:69-79), ReLU (beta=0)."""
+    h = _affine(params, "lin_in", x)
+    for i in range(n_blocks):
+        if i < combine_layer:
+            h = h + _affine(params, f"lin_z.{i}", z)
+        net = _affine(params, f"blocks.{i}.fc_0", torch.relu(h))
+        dx = _affine(params, f"blocks.{i}.fc_1", torch.relu(net))
+        h = h + dx
+    return _affine(params, "lin_out", torch.relu(h))
+
+
+def trunc_exp_density(pre: Tensor) -> Tensor:
+    """NJF/model_components/activations.py:13-38: forward of trunc_exp(x - 1) is exp(x - 1) in fp32."""
+    return torch.exp((pre - 1).float())
+
+
+# --------------------------------------------------------------------------------------
+# a9 / a13-a17: decoders
+# --------------------------------------------------------------------------------------
+class PixelEncoding:
+    """NJF/models/decoder/action_decoder.py:11-16."""
+
+    def __init__(self, features, extrinsics, intrinsics, action):
+        self.features, self.extrinsics, self.intrinsics, self.action = features, extrinsics, intrinsics, action
+
+
+def proposal_density(params: Params, xyz_world: Tensor, enc: PixelEncoding, n_freq: int = 10) -> Tensor:
+    """NJF/models/decoder/density_decoder.py:45-71 (DensityDecoderMlp.get_density).  xyz [B,R,S,3] -> [B,R,S,1]."""
+    b, r, s = xyz_world.shape[:3]
+    feats, xyz_cam, _ = pixel_aligned(xyz_world.reshape(b, r * s, 3), enc.extrinsics, enc.intrinsics, enc.features)
+    pe = nerf_positional_encoding(xyz_cam.contiguous(), n_freq)
+    dens = trunc_exp_density(resnet_fc(_sub(params, "density_head."), feats, pe))
+    return dens.reshape(b, r, s, 1)
+
+
+def decoder_density(params: Params, xyz_flat: Tensor, enc: PixelEncoding, geo_dim: int = 15, n_freq: int = 10):
+    """NJF/models/decoder/action_decoder_jacobian.py:92-119 (compute_density).  xyz_flat [B,N,3]."""
+    feats, xyz_cam, _ = pixel_aligned(xyz_flat, enc.extrinsics, enc.intrinsics, enc.features)
+    pe = nerf_positional_encoding(xyz_cam.contiguous(), n_freq)
+    out = resnet_fc(_sub(params, "density_head."), feats, pe)
+    geo, pre = torch.split(out, [geo_dim, 1], dim=-1)
+    return trunc_exp_density(pre), geo, pe, feats
+
+
+def _layer_norm(params: Params, name: str, x: Tensor) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), params[name + ".weight"], params[name + ".bias"])
+
+
+def _cross_attention(params: Params, prefix: str, x: Tensor, z: Tensor, heads: int) -> Tensor:
+    """NJF/model_components/transformer.py:39-82 (Attention, selfatt=False) wrapped in PreNorm (:14-21)."""
+    xn = _layer_norm(params, prefix + "norm", x)
+    q = F.linear(xn, params[prefix + "fn.to_q.weight"])
+    k, v = F.linear(z, params[prefix + "fn.to_kv.weight"]).chunk(2, dim=-1)
+    dim_head = q.shape[-1] // heads
+
+    def split(t):
+        return t.reshape(t.shape[0], t.shape[1], heads, dim_head).permute(0, 2, 1, 3)
+
+    q, k, v = split(q), split(k), split(v)
+    attn = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * dim_head ** -0.5, dim=-1)
+    out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(x.shape[0], x.shape[1], heads * dim_head)
+    return _affine(params, prefix + "fn.to_out.0", out)
+
+
+def _feed_forward(params: Params, prefix: str, x: Tensor) -> Tensor:
+    """NJF/model_components/transformer.py:24-36 (FeedForward, GELU) wrapped in PreNorm."""
+    xn = _layer_norm(params, prefix + "norm", x)
+    return _affine(params, prefix + "fn.net.3", F.gelu(_affine(params, prefix + "fn.net.0", xn)))
+
+
+def jacobian_mlp(params: Params, feats: Tensor, pe: Tensor) -> Tensor:
+    """NJF/models/decoder/action_decoder_jacobian.py:324-337 (ActionDecoderJacobianMLP.compute_jacobian)."""
+    return resnet_fc(_sub(params, "jacobian_head."), feats, pe)
+
+
+def jacobian_transformer(params: Params, feats: Tensor, pe: Tensor, heads: int = 8, depth: int = 3) -> Tensor:
+    """NJF/models/decoder/action_decoder_jacobian.py:418-446 + transformer.py:85-135."""
+    x = _affine(params, "jacobian_query_mlp", torch.cat([pe, feats], dim=-1))
+    z = params["jacobian_index_embedding"]
+    for layer in range(depth):
+        pre = f"jacobian_attn_decoder.layers.{layer}."
+        x = _cross_attention(params, pre + "0.", x, z, heads) + x
+        x = _feed_forward(params, pre + "1.", x) + x
+    return _affine(params, "jacobian_head", x)
+
+
+def color_head(params: Params, geo: Tensor, dir_feats: Tensor) -> Tensor:
+    """NJF/models/decoder/action_decoder_jacobian.py:208,315-322: 31->64->64->3, ReLU, Sigmoid."""
+    h = torch.cat((geo, dir_feats), dim=-1)
+    h = torch.relu(_affine(params, "color_head.0", h))
+    h = torch.relu(_affine(params, "color_head.2", h))
+    return torch.sigmoid(_affine(params, "color_head.4", h))
+
+
+def decoder_forward(params: Params, xyz: Tensor, dirs: Tensor, enc: PixelEncoding, kind: str, action_dim: int):
+    """NJF/models/decoder/action_decoder_jacobian.py:147-215 (ActionDecoderJacobian.forward).
+
+    ``params`` uses names relative to ``decoder.``.  Returns (density [B,R,S,1], color [B,R,S,3],
+    flow [B,R,S,3], jacobian [B,R,S,3A]).
+    """
+    b, r, s = xyz.shape[:3]
+    dens, geo, pe, feats = decoder_density(params, xyz.reshape(b, r * s, 3), enc)
+    jac = jacobian_mlp(params, feats, pe) if kind == "jacobian_mlp" else jacobian_transformer(params, feats, pe)
+    action = enc.action[:, None, :].expand(b, r * s, action_dim)
+    # :128-145 -- J viewed (action_dim, spatial_dim), contracted with the action
+    flow = torch.einsum("bnas,bna->bns", jac.reshape(b, r * s, action_dim, -1), action)
+    dir01 = ((dirs + 1.0) / 2.0).reshape(b * r * s, 3)  # :24-30, :194-198
+    sh = sh4_encoding(dir01.contiguous()).reshape(b, r, s, -1)
+    geo = geo.reshape(b, r, s, -1)
+    rgb = color_head(params, geo, sh)
+    return dens.reshape(b, r, s, 1), rgb, flow.reshape(b, r, s, -1), jac.reshape(b, r, s, -1)
+
+
+def decoder_encode_image(params: Params, xyz: Tensor, enc: PixelEncoding, kind: str):
+    """NJF/models/decoder/action_decoder_jacobian.py:217-249 (encode_image): density + Jacobian only."""
+    b, r, s = xyz.shape[:3]
+    dens, _, pe, feats = decoder_density(params, xyz.reshape(b, r * s, 3), enc)
+    jac = jacobian_mlp(params, feats, pe) if kind == "jacobian_mlp" else jacobian_transformer(params, feats, pe)
+    return dens.reshape(b, r, s, 1), jac.reshape(b, r, s, -1)
+
+
+# --------------------------------------------------------------------------------------
+# a18: compositing
+# --------------------------------------------------------------------------------------
+def composite_rgb(rgb: Tensor, weights: Tensor) -> Tensor:
+    """NJF/models/model.py:257-270 (render_rgb, bg_color=None)."""
+    return torch.sum(weights * rgb, dim=-2)
+
+
+def composite_depth(weights: Tensor, starts: Tensor, ends: Tensor) -> Tuple[Tensor, Tensor]:
+    """NJF/models/model.py:272-279 (render_depth); note the *tensor-global* clip bounds."""
+    steps = (starts + ends) / 2
+    depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+    return torch.clip(depth, steps.min(), steps.max()), steps
+
+
+def composite_flow(weights, positions, scene_flow, trgt_c2w, trgt_k_pix):
+    """NJF/models/model.py:288-314 (render_optical_flow)."""
+    warped = positions + scene_flow
+    mean_pos = torch.sum(weights * positions, dim=-2)
+    mean_warp = torch.sum(weights * warped, dim=-2)
+    uv0 = world_to_pixels(mean_pos, trgt_c2w, trgt_k_pix)
+    uv1 = world_to_pixels(mean_warp, trgt_c2w, trgt_k_pix)
+    return uv1 - uv0, mean_pos, mean_warp
+
+
+# --------------------------------------------------------------------------------------
+# encoder (restated torchvision resnet34 trunk; parity unpinned for the trunk itself)
+# --------------------------------------------------------------------------------------
+def _bn(params: Params, name: str, x: Tensor) -> Tensor:
+    return F.batch_norm(x, params[name + ".running_mean"], params[name + ".running_var"],
+                        params[name + ".weight"], params[name + ".bias"], training=False, eps=1e-5)
+
+
+def _basic_block(params: Params, prefix: str, x: Tensor, stride: int) -> Tensor:
+    out = F.conv2d(x, params[prefix + "conv1.weight"], stride=stride, padding=1)
+    out = torch.relu(_bn(params, prefix + "bn1", out))
+    out = _bn(params, prefix + "bn2", F.conv2d(out, params[prefix + "conv2.weight"], padding=1))
+    if prefix + "downsample.0.weight" in params:
+        x = _bn(params, prefix + "downsample.1", F.conv2d(x, params[prefix + "downsample.0.weight"], stride=stride))
+    return torch.relu(out + x)
+
+
+def encoder_features(params: Params, rgb: Tensor, num_layers: int = 4, use_first_pool: bool = True) -> Tensor:
+    """NJF/models/encoder/encoder_resnet.py:53-86 (EncoderResnet.forward), eval-mode BatchNorm.
+
+    ``params`` uses names relative to ``encoder.`` (``model.conv1.weight`` ...).  The ResNet34 trunk
+    (BasicBlock [3,4,6,3]) is torchvision's published architecture; only the upsample+concat logic
+    is reference code.
+    """
+    x = F.conv2d(rgb, params["model.conv1.weight"], stride=2, padding=3)
+    x = torch.relu(_bn(params, "model.bn1", x))
+    latents = [x]
+    depths = [3, 4, 6, 3]
+    if num_layers > 1:
+        if use_first_pool:
+            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        for li in range(1, min(num_layers, 5)):
+            for bi in range(depths[li - 1]):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                x = _basic_block(params, f"model.layer{li}.{bi}.", x, stride)
+            latents.append(x)
+    size = latents[0].shape[-2:]
+    latents = [F.interpolate(l, size, mode="bilinear", align_corners=False) for l in latents]
+    return torch.cat(latents, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a19: Model.forward and inference helpers
+# --------------------------------------------------------------------------------------
+class ForwardResult:
+    def __init__(self):
+        self.rgb = self.depth = self.optical_flow = None
+        self.weights_list: List[Tensor] = []
+        self.samples_list: List[Samples] = []
+        self.action_features = self.steps = self.weights = None
+        self.ray_positions = self.ray_positions_warped = None
+        self.density = self.color = self.flow = self.jacobian = None
+
+
+def model_forward(params: Params, *, features: Optional[Tensor] = None, input_image: Optional[Tensor] = None,
+                  ctxt_c2w: Tensor, ctxt_k_norm: Tensor, trgt_c2w: Tensor, trgt_k_pix: Tensor,
+                  origins: Tensor, directions: Tensor, z_near: Tensor, z_far: Tensor, action: Tensor,
+                  num_proposal_samples: Sequence[int], num_nerf_samples: int,
+                  decoder_kind: str = "jacobian_mlp", anneal: float = 1.0, training: bool = False,
+                  single_jitter: bool = False) -> ForwardResult:
+    """NJF/models/model.py:316-396 (Model.forward).
+
+    ``params`` carries reference state-dict names (``encoder.*``, ``decoder.*``, ``proposal_networks.N.*``).
+    Either ``features`` ([B,512,Hf,Wf], skips the encoder) or ``input_image`` must be given.
+    """
+    if features is None:
+        features = encoder_features(_sub(params, "encoder."), input_image)
+    ones = torch.ones_like(origins[..., 0:1])  # model.py:215-226 (compute_ray_bundle)
+    near = ones * z_near[:, None, None]
+    far = ones * z_far[:, None, None]
+    enc = PixelEncoding(features, ctxt_c2w, ctxt_k_norm, action)
+
+    n_prop = len(num_proposal_samples)
+    fns = [
+        (lambda xyz, i=i: proposal_density(_sub(params, f"proposal_networks.{i}."), xyz, enc))
+        for i in range(n_prop)
+    ]
+    samples, weights_list, samples_list = proposal_sampling(
+        origins, directions, near, far, fns, num_proposal_samples, num_nerf_samples, anneal, training, single_jitter
+    )
+    positions = samples.positions()
+    dirs = directions[..., None, :].expand(positions.shape)  # model.py:245-247
+
+    dens, rgb, flow, jac = decoder_forward(_sub(params, "decoder."), positions, dirs, enc, decoder_kind,
+                                           action.shape[-1])
+    weights = alpha_weights(samples.deltas, dens)
+    weights_list.append(weights)
+    samples_list.append(samples)
+
+    res = ForwardResult()
+    res.rgb = composite_rgb(rgb, weights)
+    res.depth, steps = composite_depth(weights, samples.starts, samples.ends)
+    res.optical_flow, res.ray_positions, res.ray_positions_warped = composite_flow(
+        weights, positions, flow[..., :3], trgt_c2w, trgt_k_pix
+    )
+    res.weights_list, res.samples_list = weights_list, samples_list
+    res.action_features = torch.sum(weights * jac, dim=-2)  # model.py:281-286
+    res.steps, res.weights = steps.squeeze(-1), weights.squeeze(-1)
+    res.density, res.color, res.flow, res.jacobian = dens, rgb, flow, jac
+    res.positions = positions
+    return res
+
+
+def infer_optical_flow(jacobian: Tensor, weights: Tensor, positions: Tensor, action: Tensor,
+                       trgt_c2w: Tensor, trgt_k_pix: Tensor) -> Tensor:
+    """NJF/models/model.py:497-525 (Model.infer_optical_flow) on a cached encoding."""
+    b, r, s = jacobian.shape[:3]
+    a = action.shape[-1]
+    flow = torch.einsum("brsad,ba->brsd", jacobian.reshape(b, r, s, a, -1), action)
+    out, _, _ = composite_flow(weights, positions, flow[..., :3], trgt_c2w, trgt_k_pix)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a20: training-step contract (ray subsampling + losses)
+# --------------------------------------------------------------------------------------
+def random_ray_indices(height: int, width: int, count: int) -> Tuple[Tensor, Tensor]:
+    """NJF/models/model_wrapper.py:437-444 (random_sample_ray_yx_indices); global torch RNG."""
+    idx = torch.floor(torch.rand((count, 2)) * torch.tensor([height, width])).long()
+    return idx[:, 0], idx[:, 1]
+
+
+def rgb_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """NJF/models/model_wrapper.py:119-121."""
+    return F.mse_loss(pred, target)
+
+
+def flow_loss(pred: Tensor, target: Tensor, visible_mask: Optional[Tensor] = None) -> Tensor:
+    """NJF/models/model_wrapper.py:148-160."""
+    err = 0.01 * F.mse_loss(pred, target, reduction="none")
+    if visible_mask is not None:
+        return (err * visible_mask.unsqueeze(-1)).sum() / visible_mask.sum()
+    return err.mean()
+
+
+def ds_nerf_depth_loss(weights, termination_depth, steps, lengths, sigma) -> Tensor:
+    """NJF/utils/loss_utils.py:9-35 (note: divides by 2*sigma, not 2*sigma^2)."""
+    mask = termination_depth > 0
+    loss = -torch.log(weights + 1.0e-7) * torch.exp(-((steps - termination_depth[..., None, :]) ** 2) / (2 * sigma)) * lengths
+    return torch.mean(loss.sum(-2) * mask)
