@@ -1,0 +1,188 @@
+/*
+ * njf_hip.h -- C ABI of the MI355X (gfx950) volumetric-rendering hot path of Neural Jacobian Fields.
+ *
+ * The reference (sizhe-li/neural-jacobian-field) has no FFI: its seam is the Python object API of
+ * project/neural_jacobian_field/models/model.py (Model.forward :316, encode_image :458,
+ * compute_density :416) and the operator registry in models/decoder/__init__.py:11-44.  This header
+ * is the boundary placed *underneath* that API: every entry point names the
+ * reference code it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer to fp32 unless noted; tensors are dense row-major.
+ *   - Caller owns all memory; the library never allocates, frees or keeps state between calls.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation.
+ *   - Return value: 0 = ok; negative = invalid argument (nothing was launched, see
+ *     njf_error_string); positive = a hipError_t from the launch.
+ *   - Re-entrant and thread-safe.
+ *
+ * Packed-weight layout ("fragment-major")
+ *   The fused kernels keep activations in MFMA C/D registers between layers
+ *   (v_mfma_f32_32x32x2_f32; a wave owns 32 points, lane l owns point l&31 and half l>>5 of the
+ *   features).  A layer y = W x + b with W [d_out, d_in] (torch.nn.Linear layout) is stored as
+ *   P[kb][q][mb][lane][e] = W[fo(mb, lane&31)][16*KB*(lane>>5) + 16*kb + 4*q + e]
+ *   with MB = ceil(d_out/32), KB = ceil(d_in/32), zero padding, and
+ *   fo(mb, i) = 16*MB*((i>>2)&1) + 16*mb + (i&3) + 4*(i>>3).
+ *   njf_pack_* produce these blobs from reference-layout tensors; callers never build them by hand.
+ */
+#ifndef NJF_HIP_H
+#define NJF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NJF_ABI_VERSION 1
+#define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
+#define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
+#define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
+#define NJF_PE_DIM 63           /* NeRFEncoding(3, 10 freqs, include_input) output width */
+#define NJF_ZDIM 384            /* 3 lin_z layers x 128: channels of one net's hoisted feature map */
+
+/* floats in one packed ResnetFC blob (weights) and its bias blob */
+#define NJF_RESNET_CHUNKS 22
+#define NJF_CHUNK_FLOATS 8192
+#define NJF_RESNET_W_FLOATS (NJF_RESNET_CHUNKS * NJF_CHUNK_FLOATS)
+#define NJF_RESNET_B_FLOATS (10 * 128 + 32)
+#define NJF_COLOR_W_FLOATS NJF_CHUNK_FLOATS
+#define NJF_COLOR_B_FLOATS (64 + 32)
+
+/* Reference-layout tensors of one ResnetFC (model_components/resnet_fc.py:82-128), all device fp32. */
+typedef struct NjfResnetFcWeights {
+  const float* lin_in_w;    /* [128, 63]  */
+  const float* lin_in_b;    /* [128]      */
+  const float* fc0_w[5];    /* blocks.i.fc_0.weight [128,128] */
+  const float* fc0_b[5];    /* [128] */
+  const float* fc1_w[5];    /* blocks.i.fc_1.weight [128,128] */
+  const float* fc1_b[5];
+  const float* lin_z_w[3];  /* lin_z.i.weight [128, 512] */
+  const float* lin_z_b[3];  /* [128] */
+  const float* lin_out_w;   /* [d_out, 128] */
+  const float* lin_out_b;   /* [d_out] */
+  int d_out;                /* 1 (proposal), 16 (density+15 features), 3*A (Jacobian) ; <= 32 */
+} NjfResnetFcWeights;
+
+/* color_head of ActionDecoderJacobian* (models/decoder/action_decoder_jacobian.py:315-322). */
+typedef struct NjfColorHeadWeights {
+  const float* w0; const float* b0;   /* [64, 31], [64]  (15 geometry features ++ 16 SH) */
+  const float* w1; const float* b1;   /* [64, 64], [64] */
+  const float* w2; const float* b2;   /* [3, 64],  [3]  */
+} NjfColorHeadWeights;
+
+/* Cameras + scene bounds shared by the fused kernels.  Inverses are taken by the caller
+ * (torch.linalg.inv on device), mirroring transform_world2cam (rendering/geometry.py:59-65). */
+typedef struct NjfCameras {
+  const float* ctxt_w2c;     /* [B,4,4] inverse of the context cam2world */
+  const float* ctxt_k;       /* [B,3,3] normalised context intrinsics */
+  const float* trgt_w2c;     /* [B,4,4] inverse of the target cam2world (may be NULL when no flow is rendered) */
+  const float* trgt_k;       /* [B,3,3] target intrinsics in pixels */
+  const float* z_near;       /* [B] */
+  const float* z_far;        /* [B] */
+  const float* action;       /* [B,A] robot command (may be NULL -> flow outputs are skipped) */
+  int batch;                 /* B */
+  int action_dim;            /* A <= NJF_MAX_ACTION_DIM */
+} NjfCameras;
+
+/* Hoisted, channels-last feature map: G[b][y][x][c] = lin_z(F)[c] (see njf_project_features). */
+typedef struct NjfFeatureMap {
+  const float* data;   /* [B, Hf, Wf, stride] */
+  int height, width;   /* Hf, Wf */
+  int stride;          /* floats per texel (>= offset + NJF_ZDIM) */
+} NjfFeatureMap;
+
+/* ---- library info ------------------------------------------------------------------------ */
+int njf_abi_version(void);
+const char* njf_error_string(int code);
+
+/* ---- weight packing (one-off per weight update) -------------------------------------------- */
+/* Packs one ResnetFC into `w_out` [NJF_RESNET_W_FLOATS] / `b_out` [NJF_RESNET_B_FLOATS] and its
+ * three lin_z layers into `wz_out` [512,384] (k-major) / `bz_out` [384] (inputs of
+ * njf_project_features).  Replaces nothing in the reference: it is the layout change that lets
+ * ResnetFC.forward (resnet_fc.py:130-154) run as one fused kernel. */
+int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, float* bz_out,
+                      void* stream);
+/* Same, writing lin_z into a wider [512, wz_ld] matrix (several nets side by side: pass wz_out + column offset). */
+int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
+                         float* bz_out, void* stream);
+int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, void* stream);
+
+/* ---- per-image feature projection ("lin_z hoist") ------------------------------------------ */
+/* G[b,p,n] = sum_k F[b,k,p] * wz[k,n] + bz[n];  F is the encoder output [B,512,Hf,Wf] (NCHW),
+ * wz [512,N] (k-major, as written by njf_pack_resnetfc*), bz [N], out [B, Hf*Wf, N].  Because bilinear interpolation is linear with weights
+ * summing to 1, lin_z(grid_sample(F)) == grid_sample(G): this moves resnet_fc.py:138-141's
+ * 3 x (512->128) GEMMs from per-point to per-texel. */
+int njf_project_features(const float* feats, const float* wz, const float* bz, int batch, int hw, int n,
+                         float* out, void* stream);
+int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, const float* bz, int batch, int hw, int n,
+                            float* out, void* stream);
+
+/* ---- ray generation: rendering/geometry.py:117-134 + :170-203 ------------------------------ */
+/* coords [B,R,2] normalised pixel centres (NULL -> full H x W grid of get_pixel_coordinates),
+ * k_inv [B,3,3] inverse normalised intrinsics, c2w [B,4,4];  outputs origins/directions [B,R,3], z [B,R]. */
+int njf_generate_rays(const float* coords, int height, int width, const float* k_inv, const float* c2w,
+                      int batch, int rays, float* origins, float* directions, float* z, void* stream);
+
+/* ---- fused proposal pass: ray_samplers.py:497-552 (level loop body) ------------------------ */
+/* For every ray: sample `s_in` bins (bins_in: [s_in+1] shared, or [B*R, s_in+1] when
+ * bins_per_ray), evaluate DensityDecoderMlp.get_density (density_decoder.py:45-71), get_weights
+ * (ray_samplers.py:77-101), weights**anneal (:529), PDFSampler (:351-451) with `u` ([s_out+1]
+ * shared or per ray) -> bins_out [B*R, s_out+1].  Optional per-sample outputs (may be NULL):
+ * weights_out, density_out [B*R, s_in]. */
+int njf_proposal_forward(const float* origins, const float* directions, int rays_per_batch,
+                         const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
+                         const float* w_pack, const float* b_pack,
+                         const float* bins_in, int bins_per_ray, int s_in,
+                         const float* u, int u_per_ray, int s_out, float anneal,
+                         float* bins_out, float* weights_out, float* density_out, void* stream);
+
+/* ---- fused final pass: action_decoder_jacobian.py:147-215 + model.py:257-314 --------------- */
+typedef struct NjfRenderOutputs {
+  float* rgb;             /* [B*R,3]  render_rgb (model.py:257-270) */
+  float* depth;           /* [B*R]    render_depth before the tensor-global clip (model.py:276) */
+  float* step_minmax;     /* [B*R,2]  per-ray min/max of the sample mid-points (inputs of the clip, model.py:277) */
+  float* flow;            /* [B*R,2]  render_optical_flow (model.py:288-314); NULL to skip */
+  float* pos;             /* [B*R,3]  sum_s w x            (vis_output.ray_positions); NULL to skip */
+  float* pos_warped;      /* [B*R,3]  sum_s w (x + flow)   (vis_output.ray_positions_warped); NULL to skip */
+  float* action_features; /* [B*R,3A] sum_s w J            (render_action_features, model.py:281-286); NULL to skip */
+  float* weights;         /* [B*R,S]  per-sample weights   (training_output / vis_output); NULL to skip */
+  float* density;         /* [B*R,S]  per-sample density; NULL to skip */
+  float* color;           /* [B*R,S,3]; NULL to skip */
+  float* sample_flow;     /* [B*R,S,3] per-sample 3-D flow; NULL to skip */
+  float* jacobian;        /* [B*R,S,3A] per-sample action features (encode_image, model.py:458-495); NULL to skip */
+} NjfRenderOutputs;
+
+/* bins [B*R, S+1] are spacing-domain bin edges in [0,1] (output of njf_proposal_forward or a
+ * sampler); the kernel maps them to Euclidean t = b*far + (1-b)*near (ray_samplers.py:240-243). */
+int njf_render_forward(const float* origins, const float* directions, int rays_per_batch,
+                       const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset_density,
+                       int gmap_offset_jacobian,
+                       const float* w_density, const float* b_density,
+                       const float* w_color, const float* b_color,
+                       const float* w_jacobian, const float* b_jacobian,
+                       const float* bins, int samples, const NjfRenderOutputs* out, void* stream);
+
+/* ---- point-list evaluation (arbitrary xyz): density_decoder.py:45-71, model.py:416-456 ----- */
+/* xyz [B,N,3] world-space points, dirs [B,N,3] or NULL.  mode 0: proposal net -> density [B*N].
+ * mode 1: decoder -> density [B*N], color [B*N,3], flow [B*N,3], jacobian [B*N,3A], geo [B*N,15]
+ * (any may be NULL); the Jacobian head runs only when w_jacobian != NULL.  The decoder blobs must be
+ * one allocation laid out [density | colour | jacobian] (also for njf_render_forward). */
+int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
+                       const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
+                       const float* w_density, const float* b_density, const float* w_color, const float* b_color,
+                       const float* w_jacobian, const float* b_jacobian,
+                       float* density, float* color, float* flow, float* jacobian, float* geo, void* stream);
+
+/* ---- stand-alone sampler / compositing ops (API parity with the un-fused reference calls) -- */
+/* RaySamples.get_weights (ray_samplers.py:77-101): deltas, densities [N,S] -> weights [N,S]. */
+int njf_alpha_weights(const float* deltas, const float* densities, int rays, int samples, float* weights, void* stream);
+/* PDFSampler.generate_ray_samples (ray_samplers.py:351-451) on spacing bins. */
+int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ray, int s_in, const float* u,
+                     int u_per_ray, int s_out, float anneal, int rays, float* bins_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NJF_HIP_H */

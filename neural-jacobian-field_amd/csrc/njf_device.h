@@ -1,0 +1,382 @@
+// Device-side building blocks shared by the fused kernels (gfx950 / CDNA4 only).
+//
+// Register-resident MLP: a wave owns a tile of 32 points.  Lane l holds point j = l & 31 and the
+// feature half hh = l >> 5.  An activation vector of width 32*MB is an array f32x16 v[MB] in the
+// C/D layout of v_mfma_f32_32x32x2_f32: v[mb][r] is logical feature 16*MB*hh + 16*mb + r of point
+// j.  Computing  out^T = W * in^T  with the weights as the A operand and the activations as the B
+// operand makes register r of the previous layer's D tile exactly K-step r of the next layer, so
+// activations never leave registers between layers; only weights stream (HBM/L2 -> LDS by
+// global_load_lds DMA, double buffered in 32 KiB chunks, one barrier per chunk).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NJF_WAVES 8
+#define NJF_THREADS (NJF_WAVES * 64)
+#define NJF_CHUNK 8192  // floats per weight chunk (32 KiB)
+
+// LDS carve (floats).  One dynamic array only (a second __shared__ object makes hipcc drain
+// vmcnt(0) in front of every ds_read of a DMA pipeline).
+#define LDS_W0 0
+#define LDS_W1 NJF_CHUNK
+#define LDS_BIAS (2 * NJF_CHUNK)
+#define LDS_BIAS_FLOATS 3072
+#define LDS_SCRATCH (LDS_BIAS + LDS_BIAS_FLOATS)
+#define LDS_SCRATCH_PER_WAVE 1056  // proposal pass: w'[<=256] | cdf[<=257] | bins[<=257] | spare
+#define LDS_TOTAL_FLOATS (LDS_SCRATCH + NJF_WAVES * LDS_SCRATCH_PER_WAVE)
+
+extern __shared__ __attribute__((aligned(16))) float njf_lds[];
+
+__device__ __forceinline__ float mfma_step(float a, float b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  return 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight stream: chunks of NJF_CHUNK floats, consumed in program order, wrapping every
+// `per_pass` chunks.  step() = one barrier: after it the current chunk is resident, and the DMA
+// for the next one has been issued into the other buffer (whose readers all passed the barrier).
+// ------------------------------------------------------------------------------------------
+struct WeightStream {
+  const float* g;  // blob base (global)
+  int per_pass;    // chunks per tile pass
+  int total;       // chunks over the whole workgroup lifetime
+  int idx;         // next chunk to consume
+  int in_pass;     // idx % per_pass of the chunk being prefetched
+};
+
+__device__ __forceinline__ void dma_chunk(const float* __restrict__ src, int buf, int wave, int lane) {
+  // 512 threads x 16 B = 8 KiB per round, 4 rounds per 32 KiB chunk.  LDS destination is
+  // wave-uniform base + lane*16 (hardware), global source is per lane.
+  float* dst = njf_lds + buf * NJF_CHUNK + wave * 256;
+  const float* s = src + wave * 256 + lane * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + r * 2048),
+                                     (__attribute__((address_space(3))) void*)(dst + r * 2048), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
+                                             int lane) {
+  st.g = g;
+  st.per_pass = per_pass;
+  st.total = per_pass * passes;
+  st.idx = 0;
+  st.in_pass = 0;
+  dma_chunk(g, 0, wave, lane);
+}
+
+__device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, int lane) {
+  __syncthreads();
+  const float* cur = njf_lds + (st.idx & 1) * NJF_CHUNK;
+  st.idx += 1;
+  st.in_pass += 1;
+  if (st.in_pass == st.per_pass) st.in_pass = 0;
+  if (st.idx < st.total) dma_chunk(st.g + (size_t)st.in_pass * NJF_CHUNK, st.idx & 1, wave, lane);
+  return cur;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[MBO] += W[:, kb range] * in   for the (kb,q) groups stored at `wl` (LDS, packed
+// [kb][q][mb][lane][e]).  RELU applies max(.,0) to the B operand on the fly.
+// ------------------------------------------------------------------------------------------
+template <int MBO, int NKB, int KB0, bool RELU, int KBI>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane, const f32x16 (&in)[KBI],
+                                          f32x16 (&out)[MBO]) {
+  const float* base = wl + lane * 4;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) a[m] = *(const f32x4*)(base + ((kb * 4 + q) * MBO + m) * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float b = in[KB0 + kb][q * 4 + e];
+        if (RELU) b = fmaxf(b, 0.f);
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][e], b, out[m], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// acc[m][r] (+)= bias[16*MB*hh + 16*m + r]   (bias in LDS, logical order)
+template <int MB, bool ASSIGN>
+__device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, f32x16 (&acc)[MB]) {
+  const float* b = bl + 16 * MB * hh;
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = *(const f32x4*)(b + 16 * m + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ASSIGN) acc[m][4 * q + e] = v[e];
+        else acc[m][4 * q + e] += v[e];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-point geometry: world -> context camera -> bilinear footprint in the hoisted feature map.
+// Mirrors get_pixel_aligned_features (model_components/pixel_aligned_features.py:11-35) and ATen's
+// grid_sampler_2d(bilinear, border, align_corners=True).  The 4-term dot products are fma chains
+// in k order: that is what torch.einsum("...ij,...j->...i") lowers to on CPU, so camera-space
+// coordinates match the oracle bit for bit (they feed a positional encoding that amplifies ulps).
+// ------------------------------------------------------------------------------------------
+struct PointGeom {
+  float xc, yc, zc;  // camera-space position (positional-encoding input)
+  int t00, t01, t10, t11;  // texel offsets (floats) into the feature map of this batch element
+  float w00, w01, w10, w11;
+};
+
+struct CamCtx {
+  float m[12];  // rows 0..2 of ctxt_w2c
+  float k[9];
+};
+
+__device__ __forceinline__ void load_ctx(const float* __restrict__ w2c, const float* __restrict__ k, int b,
+                                         CamCtx& c) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) c.m[i] = w2c[b * 16 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.k[i] = k[b * 9 + i];
+}
+
+__device__ __forceinline__ float dot4_h(const float* r, float x, float y, float z) {
+  float a = r[0] * x;
+  a = fmaf(r[1], y, a);
+  a = fmaf(r[2], z, a);
+  a = fmaf(r[3], 1.0f, a);
+  return a;
+}
+
+__device__ __forceinline__ float dot3(const float* r, float x, float y, float z) {
+  float a = r[0] * x;
+  a = fmaf(r[1], y, a);
+  a = fmaf(r[2], z, a);
+  return a;
+}
+
+__device__ __forceinline__ void point_geometry(const CamCtx& c, float px, float py, float pz, int hf, int wf,
+                                               int stride, PointGeom& g) {
+  g.xc = dot4_h(c.m + 0, px, py, pz);
+  g.yc = dot4_h(c.m + 4, px, py, pz);
+  g.zc = dot4_h(c.m + 8, px, py, pz);
+  const float u0 = dot3(c.k + 0, g.xc, g.yc, g.zc);
+  const float u1 = dot3(c.k + 3, g.xc, g.yc, g.zc);
+  const float u2 = dot3(c.k + 6, g.xc, g.yc, g.zc);
+  const float den = u2 + 1e-9f;
+  const float u = u0 / den, v = u1 / den;
+  const float gx = (u - 0.5f) * 2.0f, gy = (v - 0.5f) * 2.0f;
+  float ix = ((gx + 1.0f) / 2.0f) * (float)(wf - 1);
+  float iy = ((gy + 1.0f) / 2.0f) * (float)(hf - 1);
+  ix = fminf((float)(wf - 1), fmaxf(ix, 0.0f));
+  iy = fminf((float)(hf - 1), fmaxf(iy, 0.0f));
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float fx = ix - x0f, fy = iy - y0f;
+  const float ex = 1.0f - fx, ey = 1.0f - fy;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  x0 = min(max(x0, 0), wf - 1);  // also absorbs NaN coordinates (behind-camera points)
+  y0 = min(max(y0, 0), hf - 1);
+  const int x1 = min(x0 + 1, wf - 1), y1 = min(y0 + 1, hf - 1);
+  g.t00 = (y0 * wf + x0) * stride;
+  g.t01 = (y0 * wf + x1) * stride;
+  g.t10 = (y1 * wf + x0) * stride;
+  g.t11 = (y1 * wf + x1) * stride;
+  g.w00 = ey * ex;
+  g.w01 = ey * fx;
+  g.w10 = fy * ex;
+  g.w11 = fy * fx;
+}
+
+// h += bilerp(G)[128 channels starting at `gz`]; lane (j,hh) takes channels 64*hh .. 64*hh+63.
+__device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int hh,
+                                                   f32x16 (&h)[4]) {
+  const float* p00 = gz + g.t00 + 64 * hh;
+  const float* p01 = gz + g.t01 + 64 * hh;
+  const float* p10 = gz + g.t10 + 64 * hh;
+  const float* p11 = gz + g.t11 + 64 * hh;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = 16 * m + 4 * q;
+      const f32x4 a = *(const f32x4*)(p00 + o);
+      const f32x4 b = *(const f32x4*)(p01 + o);
+      const f32x4 c = *(const f32x4*)(p10 + o);
+      const f32x4 d = *(const f32x4*)(p11 + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = a[e] * g.w00;
+        t = fmaf(b[e], g.w01, t);
+        t = fmaf(c[e], g.w10, t);
+        t = fmaf(d[e], g.w11, t);
+        h[m][4 * q + e] += t;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// sin(arg) with exact range reduction in fp64 (arguments reach ~3e4 rad at the top octave of the
+// positional encoding; hardware v_sin_f32 and __sinf are not accurate enough there).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sin_accurate(float arg) {
+  const double u = (double)arg * 0.15915494309189533576888;  // revolutions
+  double ph = u - rint(u);                                   // [-0.5, 0.5], exact
+  if (fabs(ph) > 0.25) ph = copysign(0.5, ph) - ph;          // sin(pi - x) = sin(x)
+  const float y = (float)ph;                                 // |y| <= 0.25
+  const float y2 = y * y;
+  // sin(2*pi*y) = y * P(y^2), Taylor to x^13 (truncation < 6e-10 at |x| = pi/2)
+  float p = 3.8199525848482803f;            // +(2pi)^13/13!
+  p = fmaf(p, y2, -15.094642576822984f);    // -(2pi)^11/11!
+  p = fmaf(p, y2, 42.058693944897634f);     // +(2pi)^9/9!
+  p = fmaf(p, y2, -76.70585975306136f);     // -(2pi)^7/7!
+  p = fmaf(p, y2, 81.60524927607504f);      // +(2pi)^5/5!
+  p = fmaf(p, y2, -41.341702240399755f);    // -(2pi)^3/3!
+  p = fmaf(p, y2, 6.283185307179586f);      // 2pi
+  return y * p;
+}
+
+// Positional encoding in B-operand slot order (see njf_pack: kind 1).  Lane half hh=0 supplies
+// [sin(s_{d,f}) (30) | x | y], hh=1 supplies [sin(s_{d,f} + pi/2) (30) | z | 1].
+// s = fl(fl(2*pi)*x) * 2^f exactly as nerfstudio's NeRFEncoding computes it in fp32.
+__device__ __forceinline__ void positional_encoding(float xc, float yc, float zc, int hh, f32x16 (&pe)[2]) {
+  const float two_pi = 6.2831855f;
+  const float half_pi = hh ? 1.5707964f : 0.0f;
+  const float sx[3] = {two_pi * xc, two_pi * yc, two_pi * zc};
+#pragma unroll
+  for (int s = 0; s < 30; ++s) {
+    const int d = s / 10, f = s % 10;
+    const float arg = sx[d] * (float)(1 << f) + half_pi;
+    pe[s >> 4][s & 15] = sin_accurate(arg);
+  }
+  pe[1][14] = hh ? zc : xc;
+  pe[1][15] = hh ? 1.0f : yc;
+}
+
+// 16 real spherical harmonics (degree 4) of v = 2*((d+1)/2) - 1, tiny-cuda-nn sign convention.
+__device__ __forceinline__ void sh4(float dx, float dy, float dz, float (&o)[16]) {
+  const float x = ((dx + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float y = ((dy + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float z = ((dz + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+  o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+  o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// ------------------------------------------------------------------------------------------
+// One ResnetFC (resnet_fc.py:130-154) on a 32-point tile: 22 weight chunks.
+// bias layout (LDS): [blk: fc0 (128) | fc1 (128)] x 5 | lin_out (32).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __restrict__ bias,
+                                            const float* __restrict__ gz, const PointGeom& g,
+                                            const f32x16 (&pe)[2], int wave, int lane, f32x16 (&out)[1]) {
+  const int hh = lane >> 5;
+  f32x16 h[4], net[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) h[m] = (f32x16)(0.f);
+  {
+    const float* wl = stream_step(st, wave, lane);
+    mma_chunk<4, 2, 0, false, 2>(wl, lane, pe, h);  // lin_in (bias folded into slot 63)
+  }
+  for (int blk = 0; blk < 5; ++blk) {
+    if (blk < 3) add_hoisted_latent(gz + blk * 128, g, hh, h);
+    const float* bl = bias + blk * 256;
+    bias_init<4, true>(bl, hh, net);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<4, 2, 0, true, 4>(wl, lane, h, net);
+    }
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<4, 2, 2, true, 4>(wl, lane, h, net);
+    }
+    bias_init<4, false>(bl + 128, hh, h);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<4, 2, 0, true, 4>(wl, lane, net, h);
+    }
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<4, 2, 2, true, 4>(wl, lane, net, h);
+    }
+  }
+  bias_init<1, true>(bias + 1280, hh, out);
+  {
+    const float* wl = stream_step(st, wave, lane);
+    mma_chunk<1, 4, 0, true, 4>(wl, lane, h, out);
+  }
+}
+
+// colour head (action_decoder_jacobian.py:315-322): one chunk [L0 2048 | L1 4096 | L2 2048],
+// bias (LDS): [L1 (64) | L2 (32)].  cin: hh=0 -> [geo(15), 1], hh=1 -> sh(16).
+__device__ __forceinline__ void color_tile(WeightStream& st, const float* __restrict__ bias, const f32x16 (&cin)[1],
+                                           int wave, int lane, f32x16 (&rgb)[1]) {
+  const int hh = lane >> 5;
+  const float* wl = stream_step(st, wave, lane);
+  f32x16 a[2], b[2];
+  a[0] = (f32x16)(0.f);
+  a[1] = (f32x16)(0.f);
+  mma_chunk<2, 1, 0, false, 1>(wl, lane, cin, a);
+  bias_init<2, true>(bias, hh, b);
+  mma_chunk<2, 2, 0, true, 2>(wl + 2048, lane, a, b);
+  bias_init<1, true>(bias + 64, hh, rgb);
+  mma_chunk<1, 2, 0, true, 2>(wl + 6144, lane, b, rgb);
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers over the 32 points of a tile (both 32-lane halves hold identical data)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float half_min(float v) {
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// inclusive prefix sum over the 32 lanes of each half
+__device__ __forceinline__ float half_scan(float v, int j) {
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const float t = __shfl_up(v, o, 32);
+    if (j >= o) v += t;
+  }
+  return v;
+}
+
+// XCD-aware block remap: consecutive work items (neighbouring rays) stay on one XCD / one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}

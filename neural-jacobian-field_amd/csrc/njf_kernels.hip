@@ -1,0 +1,980 @@
+// Fused HIP kernels + C ABI (include/njf_hip.h) for the NJF volumetric-rendering hot path.
+// gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// (-ffp-contract=off: geometry must round exactly like the ATen ops of the reference path;
+//  every intended fma is written as fmaf()).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/njf_hip.h"
+#include "njf_device.h"
+
+// =============================================================================================
+// error codes
+// =============================================================================================
+enum {
+  NJF_OK = 0,
+  NJF_E_NULL = -1,
+  NJF_E_SHAPE = -2,
+  NJF_E_ACTION_DIM = -3,
+  NJF_E_SAMPLES = -4,
+  NJF_E_DOUT = -5,
+  NJF_E_MODE = -6,
+  NJF_E_GMAP = -7,
+};
+
+extern "C" int njf_abi_version(void) { return NJF_ABI_VERSION; }
+
+extern "C" const char* njf_error_string(int code) {
+  switch (code) {
+    case NJF_OK: return "ok";
+    case NJF_E_NULL: return "required pointer is NULL";
+    case NJF_E_SHAPE: return "invalid shape (negative/zero extent or overflow)";
+    case NJF_E_ACTION_DIM: return "action_dim must be in [1, NJF_MAX_ACTION_DIM]";
+    case NJF_E_SAMPLES: return "samples per ray must be in [1, 256] for the proposal pass / >= 1 for rendering";
+    case NJF_E_DOUT: return "ResnetFC d_out must be in [1, 32]";
+    case NJF_E_MODE: return "unknown mode";
+    case NJF_E_GMAP: return "feature map stride/offset does not cover NJF_ZDIM channels or is not 16-byte aligned";
+    default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown njf error";
+  }
+}
+
+static inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? NJF_OK : (int)e;
+}
+
+// =============================================================================================
+// weight packing
+// =============================================================================================
+struct PackLayer {
+  const float* w;  // [d_out, d_in] row-major (torch Linear)
+  const float* b;  // [d_out] or NULL
+  int d_out, d_in;
+  int mb, kb;  // output / input 32-blocks
+  int kind;    // 0 plain, 1 lin_in (PE slots + bias column), 2 colour layer 0 (geo|1|sh slots)
+  float* dst;  // kb*4*mb*256 floats
+  float* bdst;  // 32*mb floats (logical order, zero padded) or NULL
+};
+
+__global__ void pack_layer_kernel(PackLayer L) {
+  const int n = L.kb * 4 * L.mb * 256;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63;
+    int rest = i >> 8;
+    const int m = rest % L.mb;
+    rest /= L.mb;
+    const int q = rest & 3, kb = rest >> 2;
+    const int ip = lane & 31, kh = lane >> 5;
+    const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);  // logical output row
+    const int k = 16 * L.kb * kh + 16 * kb + 4 * q + e;                              // logical input slot
+    float v = 0.f;
+    if (f < L.d_out) {
+      if (L.kind == 0) {
+        if (k < L.d_in) v = L.w[f * L.d_in + k];
+      } else if (L.kind == 1) {  // slots: [sin 0..29 | x | y || cos 30..59 | z | bias]
+        int ch;
+        if (k < 30) ch = k;
+        else if (k == 30) ch = 60;
+        else if (k == 31) ch = 61;
+        else if (k < 62) ch = k - 2;
+        else if (k == 62) ch = 62;
+        else ch = -1;
+        v = ch >= 0 ? L.w[f * L.d_in + ch] : L.b[f];
+      } else {  // slots: [geo 0..14 | bias || sh 0..15]
+        if (k < 15) v = L.w[f * L.d_in + k];
+        else if (k == 15) v = L.b[f];
+        else v = L.w[f * L.d_in + (k - 1)];
+      }
+    }
+    L.dst[i] = v;
+  }
+  if (L.bdst != nullptr && blockIdx.x == 0) {
+    for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = (f < L.d_out && L.b) ? L.b[f] : 0.f;
+  }
+}
+
+__global__ void fill_kernel(float* p, int n, float v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+// lin_z.{0,1,2}.weight [128,512] -> wz[k * ld + 128*i + f]  (k-major: coalesced B operand of the projection)
+__global__ void pack_linz_kernel(const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
+                                 const float* b2, float* wz, int ld, float* bz) {
+  const int n = 3 * 128 * 512;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i % 384, k = i / 384;
+    const int l = c >> 7, f = c & 127;
+    const float* w = l == 0 ? w0 : (l == 1 ? w1 : w2);
+    wz[(size_t)k * ld + c] = w[f * 512 + k];
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < 384; c += blockDim.x) {
+      const int l = c >> 7, f = c & 127;
+      bz[c] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f];
+    }
+}
+
+static void launch_pack(const float* w, const float* b, int d_out, int d_in, int mb, int kb, int kind, float* dst,
+                        float* bdst, hipStream_t s) {
+  PackLayer L{w, b, d_out, d_in, mb, kb, kind, dst, bdst};
+  const int n = kb * 4 * mb * 256;
+  pack_layer_kernel<<<(n + 255) / 256, 256, 0, s>>>(L);
+}
+
+extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
+                                    float* bz_out, void* stream) {
+  if (!src || !w_out || !b_out) return NJF_E_NULL;
+  if (src->d_out < 1 || src->d_out > 32) return NJF_E_DOUT;
+  if (!src->lin_in_w || !src->lin_in_b || !src->lin_out_w || !src->lin_out_b) return NJF_E_NULL;
+  for (int i = 0; i < 5; ++i)
+    if (!src->fc0_w[i] || !src->fc0_b[i] || !src->fc1_w[i] || !src->fc1_b[i]) return NJF_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  // chunk 0: lin_in 63(+bias) -> 128
+  launch_pack(src->lin_in_w, src->lin_in_b, 128, NJF_PE_DIM, 4, 2, 1, w_out, nullptr, s);
+  for (int i = 0; i < 5; ++i) {
+    float* base = w_out + (size_t)(1 + 4 * i) * NJF_CHUNK_FLOATS;
+    launch_pack(src->fc0_w[i], src->fc0_b[i], 128, 128, 4, 4, 0, base, b_out + 256 * i, s);
+    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, base + 2 * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s);
+  }
+  float* last = w_out + (size_t)21 * NJF_CHUNK_FLOATS;
+  launch_pack(src->lin_out_w, src->lin_out_b, src->d_out, 128, 1, 4, 0, last, b_out + 1280, s);
+  fill_kernel<<<16, 256, 0, s>>>(last + 4096, 4096, 0.f);
+  if (wz_out) {
+    if (!bz_out || wz_ld < 384) return NJF_E_SHAPE;
+    for (int i = 0; i < 3; ++i)
+      if (!src->lin_z_w[i] || !src->lin_z_b[i]) return NJF_E_NULL;
+    pack_linz_kernel<<<256, 256, 0, s>>>(src->lin_z_w[0], src->lin_z_w[1], src->lin_z_w[2], src->lin_z_b[0],
+                                         src->lin_z_b[1], src->lin_z_b[2], wz_out, wz_ld, bz_out);
+  }
+  return launch_status();
+}
+
+extern "C" int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, float* bz_out,
+                                 void* stream) {
+  return njf_pack_resnetfc_ld(src, w_out, b_out, wz_out, 384, bz_out, stream);
+}
+
+extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, void* stream) {
+  if (!src || !w_out || !b_out || !src->w0 || !src->b0 || !src->w1 || !src->b1 || !src->w2 || !src->b2) return NJF_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  launch_pack(src->w0, src->b0, 64, 31, 2, 1, 2, w_out, nullptr, s);
+  launch_pack(src->w1, src->b1, 64, 64, 2, 2, 0, w_out + 2048, b_out, s);
+  launch_pack(src->w2, src->b2, 3, 64, 1, 2, 0, w_out + 6144, b_out + 64, s);
+  return launch_status();
+}
+
+// =============================================================================================
+// feature projection  G[b,p,n] = sum_k F[b,k,p] * wz[k*ld+n] + bz[n]       (fp32 MFMA)
+// =============================================================================================
+// One wave: 32 texels x 128 channels, K = 512 swept two at a time straight from global memory
+// (A: 32 consecutive texels of one channel plane = one 128-B line; B: 32 consecutive output
+// channels of one k row).  Per-image cost (19 GFLOP at 256^2) is ~1% of a frame.
+__global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ feats, const float* __restrict__ wz,
+                                                      const float* __restrict__ bz, int hw, int n, int ld,
+                                                      float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.z;
+  const int p0 = (blockIdx.x * 4 + wave) * 32;
+  const int n0 = blockIdx.y * 128;
+  if (p0 >= hw) return;
+  const int p = min(p0 + j, hw - 1);
+  const float* fa = feats + (size_t)b * 512 * hw + p;
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x16)(0.f);
+  int nn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
+#pragma unroll 4
+  for (int k = 0; k < 512; k += 2) {
+    const float a = fa[(size_t)(k + kh) * hw];
+    const float* wr = wz + (size_t)(k + kh) * ld;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[nn[t]], acc[t], 0, 0, 0);
+  }
+  // D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (texel)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = n0 + 32 * t + j;
+    if (c >= n) continue;
+    const float bias = bz[c];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (p0 + row < hw) out[((size_t)b * hw + p0 + row) * n + c] = acc[t][r] + bias;
+    }
+  }
+}
+
+extern "C" int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, const float* bz, int batch, int hw,
+                                       int n, float* out, void* stream) {
+  if (!feats || !wz || !bz || !out) return NJF_E_NULL;
+  if (batch < 1 || hw < 1 || n < 1 || wz_ld < n) return NJF_E_SHAPE;
+  dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
+  project_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(feats, wz, bz, hw, n, wz_ld, out);
+  return launch_status();
+}
+
+extern "C" int njf_project_features(const float* feats, const float* wz, const float* bz, int batch, int hw, int n,
+                                    float* out, void* stream) {
+  return njf_project_features_ld(feats, wz, n, bz, batch, hw, n, out, stream);
+}
+
+// =============================================================================================
+// ray generation (rendering/geometry.py:117-134, :170-203)
+// =============================================================================================
+__global__ void raygen_kernel(const float* __restrict__ coords, int height, int width, const float* __restrict__ k_inv,
+                              const float* __restrict__ c2w, int batch, int rays, float* __restrict__ origins,
+                              float* __restrict__ directions, float* __restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * rays) return;
+  const int b = i / rays, r = i - b * rays;
+  float x, y;
+  if (coords) {
+    x = coords[2 * (size_t)i];
+    y = coords[2 * (size_t)i + 1];
+  } else {  // get_pixel_coordinates: x = (col + 0.5) / W, y = (row + 0.5) / H, row-major pixels
+    const int row = r / width, col = r - row * width;
+    x = ((float)col + 0.5f) / (float)width;
+    y = ((float)row + 0.5f) / (float)height;
+  }
+  const float* ki = k_inv + b * 9;
+  // einsum("cij,crj->cri", K^-1, [x, y, 1]): fma chain in j order (see point_geometry)
+  float cx = fmaf(ki[2], 1.0f, fmaf(ki[1], y, ki[0] * x));
+  float cy = fmaf(ki[5], 1.0f, fmaf(ki[4], y, ki[3] * x));
+  float cz = fmaf(ki[8], 1.0f, fmaf(ki[7], y, ki[6] * x));
+  cx *= 1.0f;  // unproject multiplies by z = 1 (geometry.py:56)
+  const float nrm = sqrtf(cx * cx + cy * cy + cz * cz);
+  cx /= nrm;
+  cy /= nrm;
+  cz /= nrm;
+  const float* m = c2w + b * 16;
+  const float dx = fmaf(m[3], 0.0f, fmaf(m[2], cz, fmaf(m[1], cy, m[0] * cx)));
+  const float dy = fmaf(m[7], 0.0f, fmaf(m[6], cz, fmaf(m[5], cy, m[4] * cx)));
+  const float dz = fmaf(m[11], 0.0f, fmaf(m[10], cz, fmaf(m[9], cy, m[8] * cx)));
+  origins[3 * (size_t)i + 0] = m[3];
+  origins[3 * (size_t)i + 1] = m[7];
+  origins[3 * (size_t)i + 2] = m[11];
+  directions[3 * (size_t)i + 0] = dx;
+  directions[3 * (size_t)i + 1] = dy;
+  directions[3 * (size_t)i + 2] = dz;
+  if (z) z[i] = cz;
+}
+
+extern "C" int njf_generate_rays(const float* coords, int height, int width, const float* k_inv, const float* c2w,
+                                 int batch, int rays, float* origins, float* directions, float* z, void* stream) {
+  if (!k_inv || !c2w || !origins || !directions) return NJF_E_NULL;
+  if (batch < 1 || rays < 1) return NJF_E_SHAPE;
+  if (!coords && (height < 1 || width < 1 || (long long)height * width != rays)) return NJF_E_SHAPE;
+  const int n = batch * rays;
+  raygen_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(coords, height, width, k_inv, c2w, batch, rays, origins,
+                                                                 directions, z);
+  return launch_status();
+}
+
+// =============================================================================================
+// shared pieces of the fused ray kernels
+// =============================================================================================
+struct RayCommon {
+  const float* origins;
+  const float* directions;
+  int rays_per_batch;
+  int total_rays;
+  NjfCameras cams;
+  NjfFeatureMap gmap;
+};
+
+__device__ __forceinline__ void load_bias_block(const float* __restrict__ src, int n, int dst_off) {
+  for (int i = threadIdx.x; i < n; i += NJF_THREADS) njf_lds[LDS_BIAS + dst_off + i] = src[i];
+}
+
+// alpha compositing weights of one 32-sample tile (ray_samplers.py:77-101), carrying the running
+// optical depth across tiles.
+__device__ __forceinline__ float tile_weights(float delta, float sigma, bool valid, int j, float& carry) {
+  const float ds = (valid && delta > 0.f) ? delta * sigma : 0.f;
+  const float incl = half_scan(ds, j);
+  float excl = __shfl_up(incl, 1, 32);
+  if (j == 0) excl = 0.f;
+  excl += carry;
+  carry += __shfl(incl, 31, 32);
+  const float alpha = 1.0f - expf(-ds);
+  return alpha * expf(-excl);
+}
+
+// inverse-CDF resampling of one ray (ray_samplers.py:351-451).  w' (already annealed, +padding not
+// yet applied) lives in sc[0..s_in); cdf is built in sc[256..256+s_in].  All 64 lanes cooperate.
+__device__ __forceinline__ void pdf_resample_ray(float* __restrict__ sc, const float* __restrict__ bins_in, int s_in,
+                                                 const float* __restrict__ u, int s_out, float* __restrict__ bins_out,
+                                                 int lane, bool store) {
+  float part = 0.f;
+  for (int i = lane; i < s_in; i += 64) part += sc[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+  float wsum = part;
+  const float pad = fmaxf(1e-5f - wsum, 0.f);
+  const float padper = pad / (float)s_in;
+  wsum += pad;
+  // inclusive cumsum of pdf: contiguous run per lane + wave scan of run totals
+  const int per = (s_in + 63) >> 6;
+  const int i0 = lane * per;
+  float run = 0.f;
+  for (int i = 0; i < per; ++i) {
+    const int s = i0 + i;
+    if (s < s_in) run += (sc[s] + padper) / wsum;
+  }
+  float incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  float acc = incl - run;
+  float* cdf = sc + 256;
+  __syncthreads();  // all lanes have read sc[] for wsum before anyone overwrites (uniform control flow)
+  for (int i = 0; i < per; ++i) {
+    const int s = i0 + i;
+    if (s < s_in) {
+      acc += (sc[s] + padper) / wsum;
+      cdf[s + 1] = fminf(1.0f, acc);
+    }
+  }
+  if (lane == 0) cdf[0] = 0.f;
+  __syncthreads();
+  for (int k = lane; k <= s_out; k += 64) {
+    const float uk = u[k];
+    int lo = 0, hi = s_in + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= uk) lo = mid + 1;
+      else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), s_in), above = min(max(lo, 0), s_in);
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float g0 = bins_in[below], g1 = bins_in[above];
+    float t = (uk - c0) / (c1 - c0);
+    if (t != t) t = 0.f;  // nan_to_num(nan=0); +-inf are absorbed by the clip
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    if (store) bins_out[k] = g0 + t * (g1 - g0);
+  }
+}
+
+// =============================================================================================
+// proposal pass
+// =============================================================================================
+struct ProposalArgs {
+  RayCommon rc;
+  int gmap_offset;
+  const float* w_pack;
+  const float* b_pack;
+  const float* bins_in;
+  int bins_per_ray;
+  int s_in;
+  const float* u;
+  int u_per_ray;
+  int s_out;
+  float anneal;
+  float* bins_out;
+  float* weights_out;
+  float* density_out;
+};
+
+__global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ray = wg * NJF_WAVES + wave;
+  const bool ray_ok = ray < a.rc.total_rays;
+  const int rayc = min(ray, a.rc.total_rays - 1);
+  const int b = rayc / a.rc.rays_per_batch;
+
+  load_bias_block(a.b_pack, NJF_RESNET_B_FLOATS, 0);
+  const int tiles = (a.s_in + 31) >> 5;
+  WeightStream st;
+  stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane);
+
+  CamCtx cam;
+  load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
+  const float near = a.rc.cams.z_near[b], far = a.rc.cams.z_far[b];
+  const float ox = a.rc.origins[3 * (size_t)rayc], oy = a.rc.origins[3 * (size_t)rayc + 1],
+              oz = a.rc.origins[3 * (size_t)rayc + 2];
+  const float dx = a.rc.directions[3 * (size_t)rayc], dy = a.rc.directions[3 * (size_t)rayc + 1],
+              dz = a.rc.directions[3 * (size_t)rayc + 2];
+  const float* gz = a.rc.gmap.data + (size_t)b * a.rc.gmap.height * a.rc.gmap.width * a.rc.gmap.stride + a.gmap_offset;
+  const float* bins = a.bins_in + (a.bins_per_ray ? (size_t)rayc * (a.s_in + 1) : 0);
+  float* sc = njf_lds + LDS_SCRATCH + wave * LDS_SCRATCH_PER_WAVE;
+  const float* bias = njf_lds + LDS_BIAS;
+
+  float carry = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    const int s = t * 32 + j;
+    const bool valid = s < a.s_in;
+    const int sc_i = min(s, a.s_in - 1);
+    const float b0 = bins[sc_i], b1 = bins[sc_i + 1];
+    const float start = b0 * far + (1.0f - b0) * near;
+    const float end = b1 * far + (1.0f - b1) * near;
+    const float se = start + end;
+    const float px = ox + (dx * se) / 2.0f, py = oy + (dy * se) / 2.0f, pz = oz + (dz * se) / 2.0f;
+    PointGeom g;
+    point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
+    f32x16 pe[2];
+    positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+    f32x16 out[1];
+    resnet_tile(st, bias, gz, g, pe, wave, lane, out);
+    const float pre = __shfl(out[0][0], j, 64);
+    const float sigma = expf(pre - 1.0f);
+    const float w = tile_weights(end - start, sigma, valid, j, carry);
+    if (valid && hh == 0) {
+      float wa = w;
+      if (a.anneal != 1.0f) wa = powf(w, a.anneal);
+      sc[s] = wa + 0.01f;  // histogram_padding (ray_samplers.py:375)
+      if (ray_ok) {
+        if (a.weights_out) a.weights_out[(size_t)ray * a.s_in + s] = w;
+        if (a.density_out) a.density_out[(size_t)ray * a.s_in + s] = sigma;
+      }
+    }
+  }
+  __syncthreads();
+  const float* u = a.u + (a.u_per_ray ? (size_t)rayc * (a.s_out + 1) : 0);
+  pdf_resample_ray(sc, bins, a.s_in, u, a.s_out, a.bins_out + (size_t)rayc * (a.s_out + 1), lane, ray_ok);
+}
+
+// =============================================================================================
+// decoder evaluation of one tile: density + colour (+ Jacobian / flow)
+// =============================================================================================
+struct TileOut {
+  float sigma;
+  float rgb[3];
+  float flow[3];
+};
+
+// bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian 1312]
+template <bool WITH_J>
+__device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __restrict__ gz_d,
+                                             const float* __restrict__ gz_j, const PointGeom& g, float dirx, float diry,
+                                             float dirz, const float* __restrict__ action, int action_dim, int wave,
+                                             int lane, TileOut& o, f32x16 (&geo)[1], f32x16 (&jac)[1]) {
+  const int j = lane & 31, hh = lane >> 5;
+  const float* bias = njf_lds + LDS_BIAS;
+  f32x16 pe[2];
+  positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+  resnet_tile(st, bias, gz_d, g, pe, wave, lane, geo);
+  o.sigma = expf(__shfl(geo[0][15], j, 64) - 1.0f);
+  {
+    float sh[16];
+    sh4(dirx, diry, dirz, sh);
+    f32x16 cin[1], crgb[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cin[0][r] = hh ? sh[r] : (r < 15 ? geo[0][r] : 1.0f);
+    color_tile(st, bias + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = __shfl(crgb[0][c], j, 64);
+      o.rgb[c] = 1.0f / (1.0f + expf(-x));
+    }
+  }
+  if (WITH_J) {
+    resnet_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
+    // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
+    // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
+    float ph[3] = {0.f, 0.f, 0.f};
+    if (action) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d0 = r, d1 = 16 + r;  // logical output index for hh = 0 / 1
+        const float a0 = (d0 / 3) < action_dim ? action[d0 / 3] : 0.f;
+        const float a1 = (d1 / 3) < action_dim ? action[d1 / 3] : 0.f;
+        ph[r % 3] = fmaf(jac[0][r], hh ? a1 : a0, ph[r % 3]);
+      }
+    }
+    // hh=0: spatial index s = r%3 ; hh=1: s = (16+r)%3 = (r+1)%3  ->  phase (s+2)%3
+    float mine[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) mine[s] = hh ? ph[(s + 2) % 3] : ph[s];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) o.flow[s] = mine[s] + __shfl_xor(mine[s], 32, 64);
+  } else {
+    o.flow[0] = o.flow[1] = o.flow[2] = 0.f;
+  }
+}
+
+// =============================================================================================
+// final pass: decoder + compositing
+// =============================================================================================
+struct RenderArgs {
+  RayCommon rc;
+  int goff_d, goff_j;
+  const float* w_all;  // [density 22 chunks | colour 1 | jacobian 22] contiguous
+  const float* b_d;
+  const float* b_c;
+  const float* b_j;
+  const float* bins;
+  int samples;
+  NjfRenderOutputs out;
+};
+
+template <bool WITH_J>
+__global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ray = wg * NJF_WAVES + wave;
+  const bool ray_ok = ray < a.rc.total_rays;
+  const int rayc = min(ray, a.rc.total_rays - 1);
+  const int b = rayc / a.rc.rays_per_batch;
+  const int S = a.samples;
+
+  load_bias_block(a.b_d, NJF_RESNET_B_FLOATS, 0);
+  load_bias_block(a.b_c, NJF_COLOR_B_FLOATS, NJF_RESNET_B_FLOATS);
+  if (WITH_J) load_bias_block(a.b_j, NJF_RESNET_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
+  const int tiles = (S + 31) >> 5;
+  WeightStream st;
+  stream_begin(st, a.w_all, WITH_J ? 2 * NJF_RESNET_CHUNKS + 1 : NJF_RESNET_CHUNKS + 1, tiles, wave, lane);
+
+  CamCtx cam;
+  load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
+  const float near = a.rc.cams.z_near[b], far = a.rc.cams.z_far[b];
+  const float ox = a.rc.origins[3 * (size_t)rayc], oy = a.rc.origins[3 * (size_t)rayc + 1],
+              oz = a.rc.origins[3 * (size_t)rayc + 2];
+  const float dx = a.rc.directions[3 * (size_t)rayc], dy = a.rc.directions[3 * (size_t)rayc + 1],
+              dz = a.rc.directions[3 * (size_t)rayc + 2];
+  const size_t gbase = (size_t)b * a.rc.gmap.height * a.rc.gmap.width * a.rc.gmap.stride;
+  const float* gz_d = a.rc.gmap.data + gbase + a.goff_d;
+  const float* gz_j = a.rc.gmap.data + gbase + a.goff_j;
+  const float* bins = a.bins + (size_t)rayc * (S + 1);
+  const int A = a.rc.cams.action_dim;
+  const float* action = a.rc.cams.action ? a.rc.cams.action + (size_t)b * A : nullptr;
+
+  float carry = 0.f;
+  float acc_rgb[3] = {0.f, 0.f, 0.f}, acc_w = 0.f, acc_wt = 0.f;
+  float acc_p[3] = {0.f, 0.f, 0.f}, acc_pw[3] = {0.f, 0.f, 0.f};
+  float tmin = 3.0e38f, tmax = -3.0e38f;
+  f32x16 acc_j = (f32x16)(0.f);
+  const bool want_af = WITH_J && a.out.action_features != nullptr;
+
+  for (int t = 0; t < tiles; ++t) {
+    const int s = t * 32 + j;
+    const bool valid = s < S;
+    const int sc_i = min(s, S - 1);
+    const float b0 = bins[sc_i], b1 = bins[sc_i + 1];
+    const float start = b0 * far + (1.0f - b0) * near;
+    const float end = b1 * far + (1.0f - b1) * near;
+    const float se = start + end;
+    const float tm = se / 2.0f;
+    const float px = ox + (dx * se) / 2.0f, py = oy + (dy * se) / 2.0f, pz = oz + (dz * se) / 2.0f;
+    PointGeom g;
+    point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
+    TileOut o;
+    f32x16 geo[1], jac[1];
+    decoder_tile<WITH_J>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac);
+    const float w = tile_weights(end - start, o.sigma, valid, j, carry);
+    if (valid) {
+      acc_w += w;
+      acc_wt = fmaf(w, tm, acc_wt);
+      tmin = fminf(tmin, tm);
+      tmax = fmaxf(tmax, tm);
+      const float pp[3] = {px, py, pz};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc_rgb[c] = fmaf(w, o.rgb[c], acc_rgb[c]);
+        acc_p[c] = fmaf(w, pp[c], acc_p[c]);
+        acc_pw[c] = fmaf(w, pp[c] + o.flow[c], acc_pw[c]);
+      }
+      if (want_af) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_j[r] = fmaf(w, jac[0][r], acc_j[r]);
+      }
+      if (ray_ok) {
+        const size_t si = (size_t)ray * S + s;
+        if (hh == 0) {
+          if (a.out.weights) a.out.weights[si] = w;
+          if (a.out.density) a.out.density[si] = o.sigma;
+          if (a.out.color) {
+            a.out.color[3 * si] = o.rgb[0];
+            a.out.color[3 * si + 1] = o.rgb[1];
+            a.out.color[3 * si + 2] = o.rgb[2];
+          }
+          if (a.out.sample_flow) {
+            a.out.sample_flow[3 * si] = o.flow[0];
+            a.out.sample_flow[3 * si + 1] = o.flow[1];
+            a.out.sample_flow[3 * si + 2] = o.flow[2];
+          }
+        }
+        if (WITH_J && a.out.jacobian) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = 16 * hh + r;
+            if (d < 3 * A) a.out.jacobian[si * (3 * A) + d] = jac[0][r];
+          }
+        }
+      }
+    }
+  }
+
+  // reduce over the ray's samples (32 lanes of a half; both halves hold identical per-sample data)
+  acc_w = half_sum(acc_w);
+  acc_wt = half_sum(acc_wt);
+  tmin = half_min(tmin);
+  tmax = half_max(tmax);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    acc_rgb[c] = half_sum(acc_rgb[c]);
+    acc_p[c] = half_sum(acc_p[c]);
+    acc_pw[c] = half_sum(acc_pw[c]);
+  }
+  if (want_af) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_j[r] = half_sum(acc_j[r]);
+    if (ray_ok && j == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = 16 * hh + r;
+        if (d < 3 * A) a.out.action_features[(size_t)ray * (3 * A) + d] = acc_j[r];
+      }
+    }
+  }
+  if (ray_ok && lane == 0) {
+    if (a.out.rgb) {
+      a.out.rgb[3 * (size_t)ray] = acc_rgb[0];
+      a.out.rgb[3 * (size_t)ray + 1] = acc_rgb[1];
+      a.out.rgb[3 * (size_t)ray + 2] = acc_rgb[2];
+    }
+    if (a.out.depth) a.out.depth[ray] = acc_wt / (acc_w + 1e-10f);
+    if (a.out.step_minmax) {
+      a.out.step_minmax[2 * (size_t)ray] = tmin;
+      a.out.step_minmax[2 * (size_t)ray + 1] = tmax;
+    }
+    if (a.out.pos) {
+      a.out.pos[3 * (size_t)ray] = acc_p[0];
+      a.out.pos[3 * (size_t)ray + 1] = acc_p[1];
+      a.out.pos[3 * (size_t)ray + 2] = acc_p[2];
+    }
+    if (a.out.pos_warped) {
+      a.out.pos_warped[3 * (size_t)ray] = acc_pw[0];
+      a.out.pos_warped[3 * (size_t)ray + 1] = acc_pw[1];
+      a.out.pos_warped[3 * (size_t)ray + 2] = acc_pw[2];
+    }
+    if (a.out.flow && a.rc.cams.trgt_w2c && a.rc.cams.trgt_k) {
+      // project_world_coords_to_camera (rendering/geometry.py:206-215) of both means
+      const float* m = a.rc.cams.trgt_w2c + b * 16;
+      const float* k = a.rc.cams.trgt_k + b * 9;
+      float uv[2][2];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const float* p = v ? acc_pw : acc_p;
+        const float xc = dot4_h(m + 0, p[0], p[1], p[2]);
+        const float yc = dot4_h(m + 4, p[0], p[1], p[2]);
+        const float zc = dot4_h(m + 8, p[0], p[1], p[2]);
+        const float u0 = dot3(k + 0, xc, yc, zc), u1 = dot3(k + 3, xc, yc, zc), u2 = dot3(k + 6, xc, yc, zc);
+        uv[v][0] = u0 / (u2 + 1e-9f);
+        uv[v][1] = u1 / (u2 + 1e-9f);
+      }
+      a.out.flow[2 * (size_t)ray] = uv[1][0] - uv[0][0];
+      a.out.flow[2 * (size_t)ray + 1] = uv[1][1] - uv[0][1];
+    }
+  }
+}
+
+// =============================================================================================
+// point-list evaluation
+// =============================================================================================
+struct PointsArgs {
+  const float* xyz;
+  const float* dirs;
+  int points_per_batch;
+  int total_points;
+  NjfCameras cams;
+  NjfFeatureMap gmap;
+  int goff_d, goff_j;
+  const float* w_all;
+  const float* b_d;
+  const float* b_c;
+  const float* b_j;
+  float* density;
+  float* color;
+  float* flow;
+  float* jacobian;
+  float* geo;
+};
+
+// MODE 0: proposal net (density only); 1: decoder without Jacobian head; 2: full decoder
+template <int MODE>
+__global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = wg * NJF_WAVES + wave;
+  const int p = tile * 32 + j;
+  const bool ok = p < a.total_points;
+  const int pc = min(p, a.total_points - 1);
+  const int b = pc / a.points_per_batch;  // per lane: a tile may straddle batch elements
+
+  load_bias_block(a.b_d, NJF_RESNET_B_FLOATS, 0);
+  if (MODE >= 1) load_bias_block(a.b_c, NJF_COLOR_B_FLOATS, NJF_RESNET_B_FLOATS);
+  if (MODE == 2) load_bias_block(a.b_j, NJF_RESNET_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
+  WeightStream st;
+  stream_begin(st, a.w_all, MODE == 0 ? NJF_RESNET_CHUNKS : (MODE == 1 ? NJF_RESNET_CHUNKS + 1 : 2 * NJF_RESNET_CHUNKS + 1),
+               1, wave, lane);
+  CamCtx cam;
+  load_ctx(a.cams.ctxt_w2c, a.cams.ctxt_k, b, cam);
+  const float px = a.xyz[3 * (size_t)pc], py = a.xyz[3 * (size_t)pc + 1], pz = a.xyz[3 * (size_t)pc + 2];
+  PointGeom g;
+  point_geometry(cam, px, py, pz, a.gmap.height, a.gmap.width, a.gmap.stride, g);
+  const size_t gbase = (size_t)b * a.gmap.height * a.gmap.width * a.gmap.stride;
+  const float* bias = njf_lds + LDS_BIAS;
+  if (MODE == 0) {
+    f32x16 pe[2], out[1];
+    positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+    resnet_tile(st, bias, a.gmap.data + gbase + a.goff_d, g, pe, wave, lane, out);
+    if (ok && hh == 0 && a.density) a.density[p] = expf(out[0][0] - 1.0f);
+  } else {
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    if (a.dirs) {
+      dx = a.dirs[3 * (size_t)pc];
+      dy = a.dirs[3 * (size_t)pc + 1];
+      dz = a.dirs[3 * (size_t)pc + 2];
+    }
+    const int A = a.cams.action_dim;
+    const float* action = a.cams.action ? a.cams.action + (size_t)b * A : nullptr;
+    TileOut o;
+    f32x16 geo[1], jac[1];
+    // NOTE: `action` is per lane here (tiles may straddle batch elements)
+    decoder_tile<MODE == 2>(st, a.gmap.data + gbase + a.goff_d, a.gmap.data + gbase + a.goff_j, g, dx, dy, dz, action, A,
+                            wave, lane, o, geo, jac);
+    if (ok) {
+      if (hh == 0) {
+        if (a.density) a.density[p] = o.sigma;
+        if (a.color) {
+          a.color[3 * (size_t)p] = o.rgb[0];
+          a.color[3 * (size_t)p + 1] = o.rgb[1];
+          a.color[3 * (size_t)p + 2] = o.rgb[2];
+        }
+        if (a.flow && MODE == 2) {
+          a.flow[3 * (size_t)p] = o.flow[0];
+          a.flow[3 * (size_t)p + 1] = o.flow[1];
+          a.flow[3 * (size_t)p + 2] = o.flow[2];
+        }
+        if (a.geo) {
+#pragma unroll
+          for (int r = 0; r < 15; ++r) a.geo[15 * (size_t)p + r] = geo[0][r];
+        }
+      }
+      if (MODE == 2 && a.jacobian) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = 16 * hh + r;
+          if (d < 3 * A) a.jacobian[(size_t)p * (3 * A) + d] = jac[0][r];
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// stand-alone sampler ops
+// =============================================================================================
+__global__ void __launch_bounds__(256) alpha_weights_kernel(const float* __restrict__ deltas,
+                                                            const float* __restrict__ dens, int rays, int samples,
+                                                            float* __restrict__ weights) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // one wave per ray, both halves duplicate
+  const int lane = threadIdx.x & 63, j = lane & 31;
+  if (wave >= rays) return;
+  float carry = 0.f;
+  for (int t = 0; t * 32 < samples; ++t) {
+    const int s = t * 32 + j;
+    const bool valid = s < samples;
+    const size_t i = (size_t)wave * samples + min(s, samples - 1);
+    const float w = tile_weights(deltas[i], dens[i], valid, j, carry);
+    if (valid && lane < 32) weights[i] = w;
+  }
+}
+
+extern "C" int njf_alpha_weights(const float* deltas, const float* densities, int rays, int samples, float* weights,
+                                 void* stream) {
+  if (!deltas || !densities || !weights) return NJF_E_NULL;
+  if (rays < 1 || samples < 1) return NJF_E_SHAPE;
+  alpha_weights_kernel<<<(rays + 3) / 4, 256, 0, (hipStream_t)stream>>>(deltas, densities, rays, samples, weights);
+  return launch_status();
+}
+
+struct PdfArgs {
+  const float* weights;
+  const float* bins_in;
+  int bins_per_ray, s_in;
+  const float* u;
+  int u_per_ray, s_out;
+  float anneal;
+  int rays;
+  float* bins_out;
+};
+
+__global__ void __launch_bounds__(NJF_THREADS) pdf_kernel(PdfArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * NJF_WAVES + wave;
+  const bool ok = ray < a.rays;
+  const int rayc = min(ray, a.rays - 1);
+  float* sc = njf_lds + LDS_SCRATCH + wave * LDS_SCRATCH_PER_WAVE;
+  for (int s = lane; s < a.s_in; s += 64) {
+    float w = a.weights[(size_t)rayc * a.s_in + s];
+    if (a.anneal != 1.0f) w = powf(w, a.anneal);
+    sc[s] = w + 0.01f;
+  }
+  __syncthreads();
+  const float* bins = a.bins_in + (a.bins_per_ray ? (size_t)rayc * (a.s_in + 1) : 0);
+  const float* u = a.u + (a.u_per_ray ? (size_t)rayc * (a.s_out + 1) : 0);
+  pdf_resample_ray(sc, bins, a.s_in, u, a.s_out, a.bins_out + (size_t)rayc * (a.s_out + 1), lane, ok);
+}
+
+extern "C" int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ray, int s_in, const float* u,
+                                int u_per_ray, int s_out, float anneal, int rays, float* bins_out, void* stream) {
+  if (!weights || !bins_in || !u || !bins_out) return NJF_E_NULL;
+  if (rays < 1 || s_out < 1) return NJF_E_SHAPE;
+  if (s_in < 1 || s_in > 256) return NJF_E_SAMPLES;
+  PdfArgs a{weights, bins_in, bins_per_ray, s_in, u, u_per_ray, s_out, anneal, rays, bins_out};
+  pdf_kernel<<<(rays + NJF_WAVES - 1) / NJF_WAVES, NJF_THREADS, LDS_TOTAL_FLOATS * sizeof(float), (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+// =============================================================================================
+// launchers of the fused kernels
+// =============================================================================================
+static int check_common(const float* origins, const float* directions, int rays_per_batch, const NjfCameras* cams,
+                        const NjfFeatureMap* gmap) {
+  if (!origins || !directions || !cams || !gmap) return NJF_E_NULL;
+  if (!cams->ctxt_w2c || !cams->ctxt_k || !cams->z_near || !cams->z_far || !gmap->data) return NJF_E_NULL;
+  if (rays_per_batch < 1 || cams->batch < 1 || gmap->height < 1 || gmap->width < 1) return NJF_E_SHAPE;
+  if ((long long)rays_per_batch * cams->batch > 0x7fffffffLL / 64) return NJF_E_SHAPE;
+  return NJF_OK;
+}
+
+static int check_gmap(const NjfFeatureMap* gmap, int off) {
+  if (off < 0 || (off & 3) || (gmap->stride & 3) || off + NJF_ZDIM > gmap->stride) return NJF_E_GMAP;
+  return NJF_OK;
+}
+
+template <typename K, typename A>
+static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s) {
+  static_assert(sizeof(A) <= 4096, "kernel args too large");
+  const int grid = (work_items + NJF_WAVES - 1) / NJF_WAVES;
+  const size_t lds = LDS_TOTAL_FLOATS * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  kernel<<<grid, NJF_THREADS, lds, s>>>(args);
+  return launch_status();
+}
+
+extern "C" int njf_proposal_forward(const float* origins, const float* directions, int rays_per_batch,
+                                    const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
+                                    const float* w_pack, const float* b_pack, const float* bins_in, int bins_per_ray,
+                                    int s_in, const float* u, int u_per_ray, int s_out, float anneal, float* bins_out,
+                                    float* weights_out, float* density_out, void* stream) {
+  int rc = check_common(origins, directions, rays_per_batch, cams, gmap);
+  if (rc) return rc;
+  if (!w_pack || !b_pack || !bins_in || !u || !bins_out) return NJF_E_NULL;
+  if (s_in < 1 || s_in > 256 || s_out < 1) return NJF_E_SAMPLES;
+  if ((rc = check_gmap(gmap, gmap_offset))) return rc;
+  ProposalArgs a;
+  a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
+  a.gmap_offset = gmap_offset;
+  a.w_pack = w_pack;
+  a.b_pack = b_pack;
+  a.bins_in = bins_in;
+  a.bins_per_ray = bins_per_ray;
+  a.s_in = s_in;
+  a.u = u;
+  a.u_per_ray = u_per_ray;
+  a.s_out = s_out;
+  a.anneal = anneal;
+  a.bins_out = bins_out;
+  a.weights_out = weights_out;
+  a.density_out = density_out;
+  return launch_fused(proposal_kernel, a, a.rc.total_rays, (hipStream_t)stream);
+}
+
+// The decoder blobs must be one allocation laid out [density | colour | jacobian] (what
+// njf_pack_* write when given consecutive destinations); the launcher verifies contiguity.
+static int check_contiguous(const float* w_d, const float* w_c, const float* w_j, bool with_j) {
+  if (w_c != w_d + NJF_RESNET_W_FLOATS) return NJF_E_SHAPE;
+  if (with_j && w_j != w_c + NJF_COLOR_W_FLOATS) return NJF_E_SHAPE;
+  return NJF_OK;
+}
+
+extern "C" int njf_render_forward(const float* origins, const float* directions, int rays_per_batch,
+                                  const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset_density,
+                                  int gmap_offset_jacobian, const float* w_density, const float* b_density,
+                                  const float* w_color, const float* b_color, const float* w_jacobian,
+                                  const float* b_jacobian, const float* bins, int samples, const NjfRenderOutputs* out,
+                                  void* stream) {
+  int rc = check_common(origins, directions, rays_per_batch, cams, gmap);
+  if (rc) return rc;
+  if (!w_density || !b_density || !w_color || !b_color || !bins || !out) return NJF_E_NULL;
+  if (samples < 1) return NJF_E_SAMPLES;
+  const bool with_j = w_jacobian != nullptr;
+  if (with_j && !b_jacobian) return NJF_E_NULL;
+  if (with_j && (cams->action_dim < 1 || cams->action_dim > NJF_MAX_ACTION_DIM)) return NJF_E_ACTION_DIM;
+  if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
+  if (with_j && (rc = check_gmap(gmap, gmap_offset_jacobian))) return rc;
+  if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
+  RenderArgs a;
+  a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
+  a.goff_d = gmap_offset_density;
+  a.goff_j = with_j ? gmap_offset_jacobian : gmap_offset_density;
+  a.w_all = w_density;
+  a.b_d = b_density;
+  a.b_c = b_color;
+  a.b_j = b_jacobian;
+  a.bins = bins;
+  a.samples = samples;
+  a.out = *out;
+  if (with_j) return launch_fused(render_kernel<true>, a, a.rc.total_rays, (hipStream_t)stream);
+  return launch_fused(render_kernel<false>, a, a.rc.total_rays, (hipStream_t)stream);
+}
+
+extern "C" int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
+                                  const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
+                                  const float* w_density, const float* b_density, const float* w_color,
+                                  const float* b_color, const float* w_jacobian, const float* b_jacobian, float* density,
+                                  float* color, float* flow, float* jacobian, float* geo, void* stream) {
+  if (!xyz || !cams || !gmap || !w_density || !b_density) return NJF_E_NULL;
+  if (!cams->ctxt_w2c || !cams->ctxt_k || !gmap->data) return NJF_E_NULL;
+  if (points_per_batch < 1 || cams->batch < 1) return NJF_E_SHAPE;
+  if (mode != 0 && mode != 1) return NJF_E_MODE;
+  int rc;
+  if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
+  PointsArgs a;
+  a.xyz = xyz;
+  a.dirs = dirs;
+  a.points_per_batch = points_per_batch;
+  a.total_points = points_per_batch * cams->batch;
+  a.cams = *cams;
+  a.gmap = *gmap;
+  a.goff_d = gmap_offset_density;
+  a.goff_j = gmap_offset_jacobian;
+  a.w_all = w_density;
+  a.b_d = b_density;
+  a.b_c = b_color;
+  a.b_j = b_jacobian;
+  a.density = density;
+  a.color = color;
+  a.flow = flow;
+  a.jacobian = jacobian;
+  a.geo = geo;
+  const int tiles = (a.total_points + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) return launch_fused(points_kernel<0>, a, tiles, s);
+  if (!w_color || !b_color) return NJF_E_NULL;
+  const bool with_j = w_jacobian != nullptr;
+  if (with_j) {
+    if (!b_jacobian) return NJF_E_NULL;
+    if (cams->action_dim < 1 || cams->action_dim > NJF_MAX_ACTION_DIM) return NJF_E_ACTION_DIM;
+    if ((rc = check_gmap(gmap, gmap_offset_jacobian))) return rc;
+  }
+  if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
+  if (with_j) return launch_fused(points_kernel<2>, a, tiles, s);
+  return launch_fused(points_kernel<1>, a, tiles, s);
+}

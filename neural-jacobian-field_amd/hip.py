@@ -1,0 +1,249 @@
+"""ctypes binding of ``libnjf_hip.so`` (C ABI in ``include/njf_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute call goes through
+the C ABI.  There is **no CPU fallback**: if the library is missing or a tensor is not a
+contiguous fp32 device tensor the call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnjf_hip.so")
+
+MAX_ACTION_DIM = 10
+ZDIM = 384
+RESNET_W_FLOATS = 22 * 8192
+RESNET_B_FLOATS = 10 * 128 + 32
+COLOR_W_FLOATS = 8192
+COLOR_B_FLOATS = 96
+
+_vp = C.c_void_p
+
+
+class ResnetFcWeights(C.Structure):
+    _fields_ = [
+        ("lin_in_w", _vp), ("lin_in_b", _vp),
+        ("fc0_w", _vp * 5), ("fc0_b", _vp * 5), ("fc1_w", _vp * 5), ("fc1_b", _vp * 5),
+        ("lin_z_w", _vp * 3), ("lin_z_b", _vp * 3),
+        ("lin_out_w", _vp), ("lin_out_b", _vp), ("d_out", C.c_int),
+    ]
+
+
+class ColorHeadWeights(C.Structure):
+    _fields_ = [("w0", _vp), ("b0", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp)]
+
+
+class Cameras(C.Structure):
+    _fields_ = [
+        ("ctxt_w2c", _vp), ("ctxt_k", _vp), ("trgt_w2c", _vp), ("trgt_k", _vp),
+        ("z_near", _vp), ("z_far", _vp), ("action", _vp), ("batch", C.c_int), ("action_dim", C.c_int),
+    ]
+
+
+class FeatureMap(C.Structure):
+    _fields_ = [("data", _vp), ("height", C.c_int), ("width", C.c_int), ("stride", C.c_int)]
+
+
+class RenderOutputs(C.Structure):
+    _fields_ = [(n, _vp) for n in (
+        "rgb", "depth", "step_minmax", "flow", "pos", "pos_warped", "action_features",
+        "weights", "density", "color", "sample_flow", "jacobian")]
+
+
+_lib = None
+
+_SIGNATURES = {
+    "njf_abi_version": ([], C.c_int),
+    "njf_error_string": ([C.c_int], C.c_char_p),
+    "njf_pack_resnetfc": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "njf_pack_resnetfc_ld": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
+    "njf_pack_color_head": ([C.POINTER(ColorHeadWeights), _vp, _vp, _vp], C.c_int),
+    "njf_project_features": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
+    "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
+                              _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp], C.c_int),
+    "njf_render_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), _vp], C.c_int),
+    "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library() -> C.CDLL:
+    """Load ``libnjf_hip.so`` (built by ``__graft_entry__.build()``); raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+                "g.build()'`).  There is no CPU fallback for the rendering hot path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = lib
+    return _lib
+
+
+def _check(code: int) -> None:
+    if code == 0:
+        return
+    msg = load_library().njf_error_string(code).decode()
+    if code < 0:
+        raise ValueError(f"njf_hip: {msg} (code {code})")
+    raise RuntimeError(f"njf_hip: {msg} (hipError_t {code})")
+
+
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError(f"njf_hip: {name} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise ValueError(f"njf_hip: {name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"njf_hip: {name} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_cameras(ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c=None, trgt_k=None, action=None, keep=None) -> Cameras:
+    batch = ctxt_w2c.shape[0]
+    a_dim = 0 if action is None else action.shape[-1]
+    cams = Cameras(_ptr(ctxt_w2c, "ctxt_w2c"), _ptr(ctxt_k, "ctxt_k"), _ptr(trgt_w2c, "trgt_w2c"),
+                   _ptr(trgt_k, "trgt_k"), _ptr(z_near, "z_near"), _ptr(z_far, "z_far"), _ptr(action, "action"),
+                   batch, a_dim)
+    cams._keep = (ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c, trgt_k, action)  # keep tensors alive
+    return cams
+
+
+def make_feature_map(gmap: torch.Tensor) -> FeatureMap:
+    """gmap: [B, Hf, Wf, C] channels-last hoisted map."""
+    fm = FeatureMap(_ptr(gmap, "gmap"), gmap.shape[1], gmap.shape[2], gmap.shape[3])
+    fm._keep = gmap
+    return fm
+
+
+# --------------------------------------------------------------------------------------
+# packing
+# --------------------------------------------------------------------------------------
+def pack_resnetfc(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, b_out: torch.Tensor,
+                  wz: Optional[torch.Tensor] = None, wz_col: int = 0, bz: Optional[torch.Tensor] = None) -> None:
+    """``params[prefix + 'lin_in.weight']`` ... (reference ResnetFC names) -> packed blobs.
+
+    ``wz`` [512, ld] / ``bz`` [ld] receive this net's three lin_z layers at columns ``wz_col .. wz_col+383``."""
+    def p(name):
+        return _ptr(params[prefix + name].detach(), prefix + name)
+
+    src = ResnetFcWeights()
+    src.lin_in_w, src.lin_in_b = p("lin_in.weight"), p("lin_in.bias")
+    for i in range(5):
+        src.fc0_w[i], src.fc0_b[i] = p(f"blocks.{i}.fc_0.weight"), p(f"blocks.{i}.fc_0.bias")
+        src.fc1_w[i], src.fc1_b[i] = p(f"blocks.{i}.fc_1.weight"), p(f"blocks.{i}.fc_1.bias")
+    for i in range(3):
+        src.lin_z_w[i], src.lin_z_b[i] = p(f"lin_z.{i}.weight"), p(f"lin_z.{i}.bias")
+    src.lin_out_w, src.lin_out_b = p("lin_out.weight"), p("lin_out.bias")
+    src.d_out = params[prefix + "lin_out.weight"].shape[0]
+    wz_ptr = bz_ptr = None
+    ld = ZDIM
+    if wz is not None:
+        ld = wz.shape[1]
+        if wz.shape[0] != 512 or wz_col + ZDIM > ld or bz is None or bz.numel() != ld:
+            raise ValueError("njf_hip: wz must be [512, ld] with wz_col + 384 <= ld and bz [ld]")
+        wz_ptr = _ptr(wz, "wz") + 4 * wz_col
+        bz_ptr = _ptr(bz, "bz") + 4 * wz_col
+    _check(load_library().njf_pack_resnetfc_ld(C.byref(src), _ptr(w_out), _ptr(b_out), wz_ptr, ld, bz_ptr, _stream()))
+
+
+def pack_color_head(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, b_out: torch.Tensor) -> None:
+    def p(name):
+        return _ptr(params[prefix + name].detach(), prefix + name)
+
+    src = ColorHeadWeights(p("0.weight"), p("0.bias"), p("2.weight"), p("2.bias"), p("4.weight"), p("4.bias"))
+    _check(load_library().njf_pack_color_head(C.byref(src), _ptr(w_out), _ptr(b_out), _stream()))
+
+
+def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor) -> None:
+    """feats [B,512,Hf,Wf]; wz [512,N]; bz [N]; out [B,Hf,Wf,N]."""
+    b, k, hf, wf = feats.shape
+    n = wz.shape[1]
+    if k != 512 or wz.shape[0] != 512 or tuple(out.shape) != (b, hf, wf, n):
+        raise ValueError("njf_hip: project_features shape mismatch")
+    _check(load_library().njf_project_features_ld(_ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out), _stream()))
+
+
+# --------------------------------------------------------------------------------------
+# ops
+# --------------------------------------------------------------------------------------
+def generate_rays(coords, height, width, k_inv, c2w, origins, directions, z) -> None:
+    batch, rays = origins.shape[0], origins.shape[1]
+    _check(load_library().njf_generate_rays(_ptr(coords), height, width, _ptr(k_inv), _ptr(c2w), batch, rays,
+                                            _ptr(origins), _ptr(directions), _ptr(z), _stream()))
+
+
+def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_offset: int, w_pack, b_pack,
+                     bins_in, s_in: int, u, s_out: int, anneal: float, bins_out, weights_out=None,
+                     density_out=None) -> None:
+    rays_per_batch = origins.shape[1]
+    _check(load_library().njf_proposal_forward(
+        _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), gmap_offset,
+        _ptr(w_pack), _ptr(b_pack), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u), int(u.dim() > 1), s_out,
+        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), _stream()))
+
+
+def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int,
+                   w_all: torch.Tensor, b_density, b_color, b_jacobian, bins, samples: int, outputs: Dict[str, torch.Tensor],
+                   with_jacobian: bool = True) -> None:
+    """``w_all`` is the single allocation [density | colour | jacobian] of packed weights."""
+    rays_per_batch = origins.shape[1]
+    out = RenderOutputs()
+    for name, _ in RenderOutputs._fields_:
+        setattr(out, name, _ptr(outputs.get(name), name))
+    base = _ptr(w_all, "w_all")
+    w_c = base + 4 * RESNET_W_FLOATS
+    w_j = w_c + 4 * COLOR_W_FLOATS if with_jacobian else None
+    _check(load_library().njf_render_forward(
+        _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian,
+        base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_jacobian else None,
+        _ptr(bins), samples, C.byref(out), _stream()))
+
+
+def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int, mode: int,
+                   w_all, b_density, b_color=None, b_jacobian=None, with_jacobian: bool = False, density=None, color=None,
+                   flow=None, jacobian=None, geo=None) -> None:
+    points_per_batch = xyz.shape[1]
+    base = _ptr(w_all, "w_all")
+    w_c = base + 4 * RESNET_W_FLOATS if mode == 1 else None
+    w_j = (w_c + 4 * COLOR_W_FLOATS) if (mode == 1 and with_jacobian) else None
+    _check(load_library().njf_points_forward(
+        _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
+        base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if w_j else None,
+        _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo), _stream()))
+
+
+def alpha_weights(deltas, densities, weights) -> None:
+    samples = deltas.shape[-1]
+    rays = deltas.numel() // samples
+    _check(load_library().njf_alpha_weights(_ptr(deltas), _ptr(densities), rays, samples, _ptr(weights), _stream()))
+
+
+def pdf_resample(weights, bins_in, u, s_out: int, anneal: float, bins_out) -> None:
+    s_in = weights.shape[-1]
+    rays = weights.numel() // s_in
+    _check(load_library().njf_pdf_resample(_ptr(weights), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u),
+                                           int(u.dim() > 1), s_out, float(anneal), rays, _ptr(bins_out), _stream()))

@@ -356,8 +356,9 @@ def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_l
 
 
 def trunc_exp_density(pre: Tensor) -> Tensor:
-    """NJF/model_components/activations.py:13-38: forward of trunc_exp(x - 1) is exp(x - 1) in fp32."""
-    return torch.exp((pre - 1).float())
+    """NJF/model_components/activations.py:13-38: forward of trunc_exp(x - 1) is exp(x - 1) (fp32 cast only
+    under autocast, which the reference path never enables)."""
+    return torch.exp(pre - 1)
 
 
 # --------------------------------------------------------------------------------------
@@ -570,14 +571,22 @@ def model_forward(params: Params, *, features: Optional[Tensor] = None, input_im
     samples, weights_list, samples_list = proposal_sampling(
         origins, directions, near, far, fns, num_proposal_samples, num_nerf_samples, anneal, training, single_jitter
     )
+    res = final_stage(params, samples, directions, enc, trgt_c2w, trgt_k_pix, decoder_kind)
+    res.weights_list = weights_list + res.weights_list
+    res.samples_list = samples_list + res.samples_list
+    return res
+
+
+def final_stage(params: Params, samples: Samples, directions: Tensor, enc: PixelEncoding, trgt_c2w: Tensor,
+                trgt_k_pix: Tensor, decoder_kind: str = "jacobian_mlp") -> ForwardResult:
+    """Second half of NJF/models/model.py:316-396: decoder on the final samples + compositing (:342-394)."""
+    action = enc.action
     positions = samples.positions()
     dirs = directions[..., None, :].expand(positions.shape)  # model.py:245-247
 
     dens, rgb, flow, jac = decoder_forward(_sub(params, "decoder."), positions, dirs, enc, decoder_kind,
                                            action.shape[-1])
     weights = alpha_weights(samples.deltas, dens)
-    weights_list.append(weights)
-    samples_list.append(samples)
 
     res = ForwardResult()
     res.rgb = composite_rgb(rgb, weights)
@@ -585,12 +594,18 @@ def model_forward(params: Params, *, features: Optional[Tensor] = None, input_im
     res.optical_flow, res.ray_positions, res.ray_positions_warped = composite_flow(
         weights, positions, flow[..., :3], trgt_c2w, trgt_k_pix
     )
-    res.weights_list, res.samples_list = weights_list, samples_list
+    res.weights_list, res.samples_list = [weights], [samples]
     res.action_features = torch.sum(weights * jac, dim=-2)  # model.py:281-286
     res.steps, res.weights = steps.squeeze(-1), weights.squeeze(-1)
     res.density, res.color, res.flow, res.jacobian = dens, rgb, flow, jac
     res.positions = positions
     return res
+
+
+def samples_from_bins(origins: Tensor, directions: Tensor, z_near: Tensor, z_far: Tensor, bins: Tensor) -> Samples:
+    """Samples for given spacing-domain bin edges [B,R,S+1] (ray_samplers.py:244-252)."""
+    ones = torch.ones_like(origins[..., 0:1])
+    return _samples_from_bins(origins, directions, ones * z_near[:, None, None], ones * z_far[:, None, None], bins)
 
 
 def infer_optical_flow(jacobian: Tensor, weights: Tensor, positions: Tensor, action: Tensor,

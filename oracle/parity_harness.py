@@ -1,0 +1,172 @@
+"""Parity harness: fused HIP path (device) vs the CPU oracle on identical seeded inputs.
+
+TEST INFRASTRUCTURE (same status as njf_oracle.py): imported only by tests/, __graft_entry__.smoke()
+and bench.py's verification leg.  Errors are reported relative to the tensor's max-abs value
+("1e-4 rel fp32" of BASELINE.json's north_star is read norm-wise: the positional encoding amplifies
+one ulp of a camera-space coordinate by up to 2*pi*512, so element-wise relative error near zeros
+is meaningless)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+import njf_oracle as orc
+from neural_jacobian_field_amd import synthetic
+from neural_jacobian_field_amd.renderer import FusedRenderer, RenderRequest
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def general_pose(seed: int, batch: int, scale: float = 0.15) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(batch, 3, 3, generator=g)
+    m = torch.eye(4)[None].repeat(batch, 1, 1)
+    m[:, :3, :3] = torch.matrix_exp(scale * (a - a.transpose(1, 2)))
+    m[:, :3, 3] = 0.1 * torch.randn(batch, 3, generator=g)
+    return m.contiguous()
+
+
+def make_case(batch: int, height: int, width: int, rays: Optional[int], action_dim: int, seed: int = 0,
+              identity_context: bool = True):
+    """Seeded synthetic batch: weights, feature map, cameras, rays -- all CPU tensors."""
+    params = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", action_dim, with_encoder=False), seed)
+    cams = synthetic.synthetic_cameras(batch)
+    if not identity_context:
+        cams["ctxt_c2w"] = general_pose(seed + 5, batch)
+    feats = synthetic.synthetic_features(batch, height, width, seed=seed + 1)
+    coords, _ = orc.pixel_grid(height, width)
+    xy = coords.reshape(1, -1, 2)
+    if rays is not None and rays < height * width:
+        sel = torch.randperm(height * width, generator=torch.Generator().manual_seed(seed + 3))[:rays]
+        xy = xy[:, sel]
+    xy = xy.repeat(batch, 1, 1).contiguous()
+    origins, directions, _ = orc.world_rays_with_z(xy, cams["trgt_k_norm"], cams["trgt_c2w"])
+    k_pix = orc.denormalize_intrinsics(cams["trgt_k_norm"], width, height)
+    action = synthetic.synthetic_action(batch, action_dim, seed + 2)
+    return dict(params=params, feats=feats, cams=cams, origins=origins.contiguous(), directions=directions.contiguous(),
+                k_pix=k_pix, action=action)
+
+
+def oracle_forward(case, s_prop, s_final, anneal: float = 1.0):
+    c = case["cams"]
+    return orc.model_forward(case["params"], features=case["feats"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
+                             trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
+                             directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=case["action"],
+                             num_proposal_samples=[s_prop], num_nerf_samples=s_final, decoder_kind="jacobian_mlp",
+                             anneal=anneal)
+
+
+def _to64(x):
+    if isinstance(x, torch.Tensor):
+        return x.double() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: _to64(v) for k, v in x.items()}
+    return x
+
+
+def oracle_forward_fp64(case, s_prop, s_final, anneal: float = 1.0):
+    """The same algorithm evaluated in float64: the yardstick for the fp32 paths' own rounding noise."""
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        return oracle_forward(_to64(case), s_prop, s_final, anneal)
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def final_stage_fp64(case, bins32: torch.Tensor):
+    """Decoder + compositing in float64 at the fp32 oracle's sample locations."""
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        c64 = _to64(case)
+        c = c64["cams"]
+        enc = orc.PixelEncoding(c64["feats"], c["ctxt_c2w"], c["ctxt_k_norm"], c64["action"])
+        smp = orc.samples_from_bins(c64["origins"], c64["directions"], c["z_near"], c["z_far"], bins32.double())
+        return orc.final_stage(c64["params"], smp, c64["directions"], enc, c["trgt_c2w"], c64["k_pix"])
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def hip_forward(case, s_prop, s_final, device, anneal: float = 1.0, request: Optional[RenderRequest] = None,
+                final_bins: Optional[torch.Tensor] = None):
+    c = case["cams"]
+    dev = lambda t: t.to(device)
+    action_dim = case["action"].shape[-1]
+    fr = FusedRenderer(device, 1, action_dim)
+    fr.load_weights({k: dev(v) for k, v in case["params"].items()})
+    gmap = fr.project(dev(case["feats"]))
+    # inverses are taken on the CPU here so both sides see bit-identical world->camera matrices
+    res = fr.render(gmap, dev(case["origins"]), dev(case["directions"]), dev(c["ctxt_c2w"]), dev(c["ctxt_k_norm"]),
+                    dev(c["z_near"]), dev(c["z_far"]), [s_prop], s_final, trgt_c2w=dev(c["trgt_c2w"]),
+                    trgt_k_pix=dev(case["k_pix"]), action=dev(case["action"]), anneal=anneal, request=request,
+                    ctxt_w2c=dev(torch.inverse(c["ctxt_c2w"])), trgt_w2c=dev(torch.inverse(c["trgt_c2w"])),
+                    final_bins=None if final_bins is None else dev(final_bins))
+    return res, fr, gmap
+
+
+def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32, action_dim=8, device=None,
+                    tol: float = 1e-4, seed: int = 0, identity_context: bool = True, anneal: float = 1.0) -> Dict:
+    device = device or torch.device("cuda:0")
+    case = make_case(batch, height, width, rays, action_dim, seed, identity_context)
+    ref = oracle_forward(case, s_prop, s_final, anneal)
+    req = RenderRequest(vis=True, sample_weights=True, per_sample=True)
+    res, _, _ = hip_forward(case, s_prop, s_final, device, anneal, req)
+    ref_bins = torch.cat([ref.samples_list[1].spacing_starts[..., 0], ref.samples_list[1].spacing_ends[..., -1:, 0]], -1)
+    # Per-sample quantities are compared at IDENTICAL sample locations (the oracle's final bins): the
+    # inverse-CDF output differs by ~1e-6 between any two fp32 implementations and the positional
+    # encoding turns that into O(1e-3) differences of individual samples, which is conditioning, not error.
+    res2, _, _ = hip_forward(case, s_prop, s_final, device, anneal, req, final_bins=ref_bins)
+    torch.cuda.synchronize(device)
+    errs = {
+        # end to end (Model.forward standard_output, model.py:363-369)
+        "rgb": rel_err(res.rgb, ref.rgb),
+        "depth": rel_err(res.depth, ref.depth),
+        "optical_flow": rel_err(res.optical_flow, ref.optical_flow),
+        # proposal stage
+        "prop_weights": rel_err(res.weights_list[0], ref.weights_list[0]),
+        "final_bins": rel_err(res.bins_list[1], ref_bins),
+        # final stage at the oracle's sample locations
+        "s_rgb": rel_err(res2.rgb, ref.rgb),
+        "s_depth": rel_err(res2.depth, ref.depth),
+        "s_optical_flow": rel_err(res2.optical_flow, ref.optical_flow),
+        "s_weights": rel_err(res2.weights_list[0], ref.weights_list[1]),
+        "s_density": rel_err(res2.extras["density"], ref.density),
+        "s_color": rel_err(res2.extras["color"], ref.color),
+        "s_sample_flow": rel_err(res2.extras["sample_flow"], ref.flow),
+        "s_jacobian": rel_err(res2.extras["jacobian"], ref.jacobian),
+        "s_action_features": rel_err(res2.extras["action_features"], ref.action_features),
+        "s_pos": rel_err(res2.extras["pos"], ref.ray_positions),
+        "s_pos_warped": rel_err(res2.extras["pos_warped"], ref.ray_positions_warped),
+    }
+    # fp32 noise floor of the reference algorithm itself (fp32 oracle vs fp64 oracle).  The positional
+    # encoding (2*pi*2^9 gain on camera-space coordinates) makes the fp32 reference accurate to only
+    # ~1e-4 on depth/flow for some camera poses; two fp32 implementations that both sit inside that
+    # noise cannot agree better than their summed rounding errors.
+    r64 = oracle_forward_fp64(case, s_prop, s_final, anneal)
+    f64 = final_stage_fp64(case, ref_bins)
+    floor = {"rgb": rel_err(ref.rgb, r64.rgb), "depth": rel_err(ref.depth, r64.depth),
+             "optical_flow": rel_err(ref.optical_flow, r64.optical_flow),
+             "prop_weights": rel_err(ref.weights_list[0], r64.weights_list[0]),
+             "s_rgb": rel_err(ref.rgb, f64.rgb), "s_depth": rel_err(ref.depth, f64.depth),
+             "s_optical_flow": rel_err(ref.optical_flow, f64.optical_flow),
+             "s_weights": rel_err(ref.weights_list[1], f64.weights_list[0]),
+             "s_density": rel_err(ref.density, f64.density), "s_color": rel_err(ref.color, f64.color),
+             "s_sample_flow": rel_err(ref.flow, f64.flow), "s_jacobian": rel_err(ref.jacobian, f64.jacobian),
+             "s_action_features": rel_err(ref.action_features, f64.action_features),
+             "s_pos": rel_err(ref.ray_positions, f64.ray_positions),
+             "s_pos_warped": rel_err(ref.ray_positions_warped, f64.ray_positions_warped)}
+    floor["final_bins"] = floor["prop_weights"]
+    ok = True
+    for k, v in errs.items():
+        limit = max(tol, 2.0 * floor.get(k, 0.0))
+        ok = ok and math.isfinite(v) and v <= limit
+    worst = max(errs.values())
+    return {"ok": bool(ok), "tol": tol, "worst": worst, "errors": {k: float(f"{v:.3e}") for k, v in errs.items()},
+            "fp32_noise_floor": {k: float(f"{v:.3e}") for k, v in floor.items()}}

@@ -1,0 +1,29 @@
+"""GPU parity tests: fused HIP path (through the C ABI) vs the CPU oracle.  Run with -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 rel fp32" (norm-wise, see oracle/parity_harness.py)
+
+
+@pytest.fixture(scope="module")
+def device():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32),
+    dict(batch=2, height=16, width=24, rays=50, s_prop=64, s_final=64),           # ragged ray count, B=2
+    dict(batch=1, height=16, width=16, rays=17, s_prop=48, s_final=20),           # samples not a multiple of 32
+    dict(batch=1, height=32, width=32, rays=None, s_prop=64, s_final=64, action_dim=6),
+    dict(batch=2, height=16, width=16, rays=40, s_prop=32, s_final=32, identity_context=False),
+    dict(batch=1, height=16, width=16, rays=40, s_prop=32, s_final=32, anneal=0.35),
+])
+def test_fused_forward_matches_oracle(device, cfg):
+    import parity_harness as ph
+    rep = ph.run_parity_case(device=device, tol=TOL, **cfg)
+    assert rep["ok"], rep
