@@ -118,7 +118,7 @@ class FusedRenderer:
                request: Optional[RenderRequest] = None, bins0: Optional[torch.Tensor] = None,
                u_list: Optional[Sequence[torch.Tensor]] = None, ctxt_w2c: Optional[torch.Tensor] = None,
                trgt_w2c: Optional[torch.Tensor] = None, clip_depth: bool = True,
-               final_bins: Optional[torch.Tensor] = None) -> RenderResult:
+               final_bins: Optional[torch.Tensor] = None, _events=None) -> RenderResult:
         """Eval-mode by default (shared linspace bins / mid-point u).  Training-mode stratified jitter is
         injected by the caller through ``bins0`` ([B,R,S0+1]) and ``u_list`` (one [B,R,S+1] per level).
         ``final_bins`` ([B,R,S+1] spacing bins) skips the proposal levels and renders exactly those samples."""
@@ -139,6 +139,8 @@ class FusedRenderer:
         levels = list(num_proposal_samples) + [num_nerf_samples]
         res = RenderResult(rgb=None, depth=None, optical_flow=None)
         bins = bins0.contiguous() if bins0 is not None else uniform_bins(levels[0], dev)
+        if _events:
+            _events[0].record()
         for lvl in range(self.n_prop if final_bins is None else 0):
             s_in, s_out = levels[lvl], levels[lvl + 1]
             u = u_list[lvl].contiguous() if u_list is not None else pdf_u_eval(s_out, dev)
@@ -153,6 +155,8 @@ class FusedRenderer:
 
         if final_bins is not None:
             bins = final_bins.contiguous()
+        if _events:
+            _events[1].record()
         s = levels[-1]
         with_j = self.has_jacobian_mlp and action is not None
         outs: Dict[str, torch.Tensor] = {
@@ -177,6 +181,8 @@ class FusedRenderer:
                 outs["jacobian"] = torch.empty(b, r, s, 3 * self.action_dim, **f32)
         hip.render_forward(origins, directions, cams, fmap, self.goff_density, self.goff_jacobian, self.w_dec,
                            self.b_density, self.b_color, self.b_jacobian, bins, s, outs, with_jacobian=with_j)
+        if _events:
+            _events[2].record()
         depth = outs["depth"]
         if clip_depth:  # tensor-global clip of model.py:277
             depth = torch.clamp(depth, min=outs["step_minmax"][..., 0].min(), max=outs["step_minmax"][..., 1].max())
