@@ -1,0 +1,327 @@
+"""Per-point decoders -- host-side mirror of ``models/decoder/`` (registry, ABC, I/O dataclasses,
+state-dict-compatible parameter trees) whose forward passes run in the fused HIP kernels.
+
+Reference: ``models/decoder/__init__.py:11-44`` (registries), ``action_decoder.py:11-64``,
+``action_decoder_jacobian.py:86-337``, ``density_decoder.py:23-71``,
+``model_components/resnet_fc.py:82-154``.
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .config import (ActionDecoderCfg, ActionDecoderJacobianMlpCfg, ActionDecoderJacobianTransformerCfg,
+                     DensityDecoderCfg, DensityDecoderMlpCfg, MlpCfg)
+
+
+# --------------------------------------------------------------------------------------
+# I/O records (action_decoder.py:11-30, action_decoder_jacobian.py:64-75)
+# --------------------------------------------------------------------------------------
+@dataclass
+class PixelEncoding:
+    features: torch.Tensor    # [B,C,Hf,Wf] encoder output
+    extrinsics: torch.Tensor  # [B,4,4] context cam2world
+    intrinsics: torch.Tensor  # [B,3,3] normalised context intrinsics
+    action: torch.Tensor      # [B,A]
+
+
+@dataclass
+class DecoderOutput:
+    density: torch.Tensor          # [B,R,S,1]
+    color: torch.Tensor            # [B,R,S,3]
+    flow: torch.Tensor             # [B,R,S,3]
+    action_features: torch.Tensor  # [B,R,S,3A]
+
+
+@dataclass
+class DecoderFeatureOnlyOutput:
+    density: torch.Tensor
+    action_features: torch.Tensor
+
+
+@dataclass
+class DensityHeadOutput:
+    density: torch.Tensor
+    density_features: torch.Tensor
+    xyz_features: Optional[torch.Tensor]            # never materialised by the fused path (None)
+    pixel_aligned_features: Optional[torch.Tensor]  # never materialised by the fused path (None)
+
+
+# --------------------------------------------------------------------------------------
+# ResnetFC parameter tree (names/shapes/init of resnet_fc.py:27-128)
+# --------------------------------------------------------------------------------------
+class ResnetBlockFC(nn.Module):
+    def __init__(self, size: int):
+        super().__init__()
+        self.fc_0 = nn.Linear(size, size)
+        self.fc_1 = nn.Linear(size, size)
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
+        nn.init.zeros_(self.fc_1.weight)
+
+
+class ResnetFC(nn.Module):
+    """Parameter container with the reference's names.  Its arithmetic (resnet_fc.py:130-154) lives in
+    the fused kernels, reached through the owning decoder; the geometry it supports is the shipped one
+    (``MlpCfg(n_blocks=5, d_hidden=128, combine_layer=3, beta=0)``, d_in=63, d_latent=512)."""
+
+    def __init__(self, resnet_cfg: MlpCfg, d_in: int, d_latent: int, d_out: int):
+        super().__init__()
+        if (resnet_cfg.n_blocks, resnet_cfg.d_hidden, resnet_cfg.combine_layer) != (5, 128, 3) or resnet_cfg.beta > 0:
+            raise ValueError("fused ResnetFC supports MlpCfg(n_blocks=5, d_hidden=128, combine_layer=3, beta=0) only")
+        if d_in != 63 or d_latent != 512 or not (1 <= d_out <= 32):
+            raise ValueError("fused ResnetFC supports d_in=63, d_latent=512, 1 <= d_out <= 32")
+        self.resnet_cfg, self.d_latent, self.d_out = resnet_cfg, d_latent, d_out
+        h = resnet_cfg.d_hidden
+        self.lin_in = nn.Linear(d_in, h)
+        self.lin_out = nn.Linear(h, d_out)
+        self.blocks = nn.ModuleList([ResnetBlockFC(h) for _ in range(resnet_cfg.n_blocks)])
+        self.lin_z = nn.ModuleList([nn.Linear(d_latent, h) for _ in range(resnet_cfg.combine_layer)])
+        for lin in [self.lin_in, self.lin_out, *self.lin_z]:
+            nn.init.constant_(lin.bias, 0.0)
+            nn.init.kaiming_normal_(lin.weight, a=0, mode="fan_in")
+
+    def forward(self, z, x):  # pragma: no cover - documented non-goal
+        raise NotImplementedError(
+            "ResnetFC runs only fused with feature sampling (DensityDecoderMlp.get_density / "
+            "ActionDecoderJacobian.forward); the stand-alone (z, x) form is not exported by the HIP path")
+
+
+def initialize_jacobian_weights(m: nn.Module) -> None:
+    """action_decoder_jacobian.py:78-83."""
+    if type(m) == nn.Linear:
+        nn.init.normal_(m.weight, mean=0.0, std=1e-4)
+        if m.bias is not None:
+            nn.init.normal_(m.bias, mean=0.0, std=1e-4)
+
+
+def _version(module: nn.Module) -> Tuple:
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+class _HoistCache:
+    """One hoisted feature map per (feature tensor, weight version)."""
+
+    def __init__(self):
+        self.key = None
+        self.gmap = None
+
+    def get(self, features: torch.Tensor, wversion, wz: torch.Tensor, bz: torch.Tensor) -> torch.Tensor:
+        key = (features.data_ptr(), features._version, tuple(features.shape), wversion)
+        if key != self.key:
+            b, _, hf, wf = features.shape
+            gmap = torch.empty(b, hf, wf, wz.shape[1], dtype=torch.float32, device=features.device)
+            hip.project_features(features.contiguous(), wz, bz, gmap)
+            self.key, self.gmap = key, gmap
+        return self.gmap
+
+
+def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trgt_w2c=None, trgt_k=None, action_dim=None):
+    b = enc.extrinsics.shape[0]
+    dev = enc.extrinsics.device
+    zeros = torch.zeros(b, dtype=torch.float32, device=dev)
+    return hip.make_cameras(torch.linalg.inv(enc.extrinsics).contiguous(), enc.intrinsics.contiguous(),
+                            zeros if z_near is None else z_near.contiguous(),
+                            zeros if z_far is None else z_far.contiguous(), trgt_w2c, trgt_k,
+                            enc.action.contiguous() if with_action else None, action_dim)
+
+
+# --------------------------------------------------------------------------------------
+# proposal density decoder (density_decoder.py:23-71)
+# --------------------------------------------------------------------------------------
+class DensityDecoderMlp(nn.Module):
+    def __init__(self, cfg: DensityDecoderMlpCfg, encoder_dim: int):
+        super().__init__()
+        if cfg.num_frequencies != 10:
+            raise ValueError("fused path supports num_frequencies=10 (63-d positional encoding)")
+        self.cfg = cfg
+        self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=1)
+        self._packed_version = None
+        self._hoist = _HoistCache()
+
+    # ---- packed state ----------------------------------------------------------------
+    def packed(self):
+        v = _version(self)
+        if v != self._packed_version:
+            dev = self.density_head.lin_in.weight.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            self._w = torch.empty(hip.RESNET_W_FLOATS, **f32)
+            self._b = torch.empty(hip.RESNET_B_FLOATS, **f32)
+            self._wz = torch.empty(512, hip.ZDIM, **f32)
+            self._bz = torch.empty(hip.ZDIM, **f32)
+            params = {k: p for k, p in self.named_parameters()}
+            hip.pack_resnetfc(params, "density_head.", self._w, self._b, self._wz, 0, self._bz)
+            self._packed_version = v
+        return self._w, self._b
+
+    def hoisted_map(self, features: torch.Tensor) -> torch.Tensor:
+        self.packed()
+        return self._hoist.get(features, self._packed_version, self._wz, self._bz)
+
+    # ---- reference API -----------------------------------------------------------------
+    @torch.no_grad()
+    def get_density(self, world_space_xyz: torch.Tensor, pixel_encoding: PixelEncoding) -> torch.Tensor:
+        """[B,R,S,3] world points -> density [B,R,S,1]  (density_decoder.py:45-71)."""
+        b, r, s = world_space_xyz.shape[:3]
+        w, bias = self.packed()
+        fmap = hip.make_feature_map(self.hoisted_map(pixel_encoding.features))
+        out = torch.empty(b, r, s, 1, dtype=torch.float32, device=world_space_xyz.device)
+        xyz = world_space_xyz.reshape(b, r * s, 3).contiguous()
+        hip.points_forward(xyz, None, _cameras(pixel_encoding, False), fmap, 0, 0, 0, w, bias, density=out)
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# action decoders (action_decoder.py:33-64, action_decoder_jacobian.py:86-337)
+# --------------------------------------------------------------------------------------
+class ActionDecoder(nn.Module, ABC):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    @abstractmethod
+    def forward(self, world_space_xyz, world_space_dir, pixel_encoding: PixelEncoding) -> DecoderOutput: ...
+
+    @abstractmethod
+    def encode_image(self, world_space_xyz, pixel_encoding: PixelEncoding) -> DecoderFeatureOnlyOutput: ...
+
+    @abstractmethod
+    def freeze_non_action_parameters(self) -> int: ...
+
+
+class ActionDecoderJacobianMLP(ActionDecoder):
+    """density_head (d_out=16) + jacobian_head (d_out=3A) + color_head, evaluated by one fused kernel."""
+
+    spatial_dim: int = 3
+    action_param_glob_pattern = "jacobian_head"
+
+    def __init__(self, cfg: ActionDecoderJacobianMlpCfg, action_dim: int, encoder_dim: int):
+        super().__init__(cfg)
+        if cfg.num_frequencies != 10 or cfg.geometry_feature_dim != 15:
+            raise ValueError("fused path supports num_frequencies=10 and geometry_feature_dim=15")
+        if cfg.use_arm_model:
+            raise NotImplementedError("use_arm_model (second Jacobian head) is not part of the fused path")
+        if not (1 <= action_dim <= hip.MAX_ACTION_DIM):
+            raise ValueError(f"action_dim must be in [1, {hip.MAX_ACTION_DIM}]")
+        self.action_dim = action_dim
+        self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=cfg.geometry_feature_dim + 1)
+        self.jacobian_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim * action_dim)
+        self.jacobian_head.apply(initialize_jacobian_weights)
+        self.mode = "regular"
+        self.color_head = nn.Sequential(
+            nn.Linear(cfg.geometry_feature_dim + 16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 3),
+            nn.Sigmoid())
+        self._packed_version = None
+        self._hoist = _HoistCache()
+
+    def switch_mode(self, mode: str):
+        self.mode = mode
+
+    # ---- packed state ----------------------------------------------------------------
+    GOFF_DENSITY, GOFF_JACOBIAN = 0, hip.ZDIM
+
+    def packed(self):
+        v = _version(self)
+        if v != self._packed_version:
+            dev = self.density_head.lin_in.weight.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            self._w = torch.empty(2 * hip.RESNET_W_FLOATS + hip.COLOR_W_FLOATS, **f32)
+            self._bd = torch.empty(hip.RESNET_B_FLOATS, **f32)
+            self._bc = torch.empty(hip.COLOR_B_FLOATS, **f32)
+            self._bj = torch.empty(hip.RESNET_B_FLOATS, **f32)
+            self._wz = torch.empty(512, 2 * hip.ZDIM, **f32)
+            self._bz = torch.empty(2 * hip.ZDIM, **f32)
+            params = {k: p for k, p in self.named_parameters()}
+            n = hip.RESNET_W_FLOATS
+            hip.pack_resnetfc(params, "density_head.", self._w[:n], self._bd, self._wz, 0, self._bz)
+            hip.pack_color_head(params, "color_head.", self._w[n:n + hip.COLOR_W_FLOATS], self._bc)
+            hip.pack_resnetfc(params, "jacobian_head.", self._w[n + hip.COLOR_W_FLOATS:], self._bj, self._wz, hip.ZDIM,
+                              self._bz)
+            self._packed_version = v
+        return self._w, self._bd, self._bc, self._bj
+
+    def hoisted_map(self, features: torch.Tensor) -> torch.Tensor:
+        self.packed()
+        return self._hoist.get(features, self._packed_version, self._wz, self._bz)
+
+    def _points(self, xyz_flat, dirs_flat, enc: PixelEncoding, with_jacobian: bool, want: Dict[str, bool]):
+        b, n = xyz_flat.shape[:2]
+        dev = xyz_flat.device
+        w, bd, bc, bj = self.packed()
+        fmap = hip.make_feature_map(self.hoisted_map(enc.features))
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {"density": torch.empty(b, n, 1, **f32)}
+        if want.get("color"):
+            out["color"] = torch.empty(b, n, 3, **f32)
+        if want.get("geo"):
+            out["geo"] = torch.empty(b, n, 15, **f32)
+        if with_jacobian:
+            out["jacobian"] = torch.empty(b, n, 3 * self.action_dim, **f32)
+            if want.get("flow"):
+                out["flow"] = torch.empty(b, n, 3, **f32)
+        hip.points_forward(xyz_flat.contiguous(), None if dirs_flat is None else dirs_flat.contiguous(),
+                           _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.action_dim), fmap,
+                           self.GOFF_DENSITY,
+                           self.GOFF_JACOBIAN, 1, w, bd, bc, bj, with_jacobian=with_jacobian, **out)
+        return out
+
+    # ---- reference API -----------------------------------------------------------------
+    @torch.no_grad()
+    def compute_density(self, world_space_xyz: torch.Tensor, pixel_encoding: PixelEncoding) -> DensityHeadOutput:
+        """[B,N,3] -> DensityHeadOutput (action_decoder_jacobian.py:92-119)."""
+        o = self._points(world_space_xyz, None, pixel_encoding, False, {"geo": True})
+        return DensityHeadOutput(o["density"], o["geo"], None, None)
+
+    @torch.no_grad()
+    def forward(self, world_space_xyz, world_space_dir, pixel_encoding: PixelEncoding) -> DecoderOutput:
+        """action_decoder_jacobian.py:147-215."""
+        b, r, s = world_space_xyz.shape[:3]
+        o = self._points(world_space_xyz.reshape(b, r * s, 3), world_space_dir.reshape(b, r * s, 3), pixel_encoding, True,
+                         {"color": True, "flow": True})
+        sh = lambda t: t.reshape(b, r, s, -1)
+        return DecoderOutput(sh(o["density"]), sh(o["color"]), sh(o["flow"]), sh(o["jacobian"]))
+
+    @torch.no_grad()
+    def encode_image(self, world_space_xyz, pixel_encoding: PixelEncoding) -> DecoderFeatureOnlyOutput:
+        """action_decoder_jacobian.py:217-249."""
+        b, r, s = world_space_xyz.shape[:3]
+        o = self._points(world_space_xyz.reshape(b, r * s, 3), None, pixel_encoding, True, {})
+        return DecoderFeatureOnlyOutput(o["density"].reshape(b, r, s, 1), o["jacobian"].reshape(b, r, s, -1))
+
+    @torch.no_grad()
+    def compute_jacobian_at(self, world_space_xyz, pixel_encoding: PixelEncoding) -> torch.Tensor:
+        """Jacobian head on [B,N,3] points (what Model.compute_density puts in extras, model.py:447-454)."""
+        return self._points(world_space_xyz, None, pixel_encoding, True, {})["jacobian"]
+
+    def freeze_non_action_parameters(self) -> int:
+        """action_decoder_jacobian.py:251-258."""
+        count = 0
+        for name, p in self.named_parameters():
+            if self.action_param_glob_pattern not in name:
+                p.requires_grad = False
+                count += 1
+        return count
+
+
+# --------------------------------------------------------------------------------------
+# registries (models/decoder/__init__.py:11-44)
+# --------------------------------------------------------------------------------------
+DENSITY_DECODERS = {"density_mlp": DensityDecoderMlp}
+ACTION_DECODERS = {"jacobian_mlp": ActionDecoderJacobianMLP}
+
+
+def get_density_decoder(cfg: DensityDecoderCfg, encoder_dim: int) -> DensityDecoderMlp:
+    return DENSITY_DECODERS[cfg.name](cfg=cfg, encoder_dim=encoder_dim)
+
+
+def get_action_decoder(cfg: ActionDecoderCfg, action_dim: int, encoder_dim: int) -> ActionDecoder:
+    if cfg.name not in ACTION_DECODERS:
+        raise KeyError(f"action decoder {cfg.name!r} is not available in the HIP path; known: {sorted(ACTION_DECODERS)}")
+    return ACTION_DECODERS[cfg.name](cfg=cfg, action_dim=action_dim, encoder_dim=encoder_dim)

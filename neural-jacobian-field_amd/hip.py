@@ -122,9 +122,9 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def make_cameras(ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c=None, trgt_k=None, action=None, keep=None) -> Cameras:
+def make_cameras(ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c=None, trgt_k=None, action=None, action_dim=None) -> Cameras:
     batch = ctxt_w2c.shape[0]
-    a_dim = 0 if action is None else action.shape[-1]
+    a_dim = (0 if action is None else action.shape[-1]) if action_dim is None else action_dim
     cams = Cameras(_ptr(ctxt_w2c, "ctxt_w2c"), _ptr(ctxt_k, "ctxt_k"), _ptr(trgt_w2c, "trgt_w2c"),
                    _ptr(trgt_k, "trgt_k"), _ptr(z_near, "z_near"), _ptr(z_far, "z_far"), _ptr(action, "action"),
                    batch, a_dim)

@@ -1,0 +1,324 @@
+"""``Model`` -- host-side mirror of ``models/model.py`` (same dataclasses, methods and state-dict
+names) whose rendering runs in the fused HIP kernels.
+
+Reference: ``models/model.py:35-144`` (I/O records), ``:147-213`` (construction, annealing),
+``:215-314`` (ray bundle / proposal / render_*), ``:316-396`` (forward), ``:398-525`` (inference helpers),
+``:527-628`` (patch_render).
+
+Round-1 scope: forward/inference (eval or training-mode sampling) under ``torch.no_grad`` semantics --
+outputs carry no autograd graph; the backward of the fused path is SURVEY.md section 8f #2.
+"""
+
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .config import ModelCfg, RenderingCfg  # noqa: F401  (re-exported like the reference module)
+from .decoder import (DecoderOutput, DensityHeadOutput, PixelEncoding, _cameras, get_action_decoder,
+                      get_density_decoder)
+from .encoder import get_encoder
+from .ray_samplers import ProposalNetworkSampler, RayBundle, RaySamples, UniformSampler
+
+
+# ---- I/O records (model.py:56-144) -------------------------------------------------------
+@dataclass
+class CameraInput:
+    input_image: torch.Tensor      # [B,C,H,W]
+    ctxt_extrinsics: torch.Tensor  # [B,4,4]
+    ctxt_intrinsics: torch.Tensor  # [B,3,3] normalised
+    trgt_extrinsics: torch.Tensor  # [B,4,4]
+    trgt_intrinsics: torch.Tensor  # [B,3,3] pixels
+
+
+@dataclass
+class RenderingInput:
+    origins: torch.Tensor     # [B,R,3]
+    directions: torch.Tensor  # [B,R,3]
+    z_near: torch.Tensor      # [B]
+    z_far: torch.Tensor       # [B]
+
+
+@dataclass
+class RobotInput:
+    robot_action: torch.Tensor  # [B,A]
+
+
+@dataclass
+class ModelInput:
+    camera_input: CameraInput
+    rendering_input: RenderingInput
+    robot_input: RobotInput
+
+
+@dataclass
+class ModelTarget:
+    rgb: torch.Tensor
+    depth: torch.Tensor
+    optical_flow: Optional[torch.Tensor]
+    visible_mask: Optional[torch.Tensor]
+
+
+@dataclass
+class ModelStandardOutput:
+    rgb: torch.Tensor           # [B,R,3]
+    depth: torch.Tensor         # [B,R,1]
+    optical_flow: torch.Tensor  # [B,R,2]
+
+
+@dataclass
+class ModelTrainingOutput:
+    weights_list: List[torch.Tensor]
+    ray_samples_list: List[RaySamples]
+
+
+@dataclass
+class ModelVisOutput:
+    action_features: torch.Tensor
+    ray_positions: torch.Tensor
+    ray_positions_warped: torch.Tensor
+    weights: torch.Tensor
+    steps: torch.Tensor
+
+
+@dataclass
+class ModelOutput:
+    standard_output: ModelStandardOutput
+    training_output: Optional[ModelTrainingOutput]
+    vis_output: Optional[ModelVisOutput]
+
+
+@dataclass
+class ModelInferenceEncoding:
+    density: torch.Tensor
+    action_features: torch.Tensor
+    weights: torch.Tensor
+    ray_samples_positions: torch.Tensor
+
+
+@dataclass
+class RenderingOutput:
+    rgb: torch.Tensor
+    depth_raw: torch.Tensor
+    depth_rgb: Optional[torch.Tensor]
+    flow_raw: torch.Tensor
+    flow_rgb: Optional[torch.Tensor]
+    ray_positions: torch.Tensor
+    ray_positions_warped: torch.Tensor
+    action_features: torch.Tensor
+    steps: torch.Tensor
+    weights: torch.Tensor
+
+
+class Model(nn.Module):
+    def __init__(self, cfg: ModelCfg):
+        super().__init__()
+        self.cfg = cfg
+        self.encoder = get_encoder(cfg.encoder)
+        self.decoder = get_action_decoder(cfg.action_decoder, action_dim=cfg.action_dim,
+                                          encoder_dim=self.encoder.get_output_dim())
+        n_prop = len(cfg.rendering.num_proposal_samples)
+        self.proposal_networks = nn.ModuleList(
+            [get_density_decoder(cfg.density_decoder, encoder_dim=self.encoder.get_output_dim()) for _ in range(n_prop)])
+        self.density_fns = [net.get_density for net in self.proposal_networks]
+        r = cfg.rendering
+        update_schedule = lambda step: np.clip(np.interp(step, [0, r.proposal_warmup], [0, r.proposal_update_every]), 1,
+                                               r.proposal_update_every)
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=r.num_nerf_samples, num_proposal_samples_per_ray=tuple(r.num_proposal_samples),
+            num_proposal_network_iterations=n_prop, single_jitter=r.single_jitter, update_sched=update_schedule,
+            initial_sampler=UniformSampler(single_jitter=r.single_jitter))
+
+    # ---- schedule hooks (model.py:201-213) ---------------------------------------------
+    def step_before_iter(self, step):
+        r = self.cfg.rendering
+        if r.use_proposal_weight_anneal:
+            frac = np.clip(step / r.proposal_weights_anneal_max_num_iters, 0, 1)
+            b = r.proposal_weights_anneal_slope
+            self.proposal_sampler.set_anneal((b * frac) / ((b - 1) * frac + 1))
+
+    def step_after_iter(self, step):
+        if self.cfg.rendering.use_proposal_weight_anneal:
+            self.proposal_sampler.step_cb(step)
+
+    # ---- pieces of the forward (model.py:215-314) ---------------------------------------
+    def compute_ray_bundle(self, rendering_input: RenderingInput) -> RayBundle:
+        ones = torch.ones_like(rendering_input.origins[..., 0:1])
+        return RayBundle(origins=rendering_input.origins, directions=rendering_input.directions,
+                         nears=ones * rendering_input.z_near[:, None, None],
+                         fars=ones * rendering_input.z_far[:, None, None])
+
+    def compute_proposal(self, ray_bundle: RayBundle, pixel_encoding: PixelEncoding):
+        """model.py:228-255 through the generic sampler route (public pieces, arbitrary density_fns)."""
+        fns = [functools.partial(fn, pixel_encoding=pixel_encoding) for fn in self.density_fns]
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler.generate_ray_samples(ray_bundle, density_fns=fns)
+        positions = ray_samples.get_positions()
+        directions = ray_bundle.directions[..., None, :].expand(positions.shape)
+        return ray_samples, positions, directions, weights_list, ray_samples_list
+
+    @staticmethod
+    def render_rgb(rgb, weights, bg_color=None):
+        comp = torch.sum(weights * rgb, dim=-2)
+        if bg_color is not None:
+            comp = comp + (1.0 - torch.sum(weights, dim=-2)) * bg_color
+        return comp
+
+    @staticmethod
+    def render_depth(weights, ray_samples: RaySamples):
+        steps = (ray_samples.starts + ray_samples.ends) / 2
+        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+        return torch.clip(depth, steps.min(), steps.max()), steps
+
+    @staticmethod
+    def render_action_features(action_features, weights):
+        return torch.sum(weights * action_features, dim=-2)
+
+    @staticmethod
+    def _project(points, trgt_extrinsics, trgt_intrinsics):
+        hom = torch.cat([points, torch.ones_like(points[..., :1])], dim=-1)
+        cam = torch.einsum("...ij,...j->...i", torch.linalg.inv(trgt_extrinsics)[..., None, :, :], hom)
+        xyw = torch.einsum("...ij,...j->...i", trgt_intrinsics.unsqueeze(1), cam[..., :3])
+        return (xyw / (xyw[..., -1:] + 1e-9))[..., :2]
+
+    @staticmethod
+    def render_optical_flow(weights, ray_positions, scene_flow, trgt_extrinsics, trgt_intrinsics):
+        """model.py:288-314.  Stand-alone form on caller-supplied per-sample tensors (inverse-dynamics loops
+        differentiate through it, so it stays in torch); Model.forward composites in-kernel."""
+        warped = ray_positions + scene_flow
+        pos = torch.sum(weights * ray_positions, dim=-2)
+        pos_w = torch.sum(weights * warped, dim=-2)
+        uv = Model._project(pos, trgt_extrinsics, trgt_intrinsics)
+        uv_w = Model._project(pos_w, trgt_extrinsics, trgt_intrinsics)
+        return uv_w - uv, pos, pos_w
+
+    # ---- fused forward -------------------------------------------------------------------
+    def _fused_render(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
+                      features: torch.Tensor, want_lists: bool, want_vis: bool, want_samples: bool):
+        enc = PixelEncoding(features=features, extrinsics=camera_input.ctxt_extrinsics,
+                            intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action)
+        ray_bundle = self.compute_ray_bundle(rendering_input)
+        self.proposal_sampler.train(self.training)
+        bins, weights_list, bins_list = self.proposal_sampler.generate_ray_samples_fused(
+            ray_bundle, list(self.proposal_networks), enc, rendering_input.z_near, rendering_input.z_far, want_lists)
+        o, d = rendering_input.origins.contiguous(), rendering_input.directions.contiguous()
+        b, r = o.shape[:2]
+        s = self.cfg.rendering.num_nerf_samples
+        a3 = 3 * self.cfg.action_dim
+        dev = o.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        outs: Dict[str, torch.Tensor] = {"rgb": torch.empty(b, r, 3, **f32), "depth": torch.empty(b, r, 1, **f32),
+                                         "step_minmax": torch.empty(b, r, 2, **f32), "flow": torch.empty(b, r, 2, **f32)}
+        if want_lists or want_vis or want_samples:
+            outs["weights"] = torch.empty(b, r, s, **f32)
+        if want_vis:
+            outs["pos"] = torch.empty(b, r, 3, **f32)
+            outs["pos_warped"] = torch.empty(b, r, 3, **f32)
+            outs["action_features"] = torch.empty(b, r, a3, **f32)
+        if want_samples:
+            outs["density"] = torch.empty(b, r, s, 1, **f32)
+            outs["jacobian"] = torch.empty(b, r, s, a3, **f32)
+        w, bd, bc, bj = self.decoder.packed()
+        fmap = hip.make_feature_map(self.decoder.hoisted_map(features))
+        cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
+                        torch.linalg.inv(camera_input.trgt_extrinsics).contiguous(),
+                        camera_input.trgt_intrinsics.contiguous())
+        hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
+                           outs, with_jacobian=True)
+        # tensor-global clip of model.py:277
+        outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
+                                    max=outs["step_minmax"][..., 1].max())
+        return outs, bins, weights_list, bins_list, ray_bundle
+
+    @torch.no_grad()
+    def forward(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
+                compute_vis_features: bool = False) -> ModelOutput:
+        """model.py:316-396."""
+        features = self.encoder.forward(camera_input.input_image)
+        outs, bins, weights_list, bins_list, ray_bundle = self._fused_render(
+            camera_input, rendering_input, robot_input, features, want_lists=self.training, want_vis=compute_vis_features,
+            want_samples=False)
+        out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=outs["flow"]), None, None)
+        if self.training:
+            weights_list.append(outs["weights"][..., None])
+            bins_list.append(bins)
+            out.training_output = ModelTrainingOutput(
+                weights_list=weights_list, ray_samples_list=[ray_bundle.samples_from_bins(bn) for bn in bins_list])
+        if compute_vis_features:
+            smp = ray_bundle.samples_from_bins(bins)
+            out.vis_output = ModelVisOutput(
+                action_features=outs["action_features"], steps=((smp.starts + smp.ends) / 2).squeeze(-1),
+                weights=outs["weights"], ray_positions=outs["pos"], ray_positions_warped=outs["pos_warped"])
+        return out
+
+    # ---- inference helpers (model.py:398-525) -----------------------------------------------
+    @torch.no_grad()
+    def compute_pixel_encoding(self, camera_input: CameraInput, rendering_input: RenderingInput,
+                               robot_input: RobotInput) -> PixelEncoding:
+        return PixelEncoding(features=self.encoder.forward(camera_input.input_image),
+                             extrinsics=camera_input.ctxt_extrinsics, intrinsics=camera_input.ctxt_intrinsics,
+                             action=robot_input.robot_action)
+
+    @torch.no_grad()
+    def compute_density(self, world_space_xyz: torch.Tensor, pixel_encoding: PixelEncoding) -> Tuple[DensityHeadOutput, dict]:
+        """model.py:416-456.  ``world_space_xyz`` [B,N,3] (the reference annotates [B,R,S,3] but feeds the
+        flat form to get_pixel_aligned_features)."""
+        head = self.decoder.compute_density(world_space_xyz, pixel_encoding)
+        extras = {}
+        if "jacobian" in self.cfg.action_decoder.name:
+            extras["jacobian_head_output"] = self.decoder.compute_jacobian_at(world_space_xyz, pixel_encoding)
+        return head, extras
+
+    @torch.no_grad()
+    def encode_image(self, camera_input: CameraInput, rendering_input: RenderingInput,
+                     robot_input: RobotInput) -> ModelInferenceEncoding:
+        """model.py:458-495: proposal sampling + per-sample density/Jacobian/weights, cached for inverse dynamics."""
+        features = self.encoder.forward(camera_input.input_image)
+        outs, bins, _, _, ray_bundle = self._fused_render(camera_input, rendering_input, robot_input, features,
+                                                         want_lists=False, want_vis=False, want_samples=True)
+        positions = ray_bundle.samples_from_bins(bins).get_positions()
+        return ModelInferenceEncoding(density=outs["density"], action_features=outs["jacobian"],
+                                      weights=outs["weights"][..., None], ray_samples_positions=positions)
+
+    def infer_optical_flow(self, model_inference_encoding: ModelInferenceEncoding, camera_input: CameraInput,
+                           robot_input: RobotInput) -> torch.Tensor:
+        """model.py:497-525.  Differentiable w.r.t. ``robot_input.robot_action`` (the inverse-dynamics loop of
+        notebooks/real_world/2_inverse_dynamics.ipynb optimises the action through this call), hence torch ops."""
+        assert "jacobian" in self.cfg.action_decoder.name
+        enc = model_inference_encoding
+        b, r, s = enc.action_features.shape[:3]
+        a = robot_input.robot_action.shape[-1]
+        jac = enc.action_features.reshape(b, r, s, a, -1)
+        scene_flow = torch.einsum("brsad,ba->brsd", jac, robot_input.robot_action)
+        flow, _, _ = self.render_optical_flow(enc.weights, enc.ray_samples_positions, scene_flow[..., :3],
+                                              camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
+        return flow
+
+    @torch.no_grad()
+    def patch_render(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
+                     patch_size: int = 2048, render_height: int = 480, render_width: int = 640,
+                     verbose: bool = False) -> RenderingOutput:
+        """model.py:527-628.  The fused path never materialises per-point feature tensors, so the whole frame
+        is rendered in ONE pass (``patch_size`` is accepted for signature compatibility and ignored); the encoder
+        runs once instead of once per patch.  Colour-mapped depth/flow images (nerfstudio / torchvision helpers in the
+        reference) are left to the caller: ``depth_rgb``/``flow_rgb`` are None."""
+        was_training = self.training
+        self.eval()
+        try:
+            features = self.encoder.forward(camera_input.input_image)
+            outs, bins, _, _, ray_bundle = self._fused_render(camera_input, rendering_input, robot_input, features,
+                                                             want_lists=False, want_vis=True, want_samples=False)
+        finally:
+            self.train(was_training)
+        smp = ray_bundle.samples_from_bins(bins)
+        img = lambda t: t.reshape(t.shape[0], render_height, render_width, -1)
+        return RenderingOutput(
+            rgb=img(outs["rgb"]), depth_raw=img(outs["depth"]), depth_rgb=None, flow_raw=img(outs["flow"]), flow_rgb=None,
+            ray_positions=img(outs["pos"]), ray_positions_warped=img(outs["pos_warped"]),
+            action_features=img(outs["action_features"]), steps=img(((smp.starts + smp.ends) / 2).squeeze(-1)),
+            weights=img(outs["weights"]))

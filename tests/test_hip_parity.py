@@ -27,3 +27,18 @@ def test_fused_forward_matches_oracle(device, cfg):
     import parity_harness as ph
     rep = ph.run_parity_case(device=device, tol=TOL, **cfg)
     assert rep["ok"], rep
+
+
+def test_fused_kernels_are_bit_reproducible(device):
+    """Same inputs, two launches: every output must be bitwise identical (no atomics, no races)."""
+    import parity_harness as ph
+    from neural_jacobian_field_amd.renderer import RenderRequest
+    case = ph.make_case(2, 16, 16, 70, 8, seed=3, identity_context=False)
+    req = RenderRequest(vis=True, sample_weights=True, per_sample=True)
+    a, _, _ = ph.hip_forward(case, 64, 64, device, request=req)
+    b, _, _ = ph.hip_forward(case, 64, 64, device, request=req)
+    torch.cuda.synchronize()
+    assert torch.equal(a.rgb, b.rgb) and torch.equal(a.depth, b.depth) and torch.equal(a.optical_flow, b.optical_flow)
+    assert torch.equal(a.bins_list[1], b.bins_list[1])
+    for k in a.extras:
+        assert torch.equal(a.extras[k], b.extras[k]), k

@@ -1,0 +1,157 @@
+"""CPU-only checks of the host logic and of the C-ABI library (no compute calls: there is no GPU here)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return g.LIB
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "njf_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(njf_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 12
+    lib = ctypes.CDLL(built)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
+    from neural_jacobian_field_amd import hip
+    assert set(hip.EXPORTED_SYMBOLS) == set(declared)
+    assert lib.njf_abi_version() == 1
+
+
+def test_argument_validation_happens_before_any_launch(built):
+    from neural_jacobian_field_amd import hip
+    lib = hip.load_library()
+    assert lib.njf_alpha_weights(None, None, 4, 4, None, None) == -1            # NULL pointers
+    assert b"NULL" in lib.njf_error_string(-1)
+    assert lib.njf_pdf_resample(1, 1, 0, 300, 1, 0, 8, 1.0, 4, 1, None) == -4    # s_in > 256
+    assert lib.njf_generate_rays(None, 3, 3, 1, 1, 1, 10, 1, 1, None, None) == -2  # H*W != rays
+
+
+def test_no_cpu_fallback():
+    from neural_jacobian_field_amd import hip
+    with pytest.raises(ValueError, match="GPU"):
+        hip.alpha_weights(torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4))
+    from neural_jacobian_field_amd.renderer import FusedRenderer
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        FusedRenderer(torch.device("cpu"))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "neural-jacobian-field_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "njf_oracle" not in src and "parity_harness" not in src, f
+
+
+@pytest.mark.parametrize("tag,kind,adim", [("mlp", "jacobian_mlp", 8)])
+def test_model_state_dict_matches_reference_manifest(tag, kind, adim):
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    cfg = model_cfg_from_dict({
+        "action_dim": adim,
+        "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+        "action_decoder": {"name": kind},
+    })
+    model = Model(cfg)
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")) as f:
+        ref = json.load(f)[tag]
+    assert mine == ref
+
+
+def test_config_from_reference_yaml_content():
+    import yaml
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    text = """
+action_dim: 6
+rendering:
+  num_proposal_samples: [ 256 ]
+  num_nerf_samples: 256
+  single_jitter: false
+  proposal_warmup: 5000
+  proposal_update_every: 5
+  use_proposal_weight_anneal: true
+  proposal_weights_anneal_max_num_iters: 1000
+  proposal_weights_anneal_slope: 10.0
+density_decoder: {name: density_mlp, mlp: {n_blocks: 5, d_hidden: 128, combine_layer: 3, combine_type: mean, beta: 0.0}}
+action_decoder:
+  name: jacobian_mlp
+  mlp: {n_blocks: 5, d_hidden: 128, combine_layer: 3, combine_type: mean, beta: 0.0}
+  num_frequencies: 10
+  geometry_feature_dim: 15
+  use_arm_model: False
+  arm_action_dim: null
+encoder: {name: resnet, use_first_pool: true, num_layers: 4, norm_type: batch, upsample_interp: bilinear}
+"""
+    cfg = model_cfg_from_dict(yaml.safe_load(text))
+    assert cfg.action_dim == 6 and cfg.rendering.num_proposal_samples == (256,)
+    assert cfg.action_decoder.name == "jacobian_mlp" and cfg.encoder.num_layers == 4
+    with pytest.raises(KeyError):
+        model_cfg_from_dict({"action_decoder": {"name": "flow_mlp"}})
+
+
+def test_anneal_schedule_matches_oracle():
+    import njf_oracle as orc
+    from neural_jacobian_field_amd.config import ModelCfg, RenderingCfg
+    from neural_jacobian_field_amd.model import Model
+    m = Model(ModelCfg(rendering=RenderingCfg(num_proposal_samples=(8,), num_nerf_samples=8)))
+    for step in (0, 1, 300, 999, 5000):
+        m.step_before_iter(step)
+        assert abs(m.proposal_sampler._anneal - orc.anneal_value(step, 1000, 10.0)) < 1e-12
+
+
+def test_shard_bounds_cover_all_rays():
+    from neural_jacobian_field_amd.parallel import shard_bounds
+    for n in (1, 7, 64, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, k) for k in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from neural_jacobian_field_amd import parallel as par
+    g = torch.Generator().manual_seed(0)
+    rgb, trg = torch.rand(2, 101, 3, generator=g), torch.rand(2, 101, 3, generator=g)
+    flow, tflow = torch.randn(2, 101, 2, generator=g), torch.randn(2, 101, 2, generator=g)
+    depth = torch.rand(2, 101, 1, generator=g) * 12
+    mm = torch.stack([torch.rand(2, 101, generator=g) + 0.5, torch.rand(2, 101, generator=g) + 9], -1)
+    lo, hi = par.shard_bounds(101, world, rank)
+    losses = par.sharded_losses(rgb[:, lo:hi], trg[:, lo:hi], flow[:, lo:hi], tflow[:, lo:hi])
+    clipped = par.global_depth_clip(depth[:, lo:hi], mm[:, lo:hi])
+    frame = par.gather_frame(clipped, 101)
+    ref_rgb = torch.nn.functional.mse_loss(rgb, trg)
+    ref_flow = 0.01 * torch.nn.functional.mse_loss(flow, tflow)
+    ref_depth = torch.clip(depth, mm[..., 0].min(), mm[..., 1].max())
+    ok = (abs(losses["loss/rgb"] - ref_rgb) < 1e-6 and abs(losses["loss/flow_loss"] - ref_flow) < 1e-6
+          and torch.equal(frame, ref_depth))
+    open(os.path.join(tmp, f"ok{rank}"), "w").write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_ray_sharding_world_size_2_gloo(tmp_path):
+    """Ray-sharded loss / depth-clip / frame gather over 2 gloo ranks equals the unsharded computation."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(open(os.path.join(tmp_path, f"ok{r}")).read() == "True" for r in range(2))
