@@ -49,6 +49,15 @@ extern "C" {
 #define NJF_RESNET_B_FLOATS (10 * 128 + 32)
 #define NJF_COLOR_W_FLOATS NJF_CHUNK_FLOATS
 #define NJF_COLOR_B_FLOATS (64 + 32)
+/* folded transformer Jacobian head: 14 half-chunks [query | (Mqk, Nov, W1, W2) x 3 | head]; 64 hoisted query channels */
+#define NJF_TRANSFORMER_CHUNKS 7
+#define NJF_TRANSFORMER_W_FLOATS (NJF_TRANSFORMER_CHUNKS * NJF_CHUNK_FLOATS)
+#define NJF_TRANSFORMER_B_FLOATS (3 * 256 + 32)
+#define NJF_QDIM 64
+
+#define NJF_JACOBIAN_NONE 0
+#define NJF_JACOBIAN_MLP 1          /* ActionDecoderJacobianMLP (action_decoder_jacobian.py:261-337) */
+#define NJF_JACOBIAN_TRANSFORMER 2  /* ActionDecoderJacobianTransformer (:340-446), host-folded, see decoder.py */
 
 /* Reference-layout tensors of one ResnetFC (model_components/resnet_fc.py:82-128), all device fp32. */
 typedef struct NjfResnetFcWeights {
@@ -108,6 +117,11 @@ int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, float* b_out,
 int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
                          float* bz_out, void* stream);
 int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, void* stream);
+/* One torch.nn.Linear [d_out, d_in] -> fragment-major block of ceil(d_in/32)*4*ceil(d_out/32)*256 floats
+ * (+ zero-padded bias of 32*ceil(d_out/32) floats when b_out != NULL).  kind 0: plain.  kind 1: the input is
+ * the 63-d positional encoding (slot order [sin 30 | x | y || cos 30 | z | 1], bias folded into slot 63). */
+int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kind, float* w_out, float* b_out,
+                    void* stream);
 
 /* ---- per-image feature projection ("lin_z hoist") ------------------------------------------ */
 /* G[b,p,n] = sum_k F[b,k,p] * wz[k,n] + bz[n];  F is the encoder output [B,512,Hf,Wf] (NCHW),
@@ -158,7 +172,7 @@ typedef struct NjfRenderOutputs {
  * sampler); the kernel maps them to Euclidean t = b*far + (1-b)*near (ray_samplers.py:240-243). */
 int njf_render_forward(const float* origins, const float* directions, int rays_per_batch,
                        const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset_density,
-                       int gmap_offset_jacobian,
+                       int gmap_offset_jacobian, int jacobian_kind /* NJF_JACOBIAN_* */,
                        const float* w_density, const float* b_density,
                        const float* w_color, const float* b_color,
                        const float* w_jacobian, const float* b_jacobian,
@@ -167,11 +181,11 @@ int njf_render_forward(const float* origins, const float* directions, int rays_p
 /* ---- point-list evaluation (arbitrary xyz): density_decoder.py:45-71, model.py:416-456 ----- */
 /* xyz [B,N,3] world-space points, dirs [B,N,3] or NULL.  mode 0: proposal net -> density [B*N].
  * mode 1: decoder -> density [B*N], color [B*N,3], flow [B*N,3], jacobian [B*N,3A], geo [B*N,15]
- * (any may be NULL); the Jacobian head runs only when w_jacobian != NULL.  The decoder blobs must be
+ * (any may be NULL); the Jacobian head is selected by jacobian_kind.  The decoder blobs must be
  * one allocation laid out [density | colour | jacobian] (also for njf_render_forward). */
 int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
                        const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
-                       const float* w_density, const float* b_density, const float* w_color, const float* b_color,
+                       int jacobian_kind /* NJF_JACOBIAN_* */, const float* w_density, const float* b_density, const float* w_color, const float* b_color,
                        const float* w_jacobian, const float* b_jacobian,
                        float* density, float* color, float* flow, float* jacobian, float* geo, void* stream);
 

@@ -197,15 +197,16 @@ __device__ __forceinline__ void point_geometry(const CamCtx& c, float px, float 
   g.w11 = fy * fx;
 }
 
-// h += bilerp(G)[128 channels starting at `gz`]; lane (j,hh) takes channels 64*hh .. 64*hh+63.
+// h += bilerp(G)[32*MB channels starting at `gz`]; lane (j,hh) takes channels 16*MB*hh .. 16*MB*hh + 16*MB - 1.
+template <int MB>
 __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int hh,
-                                                   f32x16 (&h)[4]) {
-  const float* p00 = gz + g.t00 + 64 * hh;
-  const float* p01 = gz + g.t01 + 64 * hh;
-  const float* p10 = gz + g.t10 + 64 * hh;
-  const float* p11 = gz + g.t11 + 64 * hh;
+                                                   f32x16 (&h)[MB]) {
+  const float* p00 = gz + g.t00 + 16 * MB * hh;
+  const float* p01 = gz + g.t01 + 16 * MB * hh;
+  const float* p10 = gz + g.t10 + 16 * MB * hh;
+  const float* p11 = gz + g.t11 + 16 * MB * hh;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < MB; ++m) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int o = 16 * m + 4 * q;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     mma_chunk<4, 2, 0, false, 2>(wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
   for (int blk = 0; blk < 5; ++blk) {
-    if (blk < 3) add_hoisted_latent(gz + blk * 128, g, hh, h);
+    if (blk < 3) add_hoisted_latent<4>(gz + blk * 128, g, hh, h);
     const float* bl = bias + blk * 256;
     bias_init<4, true>(bl, hh, net);
     {
@@ -345,6 +346,96 @@ __device__ __forceinline__ void color_tile(WeightStream& st, const float* __rest
   mma_chunk<2, 2, 0, true, 2>(wl + 2048, lane, a, b);
   bias_init<1, true>(bias + 64, hh, rgb);
   mma_chunk<1, 2, 0, true, 2>(wl + 6144, lane, b, rgb);
+}
+
+// ------------------------------------------------------------------------------------------
+// Jacobian transformer head (action_decoder_jacobian.py:418-446 + model_components/transformer.py:85-135),
+// algebraically folded on the host (decoder.py::ActionDecoderJacobianTransformer.packed):
+//   x0 = W_pe*pe + bilerp(G_q)                      (jacobian_query_mlp split into PE part + hoisted feature part)
+//   per layer:  n = norm(x);  dots = Mqk*n + bqk    (to_q, K=to_kv(z)[:, :512], LayerNorm affine and the softmax
+//               a = softmax_8(dots)                  scale folded into one 64x64 matrix; rows ordered head*8 + key)
+//               x += Nov*a + bo                      (V and to_out folded into one 64x64 matrix)
+//               n = norm(x);  x += W2*gelu(W1'*n + b1') + b2
+//   J = Wj*x + bj
+// Weight stream: 14 half-chunks of 4096 floats [query | (Mqk, Nov, W1', W2) x 3 | head] = 7 chunks.
+// bias (LDS): [bqk | bo | b1' | b2] (64 each) x 3 | head (32).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void norm64(const f32x16 (&x)[2], f32x16 (&n)[2]) {
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += x[m][r];
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / 64.0f;
+  float v = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = x[m][r] - mean;
+      v = fmaf(d, d, v);
+    }
+  v += __shfl_xor(v, 32, 64);
+  const float rstd = 1.0f / sqrtf(v / 64.0f + 1e-5f);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) n[m][r] = (x[m][r] - mean) * rstd;
+}
+
+__device__ __forceinline__ void transformer_tile(WeightStream& st, const float* __restrict__ bias,
+                                                 const float* __restrict__ gq, const PointGeom& g,
+                                                 const f32x16 (&pe)[2], int keys, int wave, int lane, f32x16 (&out)[1]) {
+  const int hh = lane >> 5;
+  f32x16 x[2], n[2], t[2];
+  x[0] = (f32x16)(0.f);
+  x[1] = (f32x16)(0.f);
+  const float* wl = stream_step(st, wave, lane);
+  mma_chunk<2, 2, 0, false, 2>(wl, lane, pe, x);  // query MLP, PE part (bias in slot 63)
+  add_hoisted_latent<2>(gq, g, hh, x);            // query MLP, feature part (hoisted)
+  for (int l = 0; l < 3; ++l) {
+    const float* bl = bias + 256 * l;
+    norm64(x, n);
+    bias_init<2, true>(bl, hh, t);
+    mma_chunk<2, 2, 0, false, 2>(wl + 4096, lane, n, t);  // dots[head*8 + key]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int h8 = 0; h8 < 2; ++h8) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+          if (a < keys) mx = fmaxf(mx, t[m][8 * h8 + a]);
+        float e[8], sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          e[a] = (a < keys) ? expf(t[m][8 * h8 + a] - mx) : 0.f;
+          sum += e[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) t[m][8 * h8 + a] = e[a] / sum;
+      }
+    }
+    wl = stream_step(st, wave, lane);
+    bias_init<2, false>(bl + 64, hh, x);
+    mma_chunk<2, 2, 0, false, 2>(wl, lane, t, x);  // x += to_out(attn @ V)
+    norm64(x, n);
+    bias_init<2, true>(bl + 128, hh, t);
+    mma_chunk<2, 2, 0, false, 2>(wl + 4096, lane, n, t);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = t[m][r];
+        t[m][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (nn.GELU default)
+      }
+    wl = stream_step(st, wave, lane);
+    bias_init<2, false>(bl + 192, hh, x);
+    mma_chunk<2, 2, 0, false, 2>(wl, lane, t, x);  // x += FF
+  }
+  bias_init<1, true>(bias + 768, hh, out);
+  mma_chunk<1, 2, 0, false, 2>(wl + 4096, lane, x, out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -155,6 +155,17 @@ extern "C" int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, fl
   return njf_pack_resnetfc_ld(src, w_out, b_out, wz_out, 384, bz_out, stream);
 }
 
+extern "C" int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kind, float* w_out, float* b_out,
+                               void* stream) {
+  if (!w || !w_out) return NJF_E_NULL;
+  if (d_out < 1 || d_in < 1) return NJF_E_SHAPE;
+  if (kind == 1 && (d_in != NJF_PE_DIM || !b)) return NJF_E_SHAPE;
+  if (kind != 0 && kind != 1) return NJF_E_MODE;
+  const int mb = (d_out + 31) / 32, kb = kind == 1 ? 2 : (d_in + 31) / 32;
+  launch_pack(w, b, d_out, d_in, mb, kb, kind, w_out, b_out, (hipStream_t)stream);
+  return launch_status();
+}
+
 extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, void* stream) {
   if (!src || !w_out || !b_out || !src->w0 || !src->b0 || !src->w1 || !src->b1 || !src->w2 || !src->b2) return NJF_E_NULL;
   hipStream_t s = (hipStream_t)stream;
@@ -450,8 +461,9 @@ struct TileOut {
   float flow[3];
 };
 
-// bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian 1312]
-template <bool WITH_J>
+// bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian head (MLP 1312 / transformer 800)]
+// JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
+template <int JKIND>
 __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __restrict__ gz_d,
                                              const float* __restrict__ gz_j, const PointGeom& g, float dirx, float diry,
                                              float dirz, const float* __restrict__ action, int action_dim, int wave,
@@ -475,8 +487,9 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
       o.rgb[c] = 1.0f / (1.0f + expf(-x));
     }
   }
-  if (WITH_J) {
-    resnet_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
+  if (JKIND != 0) {
+    if (JKIND == 1) resnet_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
+    else transformer_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
     // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
     // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
     float ph[3] = {0.f, 0.f, 0.f};
@@ -515,8 +528,11 @@ struct RenderArgs {
   NjfRenderOutputs out;
 };
 
-template <bool WITH_J>
+template <int JKIND>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
+  constexpr bool WITH_J = JKIND != 0;
+  constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
+  constexpr int J_BIAS = JKIND == 1 ? NJF_RESNET_B_FLOATS : NJF_TRANSFORMER_B_FLOATS;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
@@ -529,10 +545,10 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
 
   load_bias_block(a.b_d, NJF_RESNET_B_FLOATS, 0);
   load_bias_block(a.b_c, NJF_COLOR_B_FLOATS, NJF_RESNET_B_FLOATS);
-  if (WITH_J) load_bias_block(a.b_j, NJF_RESNET_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
+  if (WITH_J) load_bias_block(a.b_j, J_BIAS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
   const int tiles = (S + 31) >> 5;
   WeightStream st;
-  stream_begin(st, a.w_all, WITH_J ? 2 * NJF_RESNET_CHUNKS + 1 : NJF_RESNET_CHUNKS + 1, tiles, wave, lane);
+  stream_begin(st, a.w_all, NJF_RESNET_CHUNKS + 1 + J_CHUNKS, tiles, wave, lane);
 
   CamCtx cam;
   load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
@@ -569,7 +585,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
     TileOut o;
     f32x16 geo[1], jac[1];
-    decoder_tile<WITH_J>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac);
+    decoder_tile<JKIND>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac);
     const float w = tile_weights(end - start, o.sigma, valid, j, carry);
     if (valid) {
       acc_w += w;
@@ -700,7 +716,8 @@ struct PointsArgs {
   float* geo;
 };
 
-// MODE 0: proposal net (density only); 1: decoder without Jacobian head; 2: full decoder
+// MODE 0: proposal net (density only); 1: decoder without Jacobian head; 2: decoder + ResnetFC Jacobian head;
+// 3: decoder + transformer Jacobian head
 template <int MODE>
 __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   const int tid = threadIdx.x;
@@ -716,8 +733,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   load_bias_block(a.b_d, NJF_RESNET_B_FLOATS, 0);
   if (MODE >= 1) load_bias_block(a.b_c, NJF_COLOR_B_FLOATS, NJF_RESNET_B_FLOATS);
   if (MODE == 2) load_bias_block(a.b_j, NJF_RESNET_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
+  if (MODE == 3) load_bias_block(a.b_j, NJF_TRANSFORMER_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
   WeightStream st;
-  stream_begin(st, a.w_all, MODE == 0 ? NJF_RESNET_CHUNKS : (MODE == 1 ? NJF_RESNET_CHUNKS + 1 : 2 * NJF_RESNET_CHUNKS + 1),
+  stream_begin(st, a.w_all,
+               MODE == 0 ? NJF_RESNET_CHUNKS
+                         : NJF_RESNET_CHUNKS + 1 + (MODE == 2 ? NJF_RESNET_CHUNKS : (MODE == 3 ? NJF_TRANSFORMER_CHUNKS : 0)),
                1, wave, lane);
   CamCtx cam;
   load_ctx(a.cams.ctxt_w2c, a.cams.ctxt_k, b, cam);
@@ -743,8 +763,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
     TileOut o;
     f32x16 geo[1], jac[1];
     // NOTE: `action` is per lane here (tiles may straddle batch elements)
-    decoder_tile<MODE == 2>(st, a.gmap.data + gbase + a.goff_d, a.gmap.data + gbase + a.goff_j, g, dx, dy, dz, action, A,
-                            wave, lane, o, geo, jac);
+    decoder_tile<(MODE >= 2 ? MODE - 1 : 0)>(st, a.gmap.data + gbase + a.goff_d, a.gmap.data + gbase + a.goff_j, g, dx, dy,
+                                             dz, action, A, wave, lane, o, geo, jac);
     if (ok) {
       if (hh == 0) {
         if (a.density) a.density[p] = o.sigma;
@@ -753,7 +773,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
           a.color[3 * (size_t)p + 1] = o.rgb[1];
           a.color[3 * (size_t)p + 2] = o.rgb[2];
         }
-        if (a.flow && MODE == 2) {
+        if (a.flow && MODE >= 2) {
           a.flow[3 * (size_t)p] = o.flow[0];
           a.flow[3 * (size_t)p + 1] = o.flow[1];
           a.flow[3 * (size_t)p + 2] = o.flow[2];
@@ -763,7 +783,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
           for (int r = 0; r < 15; ++r) a.geo[15 * (size_t)p + r] = geo[0][r];
         }
       }
-      if (MODE == 2 && a.jacobian) {
+      if (MODE >= 2 && a.jacobian) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int d = 16 * hh + r;
@@ -852,8 +872,8 @@ static int check_common(const float* origins, const float* directions, int rays_
   return NJF_OK;
 }
 
-static int check_gmap(const NjfFeatureMap* gmap, int off) {
-  if (off < 0 || (off & 3) || (gmap->stride & 3) || off + NJF_ZDIM > gmap->stride) return NJF_E_GMAP;
+static int check_gmap(const NjfFeatureMap* gmap, int off, int channels = NJF_ZDIM) {
+  if (off < 0 || (off & 3) || (gmap->stride & 3) || off + channels > gmap->stride) return NJF_E_GMAP;
   return NJF_OK;
 }
 
@@ -898,6 +918,16 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
 
 // The decoder blobs must be one allocation laid out [density | colour | jacobian] (what
 // njf_pack_* write when given consecutive destinations); the launcher verifies contiguity.
+static int check_jacobian(int kind, const NjfCameras* cams, const NjfFeatureMap* gmap, int goff_j, const float* w_j,
+                          const float* b_j) {
+  if (kind == NJF_JACOBIAN_NONE) return NJF_OK;
+  if (kind != NJF_JACOBIAN_MLP && kind != NJF_JACOBIAN_TRANSFORMER) return NJF_E_MODE;
+  if (!w_j || !b_j) return NJF_E_NULL;
+  const int max_a = kind == NJF_JACOBIAN_MLP ? NJF_MAX_ACTION_DIM : 8;  // transformer: 8 key slots per head
+  if (cams->action_dim < 1 || cams->action_dim > max_a) return NJF_E_ACTION_DIM;
+  return check_gmap(gmap, goff_j, kind == NJF_JACOBIAN_MLP ? NJF_ZDIM : NJF_QDIM);
+}
+
 static int check_contiguous(const float* w_d, const float* w_c, const float* w_j, bool with_j) {
   if (w_c != w_d + NJF_RESNET_W_FLOATS) return NJF_E_SHAPE;
   if (with_j && w_j != w_c + NJF_COLOR_W_FLOATS) return NJF_E_SHAPE;
@@ -906,19 +936,17 @@ static int check_contiguous(const float* w_d, const float* w_c, const float* w_j
 
 extern "C" int njf_render_forward(const float* origins, const float* directions, int rays_per_batch,
                                   const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset_density,
-                                  int gmap_offset_jacobian, const float* w_density, const float* b_density,
-                                  const float* w_color, const float* b_color, const float* w_jacobian,
-                                  const float* b_jacobian, const float* bins, int samples, const NjfRenderOutputs* out,
-                                  void* stream) {
+                                  int gmap_offset_jacobian, int jacobian_kind, const float* w_density,
+                                  const float* b_density, const float* w_color, const float* b_color,
+                                  const float* w_jacobian, const float* b_jacobian, const float* bins, int samples,
+                                  const NjfRenderOutputs* out, void* stream) {
   int rc = check_common(origins, directions, rays_per_batch, cams, gmap);
   if (rc) return rc;
   if (!w_density || !b_density || !w_color || !b_color || !bins || !out) return NJF_E_NULL;
   if (samples < 1) return NJF_E_SAMPLES;
-  const bool with_j = w_jacobian != nullptr;
-  if (with_j && !b_jacobian) return NJF_E_NULL;
-  if (with_j && (cams->action_dim < 1 || cams->action_dim > NJF_MAX_ACTION_DIM)) return NJF_E_ACTION_DIM;
   if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
-  if (with_j && (rc = check_gmap(gmap, gmap_offset_jacobian))) return rc;
+  if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
+  const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
   RenderArgs a;
   a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
@@ -931,13 +959,15 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.bins = bins;
   a.samples = samples;
   a.out = *out;
-  if (with_j) return launch_fused(render_kernel<true>, a, a.rc.total_rays, (hipStream_t)stream);
-  return launch_fused(render_kernel<false>, a, a.rc.total_rays, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1>, a, a.rc.total_rays, s);
+  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2>, a, a.rc.total_rays, s);
+  return launch_fused(render_kernel<0>, a, a.rc.total_rays, s);
 }
 
 extern "C" int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
                                   const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
-                                  const float* w_density, const float* b_density, const float* w_color,
+                                  int jacobian_kind, const float* w_density, const float* b_density, const float* w_color,
                                   const float* b_color, const float* w_jacobian, const float* b_jacobian, float* density,
                                   float* color, float* flow, float* jacobian, float* geo, void* stream) {
   if (!xyz || !cams || !gmap || !w_density || !b_density) return NJF_E_NULL;
@@ -968,13 +998,10 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) return launch_fused(points_kernel<0>, a, tiles, s);
   if (!w_color || !b_color) return NJF_E_NULL;
-  const bool with_j = w_jacobian != nullptr;
-  if (with_j) {
-    if (!b_jacobian) return NJF_E_NULL;
-    if (cams->action_dim < 1 || cams->action_dim > NJF_MAX_ACTION_DIM) return NJF_E_ACTION_DIM;
-    if ((rc = check_gmap(gmap, gmap_offset_jacobian))) return rc;
-  }
+  if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
+  const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
-  if (with_j) return launch_fused(points_kernel<2>, a, tiles, s);
+  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2>, a, tiles, s);
+  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3>, a, tiles, s);
   return launch_fused(points_kernel<1>, a, tiles, s);
 }

@@ -196,54 +196,58 @@ class ActionDecoder(nn.Module, ABC):
     def freeze_non_action_parameters(self) -> int: ...
 
 
-class ActionDecoderJacobianMLP(ActionDecoder):
-    """density_head (d_out=16) + jacobian_head (d_out=3A) + color_head, evaluated by one fused kernel."""
+class ActionDecoderJacobian(ActionDecoder):
+    """Shared machinery of the two Jacobian decoders (action_decoder_jacobian.py:86-258): density_head (d_out=16)
+    + colour head + a Jacobian head, evaluated by one fused kernel.  Subclasses define the Jacobian head's
+    parameters, its packed form and the width of its hoisted feature channels."""
 
     spatial_dim: int = 3
-    action_param_glob_pattern = "jacobian_head"
+    JACOBIAN_KIND = hip.JACOBIAN_NONE
+    J_W_FLOATS = 0
+    J_B_FLOATS = 0
+    J_HOIST = 0
+    GOFF_DENSITY, GOFF_JACOBIAN = 0, hip.ZDIM
 
-    def __init__(self, cfg: ActionDecoderJacobianMlpCfg, action_dim: int, encoder_dim: int):
-        super().__init__(cfg)
+    def _init_common(self, cfg, action_dim: int, encoder_dim: int, max_action: int):
         if cfg.num_frequencies != 10 or cfg.geometry_feature_dim != 15:
             raise ValueError("fused path supports num_frequencies=10 and geometry_feature_dim=15")
         if cfg.use_arm_model:
             raise NotImplementedError("use_arm_model (second Jacobian head) is not part of the fused path")
-        if not (1 <= action_dim <= hip.MAX_ACTION_DIM):
-            raise ValueError(f"action_dim must be in [1, {hip.MAX_ACTION_DIM}]")
+        if not (1 <= action_dim <= max_action):
+            raise ValueError(f"action_dim must be in [1, {max_action}] for {cfg.name}")
         self.action_dim = action_dim
         self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=cfg.geometry_feature_dim + 1)
-        self.jacobian_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim * action_dim)
-        self.jacobian_head.apply(initialize_jacobian_weights)
         self.mode = "regular"
-        self.color_head = nn.Sequential(
-            nn.Linear(cfg.geometry_feature_dim + 16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 3),
-            nn.Sigmoid())
         self._packed_version = None
         self._hoist = _HoistCache()
+
+    def _make_color_head(self, cfg):
+        return nn.Sequential(nn.Linear(cfg.geometry_feature_dim + 16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(),
+                             nn.Linear(64, 3), nn.Sigmoid())
 
     def switch_mode(self, mode: str):
         self.mode = mode
 
     # ---- packed state ----------------------------------------------------------------
-    GOFF_DENSITY, GOFF_JACOBIAN = 0, hip.ZDIM
+    def _pack_jacobian(self, params, w_j, b_j, wz, bz):  # pragma: no cover - abstract
+        raise NotImplementedError
 
     def packed(self):
         v = _version(self)
         if v != self._packed_version:
             dev = self.density_head.lin_in.weight.device
             f32 = dict(dtype=torch.float32, device=dev)
-            self._w = torch.empty(2 * hip.RESNET_W_FLOATS + hip.COLOR_W_FLOATS, **f32)
+            n = hip.RESNET_W_FLOATS
+            self._w = torch.zeros(n + hip.COLOR_W_FLOATS + self.J_W_FLOATS, **f32)
             self._bd = torch.empty(hip.RESNET_B_FLOATS, **f32)
             self._bc = torch.empty(hip.COLOR_B_FLOATS, **f32)
-            self._bj = torch.empty(hip.RESNET_B_FLOATS, **f32)
-            self._wz = torch.empty(512, 2 * hip.ZDIM, **f32)
-            self._bz = torch.empty(2 * hip.ZDIM, **f32)
+            self._bj = torch.zeros(self.J_B_FLOATS, **f32)
+            self._wz = torch.zeros(512, hip.ZDIM + self.J_HOIST, **f32)
+            self._bz = torch.zeros(hip.ZDIM + self.J_HOIST, **f32)
             params = {k: p for k, p in self.named_parameters()}
-            n = hip.RESNET_W_FLOATS
             hip.pack_resnetfc(params, "density_head.", self._w[:n], self._bd, self._wz, 0, self._bz)
             hip.pack_color_head(params, "color_head.", self._w[n:n + hip.COLOR_W_FLOATS], self._bc)
-            hip.pack_resnetfc(params, "jacobian_head.", self._w[n + hip.COLOR_W_FLOATS:], self._bj, self._wz, hip.ZDIM,
-                              self._bz)
+            self._pack_jacobian(params, self._w[n + hip.COLOR_W_FLOATS:], self._bj, self._wz, self._bz)
             self._packed_version = v
         return self._w, self._bd, self._bc, self._bj
 
@@ -268,8 +272,8 @@ class ActionDecoderJacobianMLP(ActionDecoder):
                 out["flow"] = torch.empty(b, n, 3, **f32)
         hip.points_forward(xyz_flat.contiguous(), None if dirs_flat is None else dirs_flat.contiguous(),
                            _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.action_dim), fmap,
-                           self.GOFF_DENSITY,
-                           self.GOFF_JACOBIAN, 1, w, bd, bc, bj, with_jacobian=with_jacobian, **out)
+                           self.GOFF_DENSITY, self.GOFF_JACOBIAN, 1, w, bd, bc, bj,
+                           jacobian_kind=self.JACOBIAN_KIND if with_jacobian else hip.JACOBIAN_NONE, **out)
         return out
 
     # ---- reference API -----------------------------------------------------------------
@@ -310,11 +314,127 @@ class ActionDecoderJacobianMLP(ActionDecoder):
         return count
 
 
+class ActionDecoderJacobianMLP(ActionDecoderJacobian):
+    """action_decoder_jacobian.py:261-337: Jacobian head = ResnetFC(d_out=3A)."""
+
+    action_param_glob_pattern = "jacobian_head"
+    JACOBIAN_KIND = hip.JACOBIAN_MLP
+    J_W_FLOATS, J_B_FLOATS, J_HOIST = hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM
+
+    def __init__(self, cfg: ActionDecoderJacobianMlpCfg, action_dim: int, encoder_dim: int):
+        super().__init__(cfg)
+        self._init_common(cfg, action_dim, encoder_dim, hip.MAX_ACTION_DIM)
+        self.jacobian_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim * action_dim)
+        self.jacobian_head.apply(initialize_jacobian_weights)
+        self.color_head = self._make_color_head(cfg)
+
+    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+        hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz)
+
+
+# ---- parameter tree of model_components/transformer.py (names only; arithmetic is folded + fused) ----
+class _PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+class _CrossAttention(nn.Module):
+    def __init__(self, dim, heads, dim_head, kv_dim):
+        super().__init__()
+        inner = heads * dim_head
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(kv_dim, inner * 2, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(0.0))
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), nn.Linear(hidden, dim), nn.Dropout(0.0))
+
+
+class _TransformerParams(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, kv_dim):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            nn.ModuleList([_PreNorm(dim, _CrossAttention(dim, heads, dim_head, kv_dim)), _PreNorm(dim, _FeedForward(dim, mlp_dim))])
+            for _ in range(depth)])
+
+
+class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
+    """action_decoder_jacobian.py:340-446: query MLP -> 3 x (cross-attention to A learned tokens, GELU FF) -> Linear.
+
+    The fused kernel evaluates an algebraically folded form (exact algebra, fp64 folding, fp32 evaluation):
+      * ``jacobian_query_mlp`` splits into a positional-encoding part (in-kernel) and a feature part that is
+        hoisted into the per-image map exactly like ``lin_z``;
+      * keys/values depend only on the learned ``jacobian_index_embedding`` (they are not layer-normed and shared
+        by all points, transformer.py:63-70), so ``softmax(to_q(LN x) K^T / 8) V -> to_out`` becomes
+        ``Nov . softmax_8(Mqk . norm(x) + bqk) + bo`` with two 64x64 matrices per layer (rows of ``Mqk`` ordered
+        head*8 + key; LayerNorm affine and the 1/sqrt(64) scale folded in);
+      * the feed-forward's LayerNorm affine is folded into its first Linear.
+    That is ~55 kMAC/point instead of the reference's 284 kMAC/point.
+    """
+
+    action_param_glob_pattern = "jacobian"
+    JACOBIAN_KIND = hip.JACOBIAN_TRANSFORMER
+    J_W_FLOATS, J_B_FLOATS, J_HOIST = hip.TRANSFORMER_W_FLOATS, hip.TRANSFORMER_B_FLOATS, hip.QDIM
+
+    def __init__(self, cfg: ActionDecoderJacobianTransformerCfg, action_dim: int, encoder_dim: int):
+        super().__init__(cfg)
+        t = cfg.transformer
+        if (t.attn_feat_dim, t.num_attn_heads, t.attn_depth, t.attn_mlp_dim) != (64, 8, 3, 64):
+            raise ValueError("fused transformer head supports attn_feat_dim=64, num_attn_heads=8, attn_depth=3, "
+                             "attn_mlp_dim=64 (configurations/model/model_allegro.yaml:34-39)")
+        self._init_common(cfg, action_dim, encoder_dim, 8)  # 8 key slots per head
+        self.jacobian_index_embedding = nn.Parameter(torch.randn(1, action_dim, t.attn_feat_dim), requires_grad=True)
+        self.jacobian_query_mlp = nn.Linear(encoder_dim + 63, t.attn_feat_dim)
+        self.jacobian_attn_decoder = _TransformerParams(t.attn_feat_dim, t.attn_depth, t.num_attn_heads, t.attn_head_dim,
+                                                        t.attn_mlp_dim, t.attn_feat_dim)
+        self.jacobian_head = nn.Linear(t.attn_feat_dim, self.spatial_dim * action_dim)
+        self.jacobian_head.apply(initialize_jacobian_weights)
+        self.color_head = self._make_color_head(cfg)
+
+    @torch.no_grad()
+    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+        t = self.cfg.transformer
+        heads, dh, a = t.num_attn_heads, t.attn_head_dim, self.action_dim
+        f32 = lambda x: x.to(torch.float32).contiguous()
+        half = lambda i: w_j[4096 * i: 4096 * (i + 1)]
+        qw = self.jacobian_query_mlp.weight  # [64, 63 + 512], input = cat[xyz_features, pixel_aligned_features] (:421-427)
+        hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0))
+        wz[:, hip.ZDIM:] = qw[:, 63:].t()
+        bz[hip.ZDIM:] = 0.0
+        z = self.jacobian_index_embedding[0].double()  # [A, 64]
+        for l, (attn, ff) in enumerate(self.jacobian_attn_decoder.layers):
+            g1, be1 = attn.norm.weight.double(), attn.norm.bias.double()
+            kv = z @ attn.fn.to_kv.weight.double().t()  # [A, 2*H*dh]
+            k = kv[:, : heads * dh].reshape(a, heads, dh).permute(1, 0, 2)  # [H, A, dh]
+            v = kv[:, heads * dh:].reshape(a, heads, dh).permute(1, 0, 2)
+            wq = attn.fn.to_q.weight.double().reshape(heads, dh, -1)  # [H, dh, 64]
+            mqk = torch.zeros(heads, 8, wq.shape[-1], dtype=torch.float64, device=z.device)
+            mqk[:, :a] = (dh ** -0.5) * torch.einsum("had,hdc->hac", k, wq)
+            mqk = mqk.reshape(heads * 8, -1)
+            wo = attn.fn.to_out[0].weight.double().reshape(-1, heads, dh)  # [64, H, dh]
+            nov = torch.zeros(wo.shape[0], heads, 8, dtype=torch.float64, device=z.device)
+            nov[:, :, :a] = torch.einsum("chd,had->cha", wo, v)
+            nov = nov.reshape(wo.shape[0], heads * 8)
+            g2, be2 = ff.norm.weight.double(), ff.norm.bias.double()
+            w1, b1 = ff.fn.net[0].weight.double(), ff.fn.net[0].bias.double()
+            bl = b_j[256 * l: 256 * (l + 1)]
+            hip.pack_linear(f32(mqk * g1[None, :]), f32(mqk @ be1), 0, half(1 + 4 * l), bl[0:64])
+            hip.pack_linear(f32(nov), attn.fn.to_out[0].bias, 0, half(2 + 4 * l), bl[64:128])
+            hip.pack_linear(f32(w1 * g2[None, :]), f32(w1 @ be2 + b1), 0, half(3 + 4 * l), bl[128:192])
+            hip.pack_linear(ff.fn.net[3].weight, ff.fn.net[3].bias, 0, half(4 + 4 * l), bl[192:256])
+        hip.pack_linear(self.jacobian_head.weight, self.jacobian_head.bias, 0, half(13)[:2048], b_j[768:800])
+
+
 # --------------------------------------------------------------------------------------
 # registries (models/decoder/__init__.py:11-44)
 # --------------------------------------------------------------------------------------
 DENSITY_DECODERS = {"density_mlp": DensityDecoderMlp}
-ACTION_DECODERS = {"jacobian_mlp": ActionDecoderJacobianMLP}
+ACTION_DECODERS = {"jacobian_mlp": ActionDecoderJacobianMLP, "jacobian_transformer": ActionDecoderJacobianTransformer}
 
 
 def get_density_decoder(cfg: DensityDecoderCfg, encoder_dim: int) -> DensityDecoderMlp:

@@ -22,6 +22,10 @@ RESNET_W_FLOATS = 22 * 8192
 RESNET_B_FLOATS = 10 * 128 + 32
 COLOR_W_FLOATS = 8192
 COLOR_B_FLOATS = 96
+TRANSFORMER_W_FLOATS = 7 * 8192
+TRANSFORMER_B_FLOATS = 3 * 256 + 32
+QDIM = 64
+JACOBIAN_NONE, JACOBIAN_MLP, JACOBIAN_TRANSFORMER = 0, 1, 2
 
 _vp = C.c_void_p
 
@@ -64,15 +68,16 @@ _SIGNATURES = {
     "njf_pack_resnetfc": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, _vp, _vp], C.c_int),
     "njf_pack_resnetfc_ld": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
     "njf_pack_color_head": ([C.POINTER(ColorHeadWeights), _vp, _vp, _vp], C.c_int),
+    "njf_pack_linear": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_project_features": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
                               _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp], C.c_int),
-    "njf_render_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int,
+    "njf_render_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
-                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+                            C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
 }
@@ -178,6 +183,15 @@ def pack_color_head(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.T
     _check(load_library().njf_pack_color_head(C.byref(src), _ptr(w_out), _ptr(b_out), _stream()))
 
 
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], kind: int, w_out: torch.Tensor,
+                b_out: Optional[torch.Tensor] = None) -> None:
+    """One Linear [d_out, d_in] -> fragment-major block (see include/njf_hip.h: njf_pack_linear)."""
+    d_out, d_in = weight.shape
+    _check(load_library().njf_pack_linear(_ptr(weight.detach().contiguous(), "weight"),
+                                          _ptr(None if bias is None else bias.detach().contiguous(), "bias"), d_out, d_in,
+                                          kind, _ptr(w_out, "w_out"), _ptr(b_out, "b_out"), _stream()))
+
+
 def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor) -> None:
     """feats [B,512,Hf,Wf]; wz [512,N]; bz [N]; out [B,Hf,Wf,N]."""
     b, k, hf, wf = feats.shape
@@ -208,32 +222,34 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
 
 def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int,
                    w_all: torch.Tensor, b_density, b_color, b_jacobian, bins, samples: int, outputs: Dict[str, torch.Tensor],
-                   with_jacobian: bool = True) -> None:
-    """``w_all`` is the single allocation [density | colour | jacobian] of packed weights."""
+                   jacobian_kind: int = JACOBIAN_MLP) -> None:
+    """``w_all`` is the single allocation [density | colour | jacobian head] of packed weights."""
     rays_per_batch = origins.shape[1]
     out = RenderOutputs()
     for name, _ in RenderOutputs._fields_:
         setattr(out, name, _ptr(outputs.get(name), name))
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS
-    w_j = w_c + 4 * COLOR_W_FLOATS if with_jacobian else None
+    with_j = jacobian_kind != JACOBIAN_NONE
+    w_j = w_c + 4 * COLOR_W_FLOATS if with_j else None
     _check(load_library().njf_render_forward(
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian,
-        base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_jacobian else None,
+        jacobian_kind, base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_j else None,
         _ptr(bins), samples, C.byref(out), _stream()))
 
 
 def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int, mode: int,
-                   w_all, b_density, b_color=None, b_jacobian=None, with_jacobian: bool = False, density=None, color=None,
-                   flow=None, jacobian=None, geo=None) -> None:
+                   w_all, b_density, b_color=None, b_jacobian=None, jacobian_kind: int = JACOBIAN_NONE, density=None,
+                   color=None, flow=None, jacobian=None, geo=None) -> None:
     points_per_batch = xyz.shape[1]
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS if mode == 1 else None
-    w_j = (w_c + 4 * COLOR_W_FLOATS) if (mode == 1 and with_jacobian) else None
+    with_j = mode == 1 and jacobian_kind != JACOBIAN_NONE
+    w_j = (w_c + 4 * COLOR_W_FLOATS) if with_j else None
     _check(load_library().njf_points_forward(
         _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
-        base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if w_j else None,
-        _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo), _stream()))
+        jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,
+        _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo), _stream()))
 
 
 def alpha_weights(deltas, densities, weights) -> None:

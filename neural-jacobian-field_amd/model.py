@@ -229,7 +229,7 @@ class Model(nn.Module):
                         torch.linalg.inv(camera_input.trgt_extrinsics).contiguous(),
                         camera_input.trgt_intrinsics.contiguous())
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
-                           outs, with_jacobian=True)
+                           outs, jacobian_kind=self.decoder.JACOBIAN_KIND)
         # tensor-global clip of model.py:277
         outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
                                     max=outs["step_minmax"][..., 1].max())

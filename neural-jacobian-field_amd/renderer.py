@@ -180,7 +180,8 @@ class FusedRenderer:
                 outs["sample_flow"] = torch.empty(b, r, s, 3, **f32)
                 outs["jacobian"] = torch.empty(b, r, s, 3 * self.action_dim, **f32)
         hip.render_forward(origins, directions, cams, fmap, self.goff_density, self.goff_jacobian, self.w_dec,
-                           self.b_density, self.b_color, self.b_jacobian, bins, s, outs, with_jacobian=with_j)
+                           self.b_density, self.b_color, self.b_jacobian, bins, s, outs,
+                           jacobian_kind=hip.JACOBIAN_MLP if with_j else hip.JACOBIAN_NONE)
         if _events:
             _events[2].record()
         depth = outs["depth"]

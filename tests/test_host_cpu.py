@@ -58,7 +58,7 @@ def test_product_package_never_imports_the_oracle():
                 assert "njf_oracle" not in src and "parity_harness" not in src, f
 
 
-@pytest.mark.parametrize("tag,kind,adim", [("mlp", "jacobian_mlp", 8)])
+@pytest.mark.parametrize("tag,kind,adim", [("mlp", "jacobian_mlp", 8), ("transformer", "jacobian_transformer", 6)])
 def test_model_state_dict_matches_reference_manifest(tag, kind, adim):
     from neural_jacobian_field_amd.config import model_cfg_from_dict
     from neural_jacobian_field_amd.model import Model

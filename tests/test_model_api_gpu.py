@@ -195,3 +195,45 @@ def test_generic_sampler_route_equals_fused_route(model_and_golden):
     assert rel(wl[0], wl2[0]) < 1e-5
     assert rel(smp.spacing_bins(), bins) < 1e-5
     assert rel(wl[0], g["prop_weights"]) < 5e-4
+
+
+# ---- jacobian_transformer decoder (default Allegro head; fixture uses A=6 -> exercises key masking) ----
+@pytest.fixture(scope="module")
+def transformer_model_and_golden(dev, golden):
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    g = golden("model_transformer")
+    cfg = model_cfg_from_dict({"action_dim": 6, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                               "action_decoder": {"name": "jacobian_transformer"}})
+    model = Model(cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_transformer", 6), seed=0), strict=True)
+    model.to(dev).eval()
+    return model, {k: v.to(dev) for k, v in g.items()}
+
+
+def test_transformer_decoder_at_reference_sample_locations(transformer_model_and_golden):
+    from neural_jacobian_field_amd.decoder import PixelEncoding
+    model, g = transformer_model_and_golden
+    enc = PixelEncoding(g["features"], g["ctxt_c2w"], g["ctxt_k_norm"], g["action"])
+    pos = g["final_positions"]
+    dirs = g["directions"][..., None, :].expand(pos.shape).contiguous()
+    dec = model.decoder.forward(pos, dirs, enc)
+    # identity-context batch element: tight
+    assert rel(dec.action_features[0], g["dec_action_features"][0]) < 1e-4
+    assert rel(dec.flow[0], g["dec_flow"][0]) < 1e-4
+    assert rel(dec.density[0], g["dec_density"][0]) < 1e-4
+    # general pose element: bounded by the encoding's ulp amplification
+    assert rel(dec.action_features, g["dec_action_features"]) < 5e-4
+    assert rel(dec.color, g["dec_color"]) < 5e-4
+    fo = model.decoder.encode_image(pos, enc)
+    assert rel(fo.action_features, g["enc_action_features"]) < 5e-4
+
+
+def test_transformer_model_forward_vs_reference_golden(transformer_model_and_golden):
+    model, g = transformer_model_and_golden
+    out = model.forward(*_inputs(g), compute_vis_features=True)
+    assert rel(out.standard_output.rgb, g["rgb"]) < 1e-4
+    assert rel(out.standard_output.depth, g["depth"]) < 5e-4
+    assert rel(out.standard_output.optical_flow, g["optical_flow"]) < 1e-3
+    assert rel(out.vis_output.action_features, g["vis_action_features"]) < 1e-3
