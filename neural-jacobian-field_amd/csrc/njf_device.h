@@ -14,19 +14,25 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define NJF_WAVES 8
+// Workgroup = 4 waves (one per SIMD), two workgroups resident per CU: the two waves sharing a SIMD's
+// MFMA pipe belong to DIFFERENT workgroups, so one workgroup's barrier / gather / encoding phases are
+// covered by the other's MFMA stream (with one 8-wave workgroup both waves of a SIMD stall together).
+#define NJF_WAVES 4
 #define NJF_THREADS (NJF_WAVES * 64)
 #define NJF_CHUNK 8192  // floats per weight chunk (32 KiB)
 
 // LDS carve (floats).  One dynamic array only (a second __shared__ object makes hipcc drain
-// vmcnt(0) in front of every ds_read of a DMA pipeline).
+// vmcnt(0) in front of every ds_read of a DMA pipeline).  Sized per kernel so that two workgroups
+// fit in the CU's 160 KiB: 2 x 32 KiB weight buffers + biases (+ per-wave scratch of the PDF stage).
 #define LDS_W0 0
 #define LDS_W1 NJF_CHUNK
 #define LDS_BIAS (2 * NJF_CHUNK)
-#define LDS_BIAS_FLOATS 3072
-#define LDS_SCRATCH (LDS_BIAS + LDS_BIAS_FLOATS)
-#define LDS_SCRATCH_PER_WAVE 1056  // proposal pass: w'[<=256] | cdf[<=257] | bins[<=257] | spare
-#define LDS_TOTAL_FLOATS (LDS_SCRATCH + NJF_WAVES * LDS_SCRATCH_PER_WAVE)
+#define LDS_BIAS_FLOATS 2752        // density 1312 | colour 96 | Jacobian head <= 1312 (+ pad)
+#define LDS_BIAS_FLOATS_PROPOSAL 1344
+#define LDS_SCRATCH_PER_WAVE 528    // proposal pass: w'[<=256] | cdf[<=257] (+ pad)
+#define LDS_FLOATS_RENDER (LDS_BIAS + LDS_BIAS_FLOATS)
+#define LDS_FLOATS_PROPOSAL (LDS_BIAS + LDS_BIAS_FLOATS_PROPOSAL + NJF_WAVES * LDS_SCRATCH_PER_WAVE)
+#define LDS_SCRATCH_PROPOSAL (LDS_BIAS + LDS_BIAS_FLOATS_PROPOSAL)
 
 extern __shared__ __attribute__((aligned(16))) float njf_lds[];
 
@@ -49,14 +55,14 @@ struct WeightStream {
 };
 
 __device__ __forceinline__ void dma_chunk(const float* __restrict__ src, int buf, int wave, int lane) {
-  // 512 threads x 16 B = 8 KiB per round, 4 rounds per 32 KiB chunk.  LDS destination is
+  // 256 threads x 16 B = 4 KiB per round, 8 rounds per 32 KiB chunk.  LDS destination is
   // wave-uniform base + lane*16 (hardware), global source is per lane.
   float* dst = njf_lds + buf * NJF_CHUNK + wave * 256;
   const float* s = src + wave * 256 + lane * 4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + r * 2048),
-                                     (__attribute__((address_space(3))) void*)(dst + r * 2048), 16, 0, 0);
+  for (int r = 0; r < NJF_CHUNK / (NJF_THREADS * 4); ++r) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + r * NJF_THREADS * 4),
+                                     (__attribute__((address_space(3))) void*)(dst + r * NJF_THREADS * 4), 16, 0, 0);
   }
 }
 
@@ -71,6 +77,9 @@ __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, i
 }
 
 __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, int lane) {
+#ifdef NJF_ABLATE_BARRIER  // experiment builds only: weights stay whatever is in LDS (results are garbage)
+  return njf_lds + (st.idx++ & 1) * NJF_CHUNK;
+#endif
   __syncthreads();
   const float* cur = njf_lds + (st.idx & 1) * NJF_CHUNK;
   st.idx += 1;
@@ -87,6 +96,9 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
 template <int MBO, int NKB, int KB0, bool RELU, int KBI>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane, const f32x16 (&in)[KBI],
                                           f32x16 (&out)[MBO]) {
+  // hipcc schedules this fully unrolled body as groups of 4*MBO MFMAs and re-issues each group's ds_read_b128s
+  // two MFMAs (128 cycles) before the registers are needed, which covers the LDS latency; a hand-pipelined
+  // variant measured 1-2 % slower (round-1 A/B, tools/ablate.sh).
   const float* base = wl + lane * 4;
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
@@ -197,19 +209,25 @@ __device__ __forceinline__ void point_geometry(const CamCtx& c, float px, float 
   g.w11 = fy * fx;
 }
 
-// h += bilerp(G)[32*MB channels starting at `gz`]; lane (j,hh) takes channels 16*MB*hh .. 16*MB*hh + 16*MB - 1.
+// h += bilerp(G)[32*MB channels starting at `gz`].  Within a block of 32*MB channels the map stores logical
+// feature f = 16*MB*hh + 16*m + 4*q + e at position 32*m + 8*q + 4*hh + e (njf_hoist_position), so the two
+// lanes that own a point read ADJACENT 16-byte pieces in the same instruction: 32 distinct cache lines per
+// wave-instruction instead of 64 (the gather is TA tag-rate bound, not bandwidth bound).
 template <int MB>
 __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int hh,
                                                    f32x16 (&h)[MB]) {
-  const float* p00 = gz + g.t00 + 16 * MB * hh;
-  const float* p01 = gz + g.t01 + 16 * MB * hh;
-  const float* p10 = gz + g.t10 + 16 * MB * hh;
-  const float* p11 = gz + g.t11 + 16 * MB * hh;
+#ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
+  return;
+#endif
+  const float* p00 = gz + g.t00 + 4 * hh;
+  const float* p01 = gz + g.t01 + 4 * hh;
+  const float* p10 = gz + g.t10 + 4 * hh;
+  const float* p11 = gz + g.t11 + 4 * hh;
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int o = 16 * m + 4 * q;
+      const int o = 32 * m + 8 * q;
       const f32x4 a = *(const f32x4*)(p00 + o);
       const f32x4 b = *(const f32x4*)(p01 + o);
       const f32x4 c = *(const f32x4*)(p10 + o);
@@ -251,6 +269,11 @@ __device__ __forceinline__ float sin_accurate(float arg) {
 // [sin(s_{d,f}) (30) | x | y], hh=1 supplies [sin(s_{d,f} + pi/2) (30) | z | 1].
 // s = fl(fl(2*pi)*x) * 2^f exactly as nerfstudio's NeRFEncoding computes it in fp32.
 __device__ __forceinline__ void positional_encoding(float xc, float yc, float zc, int hh, f32x16 (&pe)[2]) {
+#ifdef NJF_ABLATE_PE  // experiment builds only
+  pe[0] = (f32x16)(xc);
+  pe[1] = (f32x16)(yc + zc);
+  return;
+#endif
   const float two_pi = 6.2831855f;
   const float half_pi = hh ? 1.5707964f : 0.0f;
   const float sx[3] = {two_pi * xc, two_pi * yc, two_pi * zc};

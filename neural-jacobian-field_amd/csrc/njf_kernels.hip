@@ -98,7 +98,14 @@ __global__ void fill_kernel(float* p, int n, float v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
-// lin_z.{0,1,2}.weight [128,512] -> wz[k * ld + 128*i + f]  (k-major: coalesced B operand of the projection)
+// position of logical feature f inside its 32*MB-channel block of the hoisted map (see add_hoisted_latent)
+__host__ __device__ inline int njf_hoist_position(int f, int mb_count) {
+  const int hh = f / (16 * mb_count), r = f % (16 * mb_count);
+  const int m = r >> 4, q = (r >> 2) & 3, e = r & 3;
+  return 32 * m + 8 * q + 4 * hh + e;
+}
+
+// lin_z.{0,1,2}.weight [128,512] -> wz[k * ld + 128*i + pos(f)]  (k-major: coalesced B operand of the projection)
 __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
                                  const float* b2, float* wz, int ld, float* bz) {
   const int n = 3 * 128 * 512;
@@ -106,12 +113,12 @@ __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* 
     const int c = i % 384, k = i / 384;
     const int l = c >> 7, f = c & 127;
     const float* w = l == 0 ? w0 : (l == 1 ? w1 : w2);
-    wz[(size_t)k * ld + c] = w[f * 512 + k];
+    wz[(size_t)k * ld + 128 * l + njf_hoist_position(f, 4)] = w[f * 512 + k];
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < 384; c += blockDim.x) {
       const int l = c >> 7, f = c & 127;
-      bz[c] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f];
+      bz[128 * l + njf_hoist_position(f, 4)] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f];
     }
 }
 
@@ -415,7 +422,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
               dz = a.rc.directions[3 * (size_t)rayc + 2];
   const float* gz = a.rc.gmap.data + (size_t)b * a.rc.gmap.height * a.rc.gmap.width * a.rc.gmap.stride + a.gmap_offset;
   const float* bins = a.bins_in + (a.bins_per_ray ? (size_t)rayc * (a.s_in + 1) : 0);
-  float* sc = njf_lds + LDS_SCRATCH + wave * LDS_SCRATCH_PER_WAVE;
+  float* sc = njf_lds + LDS_SCRATCH_PROPOSAL + wave * LDS_SCRATCH_PER_WAVE;
   const float* bias = njf_lds + LDS_BIAS;
 
   float carry = 0.f;
@@ -470,9 +477,11 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
                                              int lane, TileOut& o, f32x16 (&geo)[1], f32x16 (&jac)[1]) {
   const int j = lane & 31, hh = lane >> 5;
   const float* bias = njf_lds + LDS_BIAS;
-  f32x16 pe[2];
-  positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-  resnet_tile(st, bias, gz_d, g, pe, wave, lane, geo);
+  {
+    f32x16 pe[2];
+    positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+    resnet_tile(st, bias, gz_d, g, pe, wave, lane, geo);
+  }
   o.sigma = expf(__shfl(geo[0][15], j, 64) - 1.0f);
   {
     float sh[16];
@@ -488,6 +497,10 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     }
   }
   if (JKIND != 0) {
+    // the encoding is recomputed (~1 % of the head's time) rather than held in 32 VGPRs across density + colour
+    asm volatile("" ::: "memory");
+    f32x16 pe[2];
+    positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     if (JKIND == 1) resnet_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
     else transformer_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
     // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
@@ -838,7 +851,7 @@ __global__ void __launch_bounds__(NJF_THREADS) pdf_kernel(PdfArgs a) {
   const int ray = blockIdx.x * NJF_WAVES + wave;
   const bool ok = ray < a.rays;
   const int rayc = min(ray, a.rays - 1);
-  float* sc = njf_lds + LDS_SCRATCH + wave * LDS_SCRATCH_PER_WAVE;
+  float* sc = njf_lds + LDS_SCRATCH_PROPOSAL + wave * LDS_SCRATCH_PER_WAVE;
   for (int s = lane; s < a.s_in; s += 64) {
     float w = a.weights[(size_t)rayc * a.s_in + s];
     if (a.anneal != 1.0f) w = powf(w, a.anneal);
@@ -856,7 +869,7 @@ extern "C" int njf_pdf_resample(const float* weights, const float* bins_in, int 
   if (rays < 1 || s_out < 1) return NJF_E_SHAPE;
   if (s_in < 1 || s_in > 256) return NJF_E_SAMPLES;
   PdfArgs a{weights, bins_in, bins_per_ray, s_in, u, u_per_ray, s_out, anneal, rays, bins_out};
-  pdf_kernel<<<(rays + NJF_WAVES - 1) / NJF_WAVES, NJF_THREADS, LDS_TOTAL_FLOATS * sizeof(float), (hipStream_t)stream>>>(a);
+  pdf_kernel<<<(rays + NJF_WAVES - 1) / NJF_WAVES, NJF_THREADS, LDS_FLOATS_PROPOSAL * sizeof(float), (hipStream_t)stream>>>(a);
   return launch_status();
 }
 
@@ -878,10 +891,14 @@ static int check_gmap(const NjfFeatureMap* gmap, int off, int channels = NJF_ZDI
 }
 
 template <typename K, typename A>
-static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s) {
+static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, int lds_floats = LDS_FLOATS_RENDER) {
   static_assert(sizeof(A) <= 4096, "kernel args too large");
   const int grid = (work_items + NJF_WAVES - 1) / NJF_WAVES;
-  const size_t lds = LDS_TOTAL_FLOATS * sizeof(float);
+#ifdef NJF_ABLATE_ONE_WG_PER_CU  // experiment builds only: pad LDS so a single 4-wave workgroup owns the CU
+  const size_t lds = 100 * 1024;
+#else
+  const size_t lds = (size_t)lds_floats * sizeof(float);
+#endif
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   kernel<<<grid, NJF_THREADS, lds, s>>>(args);
@@ -913,7 +930,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   a.bins_out = bins_out;
   a.weights_out = weights_out;
   a.density_out = density_out;
-  return launch_fused(proposal_kernel, a, a.rc.total_rays, (hipStream_t)stream);
+  return launch_fused(proposal_kernel, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
 }
 
 // The decoder blobs must be one allocation laid out [density | colour | jacobian] (what

@@ -404,7 +404,10 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
         half = lambda i: w_j[4096 * i: 4096 * (i + 1)]
         qw = self.jacobian_query_mlp.weight  # [64, 63 + 512], input = cat[xyz_features, pixel_aligned_features] (:421-427)
         hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0))
-        wz[:, hip.ZDIM:] = qw[:, 63:].t()
+        # hoisted query channels use the same in-block order as lin_z (csrc: njf_hoist_position, MB=2)
+        f = torch.arange(64, device=qw.device)
+        pos = 32 * ((f % 32) // 16) + 8 * ((f % 16) // 4) + 4 * (f // 32) + (f % 4)
+        wz[:, hip.ZDIM + pos] = qw[:, 63:].t()
         bz[hip.ZDIM:] = 0.0
         z = self.jacobian_index_embedding[0].double()  # [A, 64]
         for l, (attn, ff) in enumerate(self.jacobian_attn_decoder.layers):

@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnjf_hip.so")
+LIB_PATH = os.environ.get("NJF_HIP_LIB", os.path.join(_HERE, "libnjf_hip.so"))  # override: kernel A/B experiments only
 
 MAX_ACTION_DIM = 10
 ZDIM = 384
