@@ -33,7 +33,10 @@ S_PROP, S_FINAL, ACTION_DIM = 64, 64, 8
 # Algorithmic work (hoisted-lin_z formulation), MACs per point
 MAC_PROPOSAL = 172_032
 MAC_DENSITY, MAC_JACOBIAN, MAC_COLOR = 173_952, 174_976, 6_272
-PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0}
+# MFMA instructions issued per algorithmic product block: the f16x2 path evaluates hi*hi + hi*lo + lo*hi
+ISSUE_FACTOR = {"f32": 1.0, "f16x2": 3.0}
 
 
 def parse():
@@ -43,6 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=1024)
+    ap.add_argument("--precision", choices=["f16x2", "f32"], default=None,
+                    help="MFMA precision of the fused MLPs (default: package default, f16x2 split with fp32 accumulate)")
     return ap.parse_args()
 
 
@@ -104,7 +109,9 @@ def main():
     case = ph.make_case(1, H, W, None, ACTION_DIM, seed=rank)
     cams = case["cams"]
     dev = lambda t: t.to(device)
-    fr = FusedRenderer(device, 1, ACTION_DIM)
+    from neural_jacobian_field_amd import hip
+    precision = args.precision or hip.DEFAULT_PRECISION
+    fr = FusedRenderer(device, 1, ACTION_DIM, precision=precision)
     fr.load_weights({k: dev(v) for k, v in case["params"].items()})
     feats = dev(case["feats"])
     origins, directions = dev(case["origins"]), dev(case["directions"])
@@ -166,7 +173,7 @@ def main():
         render_flop = 2.0 * rays * S_FINAL * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
         achieved = render_flop / (k_ms["render"] * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_render_kernel_hbm_bytes.json")
+        pmc = os.path.join(ROOT, "profiles", f"r01_render_kernel_hbm_bytes_{precision}.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
@@ -174,16 +181,20 @@ def main():
             "metric": "rendered rays/s (64 samples/ray, 256^2 image)",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if precision == "f32" else "f32 in/out + fp32 accumulate; MFMA operands split hi+lo into 2 x f16 "
+                     "(3 f16 MFMAs per product block, fp32-class accuracy: same parity bound as the f32-MFMA path)",
+            "data": "synthetic",
             "config": {"workload": "C2: Allegro single-view PixelNeRF, B=1, 256x256 rays, 64 proposal + 64 final "
                                    "samples/ray, jacobian_mlp, A=8, eval-mode Model.forward (encoder excluded), "
                                    "+ rgb/flow loss" + (" + RCCL all-reduce" if world > 1 else ""),
                        "rays_per_gpu": rays, "parallelism": f"dp{world} (ray-sharded, replicated weights)"},
             "kernel_ms": {k: round(v, 3) for k, v in k_ms.items()},
-            "roofline": {"kernel": "render_kernel<true> (density+colour+Jacobian MLPs + compositing)", "bound": "mfma",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "algorithmic_flop_per_launch": render_flop},
+            "roofline": {"kernel": f"render_kernel<jacobian_mlp, {precision}> (density+colour+Jacobian MLPs + compositing)",
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
+                         "algorithmic_flop_per_launch": render_flop,
+                         "mfma_issue_factor": ISSUE_FACTOR[precision],
+                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_TFLOPS["f32"], 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case, args.cpu_sample_rays)

@@ -55,6 +55,11 @@ extern "C" {
 #define NJF_TRANSFORMER_B_FLOATS (3 * 256 + 32)
 #define NJF_QDIM 64
 
+/* MFMA precision of the fused MLPs.  A packed blob and the forward call that consumes it must agree. */
+#define NJF_PRECISION_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products */
+#define NJF_PRECISION_F16X2 1  /* fp32 operands split hi+lo into two fp16; hi*hi + hi*lo + lo*hi accumulated in fp32
+                                  by v_mfma_f32_32x32x16_f16: fp32-class accuracy (dropped term 2^-22) at 3/16 the cost */
+
 #define NJF_JACOBIAN_NONE 0
 #define NJF_JACOBIAN_MLP 1          /* ActionDecoderJacobianMLP (action_decoder_jacobian.py:261-337) */
 #define NJF_JACOBIAN_TRANSFORMER 2  /* ActionDecoderJacobianTransformer (:340-446), host-folded, see decoder.py */
@@ -112,16 +117,16 @@ const char* njf_error_string(int code);
  * njf_project_features).  Replaces nothing in the reference: it is the layout change that lets
  * ResnetFC.forward (resnet_fc.py:130-154) run as one fused kernel. */
 int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, float* bz_out,
-                      void* stream);
+                      int precision, void* stream);
 /* Same, writing lin_z into a wider [512, wz_ld] matrix (several nets side by side: pass wz_out + column offset). */
 int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
-                         float* bz_out, void* stream);
-int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, void* stream);
+                         float* bz_out, int precision, void* stream);
+int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, int precision, void* stream);
 /* One torch.nn.Linear [d_out, d_in] -> fragment-major block of ceil(d_in/32)*4*ceil(d_out/32)*256 floats
  * (+ zero-padded bias of 32*ceil(d_out/32) floats when b_out != NULL).  kind 0: plain.  kind 1: the input is
  * the 63-d positional encoding (slot order [sin 30 | x | y || cos 30 | z | 1], bias folded into slot 63). */
 int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kind, float* w_out, float* b_out,
-                    void* stream);
+                    int precision, void* stream);
 
 /* ---- per-image feature projection ("lin_z hoist") ------------------------------------------ */
 /* G[b,p,n] = sum_k F[b,k,p] * wz[k,n] + bz[n];  F is the encoder output [B,512,Hf,Wf] (NCHW),
@@ -150,7 +155,7 @@ int njf_proposal_forward(const float* origins, const float* directions, int rays
                          const float* w_pack, const float* b_pack,
                          const float* bins_in, int bins_per_ray, int s_in,
                          const float* u, int u_per_ray, int s_out, float anneal,
-                         float* bins_out, float* weights_out, float* density_out, void* stream);
+                         float* bins_out, float* weights_out, float* density_out, int precision, void* stream);
 
 /* ---- fused final pass: action_decoder_jacobian.py:147-215 + model.py:257-314 --------------- */
 typedef struct NjfRenderOutputs {
@@ -176,7 +181,7 @@ int njf_render_forward(const float* origins, const float* directions, int rays_p
                        const float* w_density, const float* b_density,
                        const float* w_color, const float* b_color,
                        const float* w_jacobian, const float* b_jacobian,
-                       const float* bins, int samples, const NjfRenderOutputs* out, void* stream);
+                       const float* bins, int samples, const NjfRenderOutputs* out, int precision, void* stream);
 
 /* ---- point-list evaluation (arbitrary xyz): density_decoder.py:45-71, model.py:416-456 ----- */
 /* xyz [B,N,3] world-space points, dirs [B,N,3] or NULL.  mode 0: proposal net -> density [B*N].
@@ -187,7 +192,7 @@ int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch
                        const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
                        int jacobian_kind /* NJF_JACOBIAN_* */, const float* w_density, const float* b_density, const float* w_color, const float* b_color,
                        const float* w_jacobian, const float* b_jacobian,
-                       float* density, float* color, float* flow, float* jacobian, float* geo, void* stream);
+                       float* density, float* color, float* flow, float* jacobian, float* geo, int precision, void* stream);
 
 /* ---- stand-alone sampler / compositing ops (API parity with the un-fused reference calls) -- */
 /* RaySamples.get_weights (ray_samplers.py:77-101): deltas, densities [N,S] -> weights [N,S]. */

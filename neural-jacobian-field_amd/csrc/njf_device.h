@@ -13,6 +13,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// MFMA precision of the fused MLPs (same activation layout, same chunk sizes, different A-fragment packing):
+//   PREC_F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak)
+//   PREC_F16X2 : every fp32 operand x is split as x = hi + lo (two fp16), and hi*hi + hi*lo + lo*hi is
+//                accumulated in fp32 by v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s peak, 3 instructions per product
+//                block): the dropped lo*lo term is 2^-22 relative, i.e. fp32-class accuracy at 3/16 of the cost.
+#define PREC_F32 0
+#define PREC_F16X2 1
 
 // Workgroup = 4 waves (one per SIMD), two workgroups resident per CU: the two waves sharing a SIMD's
 // MFMA pipe belong to DIFFERENT workgroups, so one workgroup's barrier / gather / encoding phases are
@@ -93,26 +102,55 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
 // out[MBO] += W[:, kb range] * in   for the (kb,q) groups stored at `wl` (LDS, packed
 // [kb][q][mb][lane][e]).  RELU applies max(.,0) to the B operand on the fly.
 // ------------------------------------------------------------------------------------------
-template <int MBO, int NKB, int KB0, bool RELU, int KBI>
+template <int PREC, int MBO, int NKB, int KB0, bool RELU, int KBI>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane, const f32x16 (&in)[KBI],
                                           f32x16 (&out)[MBO]) {
-  // hipcc schedules this fully unrolled body as groups of 4*MBO MFMAs and re-issues each group's ds_read_b128s
-  // two MFMAs (128 cycles) before the registers are needed, which covers the LDS latency; a hand-pipelined
-  // variant measured 1-2 % slower (round-1 A/B, tools/ablate.sh).
-  const float* base = wl + lane * 4;
+  if constexpr (PREC == PREC_F32) {
+    // hipcc schedules this fully unrolled body as groups of 4*MBO MFMAs and re-issues each group's ds_read_b128s
+    // two MFMAs (128 cycles) before the registers are needed, which covers the LDS latency; a hand-pipelined
+    // variant measured 1-2 % slower (round-1 A/B, tools/ablate.sh).
+    const float* base = wl + lane * 4;
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 a[MBO];
+      for (int q = 0; q < 4; ++q) {
+        f32x4 a[MBO];
 #pragma unroll
-      for (int m = 0; m < MBO; ++m) a[m] = *(const f32x4*)(base + ((kb * 4 + q) * MBO + m) * 256);
+        for (int m = 0; m < MBO; ++m) a[m] = *(const f32x4*)(base + ((kb * 4 + q) * MBO + m) * 256);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float b = in[KB0 + kb][q * 4 + e];
-        if (RELU) b = fmaxf(b, 0.f);
+        for (int e = 0; e < 4; ++e) {
+          float b = in[KB0 + kb][q * 4 + e];
+          if (RELU) b = fmaxf(b, 0.f);
 #pragma unroll
-        for (int m = 0; m < MBO; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][e], b, out[m], 0, 0, 0);
+          for (int m = 0; m < MBO; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][e], b, out[m], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
+    // Lane (j,hh) supplies its own registers 8*tt .. 8*tt+7 of block kb as the 8 k-values of step t = 2*kb + tt.
+    const f16x8* base = (const f16x8*)wl + lane;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        f16x8 bh, bl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float x = in[KB0 + kb][8 * tt + i];
+          if (RELU) x = fmaxf(x, 0.f);
+          const _Float16 h = (_Float16)x;
+          bh[i] = h;
+          bl[i] = (_Float16)(x - (float)h);
+        }
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) {
+          const f16x8 ah = base[(((kb * 2 + tt) * MBO + m) * 2 + 0) * 64];
+          const f16x8 al = base[(((kb * 2 + tt) * MBO + m) * 2 + 1) * 64];
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[m], 0, 0, 0);
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[m], 0, 0, 0);
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[m], 0, 0, 0);
+        }
       }
     }
   }
@@ -315,6 +353,7 @@ __device__ __forceinline__ void sh4(float dx, float dy, float dz, float (&o)[16]
 // One ResnetFC (resnet_fc.py:130-154) on a 32-point tile: 22 weight chunks.
 // bias layout (LDS): [blk: fc0 (128) | fc1 (128)] x 5 | lin_out (32).
 // ------------------------------------------------------------------------------------------
+template <int PREC>
 __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __restrict__ bias,
                                             const float* __restrict__ gz, const PointGeom& g,
                                             const f32x16 (&pe)[2], int wave, int lane, f32x16 (&out)[1]) {
@@ -324,7 +363,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
   for (int m = 0; m < 4; ++m) h[m] = (f32x16)(0.f);
   {
     const float* wl = stream_step(st, wave, lane);
-    mma_chunk<4, 2, 0, false, 2>(wl, lane, pe, h);  // lin_in (bias folded into slot 63)
+    mma_chunk<PREC, 4, 2, 0, false, 2>(wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
   for (int blk = 0; blk < 5; ++blk) {
     if (blk < 3) add_hoisted_latent<4>(gz + blk * 128, g, hh, h);
@@ -332,31 +371,32 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     bias_init<4, true>(bl, hh, net);
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<4, 2, 0, true, 4>(wl, lane, h, net);
+      mma_chunk<PREC, 4, 2, 0, true, 4>(wl, lane, h, net);
     }
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<4, 2, 2, true, 4>(wl, lane, h, net);
+      mma_chunk<PREC, 4, 2, 2, true, 4>(wl, lane, h, net);
     }
     bias_init<4, false>(bl + 128, hh, h);
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<4, 2, 0, true, 4>(wl, lane, net, h);
+      mma_chunk<PREC, 4, 2, 0, true, 4>(wl, lane, net, h);
     }
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<4, 2, 2, true, 4>(wl, lane, net, h);
+      mma_chunk<PREC, 4, 2, 2, true, 4>(wl, lane, net, h);
     }
   }
   bias_init<1, true>(bias + 1280, hh, out);
   {
     const float* wl = stream_step(st, wave, lane);
-    mma_chunk<1, 4, 0, true, 4>(wl, lane, h, out);
+    mma_chunk<PREC, 1, 4, 0, true, 4>(wl, lane, h, out);
   }
 }
 
 // colour head (action_decoder_jacobian.py:315-322): one chunk [L0 2048 | L1 4096 | L2 2048],
 // bias (LDS): [L1 (64) | L2 (32)].  cin: hh=0 -> [geo(15), 1], hh=1 -> sh(16).
+template <int PREC>
 __device__ __forceinline__ void color_tile(WeightStream& st, const float* __restrict__ bias, const f32x16 (&cin)[1],
                                            int wave, int lane, f32x16 (&rgb)[1]) {
   const int hh = lane >> 5;
@@ -364,11 +404,11 @@ __device__ __forceinline__ void color_tile(WeightStream& st, const float* __rest
   f32x16 a[2], b[2];
   a[0] = (f32x16)(0.f);
   a[1] = (f32x16)(0.f);
-  mma_chunk<2, 1, 0, false, 1>(wl, lane, cin, a);
+  mma_chunk<PREC, 2, 1, 0, false, 1>(wl, lane, cin, a);
   bias_init<2, true>(bias, hh, b);
-  mma_chunk<2, 2, 0, true, 2>(wl + 2048, lane, a, b);
+  mma_chunk<PREC, 2, 2, 0, true, 2>(wl + 2048, lane, a, b);
   bias_init<1, true>(bias + 64, hh, rgb);
-  mma_chunk<1, 2, 0, true, 2>(wl + 6144, lane, b, rgb);
+  mma_chunk<PREC, 1, 2, 0, true, 2>(wl + 6144, lane, b, rgb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -407,6 +447,7 @@ __device__ __forceinline__ void norm64(const f32x16 (&x)[2], f32x16 (&n)[2]) {
     for (int r = 0; r < 16; ++r) n[m][r] = (x[m][r] - mean) * rstd;
 }
 
+template <int PREC>
 __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* __restrict__ bias,
                                                  const float* __restrict__ gq, const PointGeom& g,
                                                  const f32x16 (&pe)[2], int keys, int wave, int lane, f32x16 (&out)[1]) {
@@ -415,13 +456,13 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
   x[0] = (f32x16)(0.f);
   x[1] = (f32x16)(0.f);
   const float* wl = stream_step(st, wave, lane);
-  mma_chunk<2, 2, 0, false, 2>(wl, lane, pe, x);  // query MLP, PE part (bias in slot 63)
+  mma_chunk<PREC, 2, 2, 0, false, 2>(wl, lane, pe, x);  // query MLP, PE part (bias in slot 63)
   add_hoisted_latent<2>(gq, g, hh, x);            // query MLP, feature part (hoisted)
   for (int l = 0; l < 3; ++l) {
     const float* bl = bias + 256 * l;
     norm64(x, n);
     bias_init<2, true>(bl, hh, t);
-    mma_chunk<2, 2, 0, false, 2>(wl + 4096, lane, n, t);  // dots[head*8 + key]
+    mma_chunk<PREC, 2, 2, 0, false, 2>(wl + 4096, lane, n, t);  // dots[head*8 + key]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -442,10 +483,10 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
     }
     wl = stream_step(st, wave, lane);
     bias_init<2, false>(bl + 64, hh, x);
-    mma_chunk<2, 2, 0, false, 2>(wl, lane, t, x);  // x += to_out(attn @ V)
+    mma_chunk<PREC, 2, 2, 0, false, 2>(wl, lane, t, x);  // x += to_out(attn @ V)
     norm64(x, n);
     bias_init<2, true>(bl + 128, hh, t);
-    mma_chunk<2, 2, 0, false, 2>(wl + 4096, lane, n, t);
+    mma_chunk<PREC, 2, 2, 0, false, 2>(wl + 4096, lane, n, t);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -455,10 +496,10 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
       }
     wl = stream_step(st, wave, lane);
     bias_init<2, false>(bl + 192, hh, x);
-    mma_chunk<2, 2, 0, false, 2>(wl, lane, t, x);  // x += FF
+    mma_chunk<PREC, 2, 2, 0, false, 2>(wl, lane, t, x);  // x += FF
   }
   bias_init<1, true>(bias + 768, hh, out);
-  mma_chunk<1, 2, 0, false, 2>(wl + 4096, lane, x, out);
+  mma_chunk<PREC, 1, 2, 0, false, 2>(wl + 4096, lane, x, out);
 }
 
 // ------------------------------------------------------------------------------------------

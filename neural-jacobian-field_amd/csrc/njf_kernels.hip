@@ -53,41 +53,63 @@ struct PackLayer {
   int d_out, d_in;
   int mb, kb;  // output / input 32-blocks
   int kind;    // 0 plain, 1 lin_in (PE slots + bias column), 2 colour layer 0 (geo|1|sh slots)
-  float* dst;  // kb*4*mb*256 floats
+  int prec;    // NJF_PRECISION_*
+  float* dst;  // kb*4*mb*256 floats (same byte count in both precisions)
   float* bdst;  // 32*mb floats (logical order, zero padded) or NULL
 };
 
+// logical (row f, input slot k) -> source value
+__device__ __forceinline__ float pack_source(const PackLayer& L, int f, int k) {
+  if (f >= L.d_out) return 0.f;
+  if (L.kind == 0) return k < L.d_in ? L.w[f * L.d_in + k] : 0.f;
+  if (L.kind == 1) {  // slots: [sin 0..29 | x | y || cos 30..59 | z | bias]
+    int ch;
+    if (k < 30) ch = k;
+    else if (k == 30) ch = 60;
+    else if (k == 31) ch = 61;
+    else if (k < 62) ch = k - 2;
+    else if (k == 62) ch = 62;
+    else ch = -1;
+    return ch >= 0 ? L.w[f * L.d_in + ch] : L.b[f];
+  }
+  // slots: [geo 0..14 | bias || sh 0..15]
+  if (k < 15) return L.w[f * L.d_in + k];
+  if (k == 15) return L.b[f];
+  return L.w[f * L.d_in + (k - 1)];
+}
+
 __global__ void pack_layer_kernel(PackLayer L) {
-  const int n = L.kb * 4 * L.mb * 256;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int e = i & 3, lane = (i >> 2) & 63;
-    int rest = i >> 8;
-    const int m = rest % L.mb;
-    rest /= L.mb;
-    const int q = rest & 3, kb = rest >> 2;
-    const int ip = lane & 31, kh = lane >> 5;
-    const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);  // logical output row
-    const int k = 16 * L.kb * kh + 16 * kb + 4 * q + e;                              // logical input slot
-    float v = 0.f;
-    if (f < L.d_out) {
-      if (L.kind == 0) {
-        if (k < L.d_in) v = L.w[f * L.d_in + k];
-      } else if (L.kind == 1) {  // slots: [sin 0..29 | x | y || cos 30..59 | z | bias]
-        int ch;
-        if (k < 30) ch = k;
-        else if (k == 30) ch = 60;
-        else if (k == 31) ch = 61;
-        else if (k < 62) ch = k - 2;
-        else if (k == 62) ch = 62;
-        else ch = -1;
-        v = ch >= 0 ? L.w[f * L.d_in + ch] : L.b[f];
-      } else {  // slots: [geo 0..14 | bias || sh 0..15]
-        if (k < 15) v = L.w[f * L.d_in + k];
-        else if (k == 15) v = L.b[f];
-        else v = L.w[f * L.d_in + (k - 1)];
-      }
+  if (L.prec == NJF_PRECISION_F32) {
+    const int n = L.kb * 4 * L.mb * 256;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int e = i & 3, lane = (i >> 2) & 63;
+      int rest = i >> 8;
+      const int m = rest % L.mb;
+      rest /= L.mb;
+      const int q = rest & 3, kb = rest >> 2;
+      const int ip = lane & 31, kh = lane >> 5;
+      const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);  // logical output row
+      const int k = 16 * L.kb * kh + 16 * kb + 4 * q + e;                              // logical input slot
+      L.dst[i] = pack_source(L, f, k);
     }
-    L.dst[i] = v;
+  } else {
+    // [t][m][hi|lo][lane][8 x f16]; lane half kh supplies the 8 k-values 16*KB*kh + 8*t + i of K-step t
+    _Float16* dst = (_Float16*)L.dst;
+    const int n = L.kb * 2 * L.mb * 512;  // (t, m, lane, i8) tuples; each writes its hi and lo plane entry
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int i8 = i & 7, lane = (i >> 3) & 63;
+      const int rest = i >> 9;
+      const int m = rest % L.mb, t = rest / L.mb;
+      const int ip = lane & 31, kh = lane >> 5;
+      const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);
+      const int k = 16 * L.kb * kh + 8 * t + i8;
+      const float v = pack_source(L, f, k);
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      const size_t o = ((size_t)(t * L.mb + m) * 2) * 512 + lane * 8 + i8;
+      dst[o] = hi;
+      dst[o + 512] = lo;
+    }
   }
   if (L.bdst != nullptr && blockIdx.x == 0) {
     for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = (f < L.d_out && L.b) ? L.b[f] : 0.f;
@@ -122,30 +144,32 @@ __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* 
     }
 }
 
-static void launch_pack(const float* w, const float* b, int d_out, int d_in, int mb, int kb, int kind, float* dst,
+static void launch_pack(const float* w, const float* b, int d_out, int d_in, int mb, int kb, int kind, int prec, float* dst,
                         float* bdst, hipStream_t s) {
-  PackLayer L{w, b, d_out, d_in, mb, kb, kind, dst, bdst};
+  PackLayer L{w, b, d_out, d_in, mb, kb, kind, prec, dst, bdst};
   const int n = kb * 4 * mb * 256;
   pack_layer_kernel<<<(n + 255) / 256, 256, 0, s>>>(L);
 }
 
 extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
-                                    float* bz_out, void* stream) {
+                                    float* bz_out, int precision, void* stream) {
   if (!src || !w_out || !b_out) return NJF_E_NULL;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  const int P = precision;
   if (src->d_out < 1 || src->d_out > 32) return NJF_E_DOUT;
   if (!src->lin_in_w || !src->lin_in_b || !src->lin_out_w || !src->lin_out_b) return NJF_E_NULL;
   for (int i = 0; i < 5; ++i)
     if (!src->fc0_w[i] || !src->fc0_b[i] || !src->fc1_w[i] || !src->fc1_b[i]) return NJF_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   // chunk 0: lin_in 63(+bias) -> 128
-  launch_pack(src->lin_in_w, src->lin_in_b, 128, NJF_PE_DIM, 4, 2, 1, w_out, nullptr, s);
+  launch_pack(src->lin_in_w, src->lin_in_b, 128, NJF_PE_DIM, 4, 2, 1, P, w_out, nullptr, s);
   for (int i = 0; i < 5; ++i) {
     float* base = w_out + (size_t)(1 + 4 * i) * NJF_CHUNK_FLOATS;
-    launch_pack(src->fc0_w[i], src->fc0_b[i], 128, 128, 4, 4, 0, base, b_out + 256 * i, s);
-    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, base + 2 * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s);
+    launch_pack(src->fc0_w[i], src->fc0_b[i], 128, 128, 4, 4, 0, P, base, b_out + 256 * i, s);
+    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, P, base + 2 * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s);
   }
   float* last = w_out + (size_t)21 * NJF_CHUNK_FLOATS;
-  launch_pack(src->lin_out_w, src->lin_out_b, src->d_out, 128, 1, 4, 0, last, b_out + 1280, s);
+  launch_pack(src->lin_out_w, src->lin_out_b, src->d_out, 128, 1, 4, 0, P, last, b_out + 1280, s);
   fill_kernel<<<16, 256, 0, s>>>(last + 4096, 4096, 0.f);
   if (wz_out) {
     if (!bz_out || wz_ld < 384) return NJF_E_SHAPE;
@@ -158,27 +182,30 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
 }
 
 extern "C" int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, float* bz_out,
-                                 void* stream) {
-  return njf_pack_resnetfc_ld(src, w_out, b_out, wz_out, 384, bz_out, stream);
+                                 int precision, void* stream) {
+  return njf_pack_resnetfc_ld(src, w_out, b_out, wz_out, 384, bz_out, precision, stream);
 }
 
 extern "C" int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kind, float* w_out, float* b_out,
-                               void* stream) {
+                               int precision, void* stream) {
   if (!w || !w_out) return NJF_E_NULL;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   if (d_out < 1 || d_in < 1) return NJF_E_SHAPE;
   if (kind == 1 && (d_in != NJF_PE_DIM || !b)) return NJF_E_SHAPE;
   if (kind != 0 && kind != 1) return NJF_E_MODE;
   const int mb = (d_out + 31) / 32, kb = kind == 1 ? 2 : (d_in + 31) / 32;
-  launch_pack(w, b, d_out, d_in, mb, kb, kind, w_out, b_out, (hipStream_t)stream);
+  launch_pack(w, b, d_out, d_in, mb, kb, kind, precision, w_out, b_out, (hipStream_t)stream);
   return launch_status();
 }
 
-extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, void* stream) {
+extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, int precision,
+                                   void* stream) {
   if (!src || !w_out || !b_out || !src->w0 || !src->b0 || !src->w1 || !src->b1 || !src->w2 || !src->b2) return NJF_E_NULL;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   hipStream_t s = (hipStream_t)stream;
-  launch_pack(src->w0, src->b0, 64, 31, 2, 1, 2, w_out, nullptr, s);
-  launch_pack(src->w1, src->b1, 64, 64, 2, 2, 0, w_out + 2048, b_out, s);
-  launch_pack(src->w2, src->b2, 3, 64, 1, 2, 0, w_out + 6144, b_out + 64, s);
+  launch_pack(src->w0, src->b0, 64, 31, 2, 1, 2, precision, w_out, nullptr, s);
+  launch_pack(src->w1, src->b1, 64, 64, 2, 2, 0, precision, w_out + 2048, b_out, s);
+  launch_pack(src->w2, src->b2, 3, 64, 1, 2, 0, precision, w_out + 6144, b_out + 64, s);
   return launch_status();
 }
 
@@ -398,6 +425,7 @@ struct ProposalArgs {
   float* density_out;
 };
 
+template <int PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -440,7 +468,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     f32x16 out[1];
-    resnet_tile(st, bias, gz, g, pe, wave, lane, out);
+    resnet_tile<PREC>(st, bias, gz, g, pe, wave, lane, out);
     const float pre = __shfl(out[0][0], j, 64);
     const float sigma = expf(pre - 1.0f);
     const float w = tile_weights(end - start, sigma, valid, j, carry);
@@ -470,7 +498,7 @@ struct TileOut {
 
 // bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian head (MLP 1312 / transformer 800)]
 // JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
-template <int JKIND>
+template <int JKIND, int PREC>
 __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __restrict__ gz_d,
                                              const float* __restrict__ gz_j, const PointGeom& g, float dirx, float diry,
                                              float dirz, const float* __restrict__ action, int action_dim, int wave,
@@ -480,7 +508,7 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
   {
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    resnet_tile(st, bias, gz_d, g, pe, wave, lane, geo);
+    resnet_tile<PREC>(st, bias, gz_d, g, pe, wave, lane, geo);
   }
   o.sigma = expf(__shfl(geo[0][15], j, 64) - 1.0f);
   {
@@ -489,7 +517,7 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     f32x16 cin[1], crgb[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) cin[0][r] = hh ? sh[r] : (r < 15 ? geo[0][r] : 1.0f);
-    color_tile(st, bias + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb);
+    color_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float x = __shfl(crgb[0][c], j, 64);
@@ -501,8 +529,8 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     asm volatile("" ::: "memory");
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    if (JKIND == 1) resnet_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
-    else transformer_tile(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
+    if (JKIND == 1) resnet_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
+    else transformer_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
     // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
     // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
     float ph[3] = {0.f, 0.f, 0.f};
@@ -541,7 +569,7 @@ struct RenderArgs {
   NjfRenderOutputs out;
 };
 
-template <int JKIND>
+template <int JKIND, int PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   constexpr bool WITH_J = JKIND != 0;
   constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
@@ -598,7 +626,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
     TileOut o;
     f32x16 geo[1], jac[1];
-    decoder_tile<JKIND>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac);
+    decoder_tile<JKIND, PREC>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac);
     const float w = tile_weights(end - start, o.sigma, valid, j, carry);
     if (valid) {
       acc_w += w;
@@ -731,7 +759,7 @@ struct PointsArgs {
 
 // MODE 0: proposal net (density only); 1: decoder without Jacobian head; 2: decoder + ResnetFC Jacobian head;
 // 3: decoder + transformer Jacobian head
-template <int MODE>
+template <int MODE, int PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -762,7 +790,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   if (MODE == 0) {
     f32x16 pe[2], out[1];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    resnet_tile(st, bias, a.gmap.data + gbase + a.goff_d, g, pe, wave, lane, out);
+    resnet_tile<PREC>(st, bias, a.gmap.data + gbase + a.goff_d, g, pe, wave, lane, out);
     if (ok && hh == 0 && a.density) a.density[p] = expf(out[0][0] - 1.0f);
   } else {
     float dx = 0.f, dy = 0.f, dz = 1.f;
@@ -776,7 +804,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
     TileOut o;
     f32x16 geo[1], jac[1];
     // NOTE: `action` is per lane here (tiles may straddle batch elements)
-    decoder_tile<(MODE >= 2 ? MODE - 1 : 0)>(st, a.gmap.data + gbase + a.goff_d, a.gmap.data + gbase + a.goff_j, g, dx, dy,
+    decoder_tile<(MODE >= 2 ? MODE - 1 : 0), PREC>(st, a.gmap.data + gbase + a.goff_d, a.gmap.data + gbase + a.goff_j, g, dx, dy,
                                              dz, action, A, wave, lane, o, geo, jac);
     if (ok) {
       if (hh == 0) {
@@ -909,11 +937,12 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
                                     const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
                                     const float* w_pack, const float* b_pack, const float* bins_in, int bins_per_ray,
                                     int s_in, const float* u, int u_per_ray, int s_out, float anneal, float* bins_out,
-                                    float* weights_out, float* density_out, void* stream) {
+                                    float* weights_out, float* density_out, int precision, void* stream) {
   int rc = check_common(origins, directions, rays_per_batch, cams, gmap);
   if (rc) return rc;
   if (!w_pack || !b_pack || !bins_in || !u || !bins_out) return NJF_E_NULL;
   if (s_in < 1 || s_in > 256 || s_out < 1) return NJF_E_SAMPLES;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   if ((rc = check_gmap(gmap, gmap_offset))) return rc;
   ProposalArgs a;
   a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
@@ -930,7 +959,9 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   a.bins_out = bins_out;
   a.weights_out = weights_out;
   a.density_out = density_out;
-  return launch_fused(proposal_kernel, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+  if (precision == NJF_PRECISION_F16X2)
+    return launch_fused(proposal_kernel<PREC_F16X2>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+  return launch_fused(proposal_kernel<PREC_F32>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
 }
 
 // The decoder blobs must be one allocation laid out [density | colour | jacobian] (what
@@ -956,11 +987,12 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
                                   int gmap_offset_jacobian, int jacobian_kind, const float* w_density,
                                   const float* b_density, const float* w_color, const float* b_color,
                                   const float* w_jacobian, const float* b_jacobian, const float* bins, int samples,
-                                  const NjfRenderOutputs* out, void* stream) {
+                                  const NjfRenderOutputs* out, int precision, void* stream) {
   int rc = check_common(origins, directions, rays_per_batch, cams, gmap);
   if (rc) return rc;
   if (!w_density || !b_density || !w_color || !b_color || !bins || !out) return NJF_E_NULL;
   if (samples < 1) return NJF_E_SAMPLES;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
   if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
@@ -977,20 +1009,27 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.samples = samples;
   a.out = *out;
   hipStream_t s = (hipStream_t)stream;
-  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1>, a, a.rc.total_rays, s);
-  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2>, a, a.rc.total_rays, s);
-  return launch_fused(render_kernel<0>, a, a.rc.total_rays, s);
+  const int n = a.rc.total_rays;
+  if (precision == NJF_PRECISION_F16X2) {
+    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F16X2>, a, n, s);
+    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F16X2>, a, n, s);
+    return launch_fused(render_kernel<0, PREC_F16X2>, a, n, s);
+  }
+  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F32>, a, n, s);
+  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F32>, a, n, s);
+  return launch_fused(render_kernel<0, PREC_F32>, a, n, s);
 }
 
 extern "C" int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
                                   const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
                                   int jacobian_kind, const float* w_density, const float* b_density, const float* w_color,
                                   const float* b_color, const float* w_jacobian, const float* b_jacobian, float* density,
-                                  float* color, float* flow, float* jacobian, float* geo, void* stream) {
+                                  float* color, float* flow, float* jacobian, float* geo, int precision, void* stream) {
   if (!xyz || !cams || !gmap || !w_density || !b_density) return NJF_E_NULL;
   if (!cams->ctxt_w2c || !cams->ctxt_k || !gmap->data) return NJF_E_NULL;
   if (points_per_batch < 1 || cams->batch < 1) return NJF_E_SHAPE;
   if (mode != 0 && mode != 1) return NJF_E_MODE;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   int rc;
   if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
   PointsArgs a;
@@ -1013,12 +1052,18 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   a.geo = geo;
   const int tiles = (a.total_points + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) return launch_fused(points_kernel<0>, a, tiles, s);
+  const bool split = precision == NJF_PRECISION_F16X2;
+  if (mode == 0) return split ? launch_fused(points_kernel<0, PREC_F16X2>, a, tiles, s) : launch_fused(points_kernel<0, PREC_F32>, a, tiles, s);
   if (!w_color || !b_color) return NJF_E_NULL;
   if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
-  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2>, a, tiles, s);
-  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3>, a, tiles, s);
-  return launch_fused(points_kernel<1>, a, tiles, s);
+  if (split) {
+    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, PREC_F16X2>, a, tiles, s);
+    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, PREC_F16X2>, a, tiles, s);
+    return launch_fused(points_kernel<1, PREC_F16X2>, a, tiles, s);
+  }
+  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, PREC_F32>, a, tiles, s);
+  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, PREC_F32>, a, tiles, s);
+  return launch_fused(points_kernel<1, PREC_F32>, a, tiles, s);
 }

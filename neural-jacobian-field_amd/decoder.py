@@ -103,7 +103,7 @@ def initialize_jacobian_weights(m: nn.Module) -> None:
 
 
 def _version(module: nn.Module) -> Tuple:
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+    return (getattr(module, "precision", None),) + tuple((p.data_ptr(), p._version) for p in module.parameters())
 
 
 class _HoistCache:
@@ -143,6 +143,7 @@ class DensityDecoderMlp(nn.Module):
             raise ValueError("fused path supports num_frequencies=10 (63-d positional encoding)")
         self.cfg = cfg
         self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=1)
+        self.precision = hip.DEFAULT_PRECISION  # "f32" | "f16x2" (MFMA precision of the fused MLP)
         self._packed_version = None
         self._hoist = _HoistCache()
 
@@ -157,7 +158,7 @@ class DensityDecoderMlp(nn.Module):
             self._wz = torch.empty(512, hip.ZDIM, **f32)
             self._bz = torch.empty(hip.ZDIM, **f32)
             params = {k: p for k, p in self.named_parameters()}
-            hip.pack_resnetfc(params, "density_head.", self._w, self._b, self._wz, 0, self._bz)
+            hip.pack_resnetfc(params, "density_head.", self._w, self._b, self._wz, 0, self._bz, precision=self.precision)
             self._packed_version = v
         return self._w, self._b
 
@@ -174,7 +175,8 @@ class DensityDecoderMlp(nn.Module):
         fmap = hip.make_feature_map(self.hoisted_map(pixel_encoding.features))
         out = torch.empty(b, r, s, 1, dtype=torch.float32, device=world_space_xyz.device)
         xyz = world_space_xyz.reshape(b, r * s, 3).contiguous()
-        hip.points_forward(xyz, None, _cameras(pixel_encoding, False), fmap, 0, 0, 0, w, bias, density=out)
+        hip.points_forward(xyz, None, _cameras(pixel_encoding, False), fmap, 0, 0, 0, w, bias, density=out,
+                           precision=self.precision)
         return out
 
 
@@ -218,6 +220,7 @@ class ActionDecoderJacobian(ActionDecoder):
         self.action_dim = action_dim
         self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=cfg.geometry_feature_dim + 1)
         self.mode = "regular"
+        self.precision = hip.DEFAULT_PRECISION  # "f32" | "f16x2"
         self._packed_version = None
         self._hoist = _HoistCache()
 
@@ -245,8 +248,8 @@ class ActionDecoderJacobian(ActionDecoder):
             self._wz = torch.zeros(512, hip.ZDIM + self.J_HOIST, **f32)
             self._bz = torch.zeros(hip.ZDIM + self.J_HOIST, **f32)
             params = {k: p for k, p in self.named_parameters()}
-            hip.pack_resnetfc(params, "density_head.", self._w[:n], self._bd, self._wz, 0, self._bz)
-            hip.pack_color_head(params, "color_head.", self._w[n:n + hip.COLOR_W_FLOATS], self._bc)
+            hip.pack_resnetfc(params, "density_head.", self._w[:n], self._bd, self._wz, 0, self._bz, precision=self.precision)
+            hip.pack_color_head(params, "color_head.", self._w[n:n + hip.COLOR_W_FLOATS], self._bc, precision=self.precision)
             self._pack_jacobian(params, self._w[n + hip.COLOR_W_FLOATS:], self._bj, self._wz, self._bz)
             self._packed_version = v
         return self._w, self._bd, self._bc, self._bj
@@ -273,7 +276,8 @@ class ActionDecoderJacobian(ActionDecoder):
         hip.points_forward(xyz_flat.contiguous(), None if dirs_flat is None else dirs_flat.contiguous(),
                            _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.action_dim), fmap,
                            self.GOFF_DENSITY, self.GOFF_JACOBIAN, 1, w, bd, bc, bj,
-                           jacobian_kind=self.JACOBIAN_KIND if with_jacobian else hip.JACOBIAN_NONE, **out)
+                           jacobian_kind=self.JACOBIAN_KIND if with_jacobian else hip.JACOBIAN_NONE,
+                           precision=self.precision, **out)
         return out
 
     # ---- reference API -----------------------------------------------------------------
@@ -329,7 +333,7 @@ class ActionDecoderJacobianMLP(ActionDecoderJacobian):
         self.color_head = self._make_color_head(cfg)
 
     def _pack_jacobian(self, params, w_j, b_j, wz, bz):
-        hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz)
+        hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.precision)
 
 
 # ---- parameter tree of model_components/transformer.py (names only; arithmetic is folded + fused) ----
@@ -403,7 +407,7 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
         f32 = lambda x: x.to(torch.float32).contiguous()
         half = lambda i: w_j[4096 * i: 4096 * (i + 1)]
         qw = self.jacobian_query_mlp.weight  # [64, 63 + 512], input = cat[xyz_features, pixel_aligned_features] (:421-427)
-        hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0))
+        hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0), precision=self.precision)
         # hoisted query channels use the same in-block order as lin_z (csrc: njf_hoist_position, MB=2)
         f = torch.arange(64, device=qw.device)
         pos = 32 * ((f % 32) // 16) + 8 * ((f % 16) // 4) + 4 * (f // 32) + (f % 4)
@@ -426,11 +430,11 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
             g2, be2 = ff.norm.weight.double(), ff.norm.bias.double()
             w1, b1 = ff.fn.net[0].weight.double(), ff.fn.net[0].bias.double()
             bl = b_j[256 * l: 256 * (l + 1)]
-            hip.pack_linear(f32(mqk * g1[None, :]), f32(mqk @ be1), 0, half(1 + 4 * l), bl[0:64])
-            hip.pack_linear(f32(nov), attn.fn.to_out[0].bias, 0, half(2 + 4 * l), bl[64:128])
-            hip.pack_linear(f32(w1 * g2[None, :]), f32(w1 @ be2 + b1), 0, half(3 + 4 * l), bl[128:192])
-            hip.pack_linear(ff.fn.net[3].weight, ff.fn.net[3].bias, 0, half(4 + 4 * l), bl[192:256])
-        hip.pack_linear(self.jacobian_head.weight, self.jacobian_head.bias, 0, half(13)[:2048], b_j[768:800])
+            hip.pack_linear(f32(mqk * g1[None, :]), f32(mqk @ be1), 0, half(1 + 4 * l), bl[0:64], precision=self.precision)
+            hip.pack_linear(f32(nov), attn.fn.to_out[0].bias, 0, half(2 + 4 * l), bl[64:128], precision=self.precision)
+            hip.pack_linear(f32(w1 * g2[None, :]), f32(w1 @ be2 + b1), 0, half(3 + 4 * l), bl[128:192], precision=self.precision)
+            hip.pack_linear(ff.fn.net[3].weight, ff.fn.net[3].bias, 0, half(4 + 4 * l), bl[192:256], precision=self.precision)
+        hip.pack_linear(self.jacobian_head.weight, self.jacobian_head.bias, 0, half(13)[:2048], b_j[768:800], precision=self.precision)
 
 
 # --------------------------------------------------------------------------------------

@@ -26,6 +26,17 @@ TRANSFORMER_W_FLOATS = 7 * 8192
 TRANSFORMER_B_FLOATS = 3 * 256 + 32
 QDIM = 64
 JACOBIAN_NONE, JACOBIAN_MLP, JACOBIAN_TRANSFORMER = 0, 1, 2
+# MFMA precision of the fused MLPs (include/njf_hip.h: NJF_PRECISION_*).  "f16x2" = fp32 operands split into two
+# fp16 (hi+lo), three f16 MFMAs per product block, fp32 accumulation: fp32-class accuracy, ~5x less matrix time.
+PRECISIONS = {"f32": 0, "f16x2": 1}
+DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16x2")
+
+
+def precision_code(precision: Optional[str]) -> int:
+    name = DEFAULT_PRECISION if precision is None else precision
+    if name not in PRECISIONS:
+        raise ValueError(f"njf_hip: unknown precision {name!r}; choose from {sorted(PRECISIONS)}")
+    return PRECISIONS[name]
 
 _vp = C.c_void_p
 
@@ -65,19 +76,19 @@ _lib = None
 _SIGNATURES = {
     "njf_abi_version": ([], C.c_int),
     "njf_error_string": ([C.c_int], C.c_char_p),
-    "njf_pack_resnetfc": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, _vp, _vp], C.c_int),
-    "njf_pack_resnetfc_ld": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
-    "njf_pack_color_head": ([C.POINTER(ColorHeadWeights), _vp, _vp, _vp], C.c_int),
-    "njf_pack_linear": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
+    "njf_pack_resnetfc": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
+    "njf_pack_resnetfc_ld": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp], C.c_int),
+    "njf_pack_color_head": ([C.POINTER(ColorHeadWeights), _vp, _vp, C.c_int, _vp], C.c_int),
+    "njf_pack_linear": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_project_features": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
-                              _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp], C.c_int),
+                              _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_render_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
-                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), _vp], C.c_int),
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), C.c_int, _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
-                            C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+                            C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
 }
@@ -148,7 +159,8 @@ def make_feature_map(gmap: torch.Tensor) -> FeatureMap:
 # packing
 # --------------------------------------------------------------------------------------
 def pack_resnetfc(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, b_out: torch.Tensor,
-                  wz: Optional[torch.Tensor] = None, wz_col: int = 0, bz: Optional[torch.Tensor] = None) -> None:
+                  wz: Optional[torch.Tensor] = None, wz_col: int = 0, bz: Optional[torch.Tensor] = None,
+                  precision: Optional[str] = None) -> None:
     """``params[prefix + 'lin_in.weight']`` ... (reference ResnetFC names) -> packed blobs.
 
     ``wz`` [512, ld] / ``bz`` [ld] receive this net's three lin_z layers at columns ``wz_col .. wz_col+383``."""
@@ -172,24 +184,27 @@ def pack_resnetfc(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Ten
             raise ValueError("njf_hip: wz must be [512, ld] with wz_col + 384 <= ld and bz [ld]")
         wz_ptr = _ptr(wz, "wz") + 4 * wz_col
         bz_ptr = _ptr(bz, "bz") + 4 * wz_col
-    _check(load_library().njf_pack_resnetfc_ld(C.byref(src), _ptr(w_out), _ptr(b_out), wz_ptr, ld, bz_ptr, _stream()))
+    _check(load_library().njf_pack_resnetfc_ld(C.byref(src), _ptr(w_out), _ptr(b_out), wz_ptr, ld, bz_ptr,
+                                               precision_code(precision), _stream()))
 
 
-def pack_color_head(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, b_out: torch.Tensor) -> None:
+def pack_color_head(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, b_out: torch.Tensor,
+                    precision: Optional[str] = None) -> None:
     def p(name):
         return _ptr(params[prefix + name].detach(), prefix + name)
 
     src = ColorHeadWeights(p("0.weight"), p("0.bias"), p("2.weight"), p("2.bias"), p("4.weight"), p("4.bias"))
-    _check(load_library().njf_pack_color_head(C.byref(src), _ptr(w_out), _ptr(b_out), _stream()))
+    _check(load_library().njf_pack_color_head(C.byref(src), _ptr(w_out), _ptr(b_out), precision_code(precision), _stream()))
 
 
 def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], kind: int, w_out: torch.Tensor,
-                b_out: Optional[torch.Tensor] = None) -> None:
+                b_out: Optional[torch.Tensor] = None, precision: Optional[str] = None) -> None:
     """One Linear [d_out, d_in] -> fragment-major block (see include/njf_hip.h: njf_pack_linear)."""
     d_out, d_in = weight.shape
     _check(load_library().njf_pack_linear(_ptr(weight.detach().contiguous(), "weight"),
                                           _ptr(None if bias is None else bias.detach().contiguous(), "bias"), d_out, d_in,
-                                          kind, _ptr(w_out, "w_out"), _ptr(b_out, "b_out"), _stream()))
+                                          kind, _ptr(w_out, "w_out"), _ptr(b_out, "b_out"), precision_code(precision),
+                                          _stream()))
 
 
 def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor) -> None:
@@ -212,17 +227,17 @@ def generate_rays(coords, height, width, k_inv, c2w, origins, directions, z) -> 
 
 def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_offset: int, w_pack, b_pack,
                      bins_in, s_in: int, u, s_out: int, anneal: float, bins_out, weights_out=None,
-                     density_out=None) -> None:
+                     density_out=None, precision: Optional[str] = None) -> None:
     rays_per_batch = origins.shape[1]
     _check(load_library().njf_proposal_forward(
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), gmap_offset,
         _ptr(w_pack), _ptr(b_pack), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u), int(u.dim() > 1), s_out,
-        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), _stream()))
+        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), precision_code(precision), _stream()))
 
 
 def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int,
                    w_all: torch.Tensor, b_density, b_color, b_jacobian, bins, samples: int, outputs: Dict[str, torch.Tensor],
-                   jacobian_kind: int = JACOBIAN_MLP) -> None:
+                   jacobian_kind: int = JACOBIAN_MLP, precision: Optional[str] = None) -> None:
     """``w_all`` is the single allocation [density | colour | jacobian head] of packed weights."""
     rays_per_batch = origins.shape[1]
     out = RenderOutputs()
@@ -235,12 +250,12 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     _check(load_library().njf_render_forward(
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian,
         jacobian_kind, base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_j else None,
-        _ptr(bins), samples, C.byref(out), _stream()))
+        _ptr(bins), samples, C.byref(out), precision_code(precision), _stream()))
 
 
 def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int, mode: int,
                    w_all, b_density, b_color=None, b_jacobian=None, jacobian_kind: int = JACOBIAN_NONE, density=None,
-                   color=None, flow=None, jacobian=None, geo=None) -> None:
+                   color=None, flow=None, jacobian=None, geo=None, precision: Optional[str] = None) -> None:
     points_per_batch = xyz.shape[1]
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS if mode == 1 else None
@@ -249,7 +264,8 @@ def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int
     _check(load_library().njf_points_forward(
         _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
         jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,
-        _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo), _stream()))
+        _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo),
+        precision_code(precision), _stream()))
 
 
 def alpha_weights(deltas, densities, weights) -> None:

@@ -135,6 +135,14 @@ class Model(nn.Module):
             num_proposal_network_iterations=n_prop, single_jitter=r.single_jitter, update_sched=update_schedule,
             initial_sampler=UniformSampler(single_jitter=r.single_jitter))
 
+    def set_precision(self, precision: str) -> "Model":
+        """MFMA precision of the fused MLPs: "f16x2" (default; fp32 operands split into fp16 hi+lo, fp32
+        accumulate) or "f32" (exact fp32 products).  Weights are re-packed lazily."""
+        hip.precision_code(precision)
+        for m in [self.decoder, *self.proposal_networks]:
+            m.precision = precision
+        return self
+
     # ---- schedule hooks (model.py:201-213) ---------------------------------------------
     def step_before_iter(self, step):
         r = self.cfg.rendering
@@ -229,7 +237,7 @@ class Model(nn.Module):
                         torch.linalg.inv(camera_input.trgt_extrinsics).contiguous(),
                         camera_input.trgt_intrinsics.contiguous())
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
-                           outs, jacobian_kind=self.decoder.JACOBIAN_KIND)
+                           outs, jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
         # tensor-global clip of model.py:277
         outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
                                     max=outs["step_minmax"][..., 1].max())

@@ -237,7 +237,7 @@ class ProposalNetworkSampler(Sampler):
             bins_out = torch.empty(b, r, s_out + 1, dtype=torch.float32, device=dev)
             w_out = torch.empty(b, r, s_in, dtype=torch.float32, device=dev) if want_lists else None
             hip.proposal_forward(o, d, cams, fmap, 0, w, bias, bins.contiguous(), s_in, u, s_out, self._anneal, bins_out,
-                                 w_out)
+                                 w_out, precision=net.precision)
             if want_lists:
                 weights_list.append(w_out[..., None])
                 bins_list.append(bins if bins.dim() > 1 else bins.expand(b, r, -1))

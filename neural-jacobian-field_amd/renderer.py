@@ -61,13 +61,16 @@ def pdf_u_eval(num_samples: int, device) -> torch.Tensor:
 class FusedRenderer:
     """Packed weights + fused forward for one ``Model`` (jacobian_mlp decoder)."""
 
-    def __init__(self, device: torch.device, num_proposal_networks: int = 1, action_dim: int = 8):
+    def __init__(self, device: torch.device, num_proposal_networks: int = 1, action_dim: int = 8,
+                 precision: Optional[str] = None):
         if torch.device(device).type != "cuda":
             raise ValueError("FusedRenderer needs a GPU device; the rendering hot path has no CPU fallback")
         hip.load_library()
         self.device = torch.device(device)
         self.n_prop = num_proposal_networks
         self.action_dim = action_dim
+        self.precision = hip.DEFAULT_PRECISION if precision is None else precision
+        hip.precision_code(self.precision)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.w_prop = [torch.empty(hip.RESNET_W_FLOATS, **f32) for _ in range(self.n_prop)]
         self.b_prop = [torch.empty(hip.RESNET_B_FLOATS, **f32) for _ in range(self.n_prop)]
@@ -88,16 +91,17 @@ class FusedRenderer:
         """``params``: reference state-dict names -> device tensors (``decoder.*``, ``proposal_networks.i.*``)."""
         for i in range(self.n_prop):
             hip.pack_resnetfc(params, f"proposal_networks.{i}.density_head.", self.w_prop[i], self.b_prop[i],
-                              self.wz, hip.ZDIM * i, self.bz)
+                              self.wz, hip.ZDIM * i, self.bz, precision=self.precision)
         w_d = self.w_dec[: hip.RESNET_W_FLOATS]
         w_c = self.w_dec[hip.RESNET_W_FLOATS: hip.RESNET_W_FLOATS + hip.COLOR_W_FLOATS]
         w_j = self.w_dec[hip.RESNET_W_FLOATS + hip.COLOR_W_FLOATS:]
-        hip.pack_resnetfc(params, "decoder.density_head.", w_d, self.b_density, self.wz, self.goff_density, self.bz)
-        hip.pack_color_head(params, "decoder.color_head.", w_c, self.b_color)
+        hip.pack_resnetfc(params, "decoder.density_head.", w_d, self.b_density, self.wz, self.goff_density, self.bz,
+                          precision=self.precision)
+        hip.pack_color_head(params, "decoder.color_head.", w_c, self.b_color, precision=self.precision)
         self.has_jacobian_mlp = "decoder.jacobian_head.lin_in.weight" in params
         if self.has_jacobian_mlp:
             hip.pack_resnetfc(params, "decoder.jacobian_head.", w_j, self.b_jacobian, self.wz, self.goff_jacobian,
-                              self.bz)
+                              self.bz, precision=self.precision)
         else:
             self.wz[:, self.goff_jacobian:].zero_()
             self.bz[self.goff_jacobian:].zero_()
@@ -147,7 +151,7 @@ class FusedRenderer:
             bins_out = torch.empty(b, r, s_out + 1, **f32)
             w_out = torch.empty(b, r, s_in, **f32) if req.sample_weights else None
             hip.proposal_forward(origins, directions, cams, fmap, hip.ZDIM * lvl, self.w_prop[lvl], self.b_prop[lvl],
-                                 bins, s_in, u, s_out, anneal, bins_out, w_out)
+                                 bins, s_in, u, s_out, anneal, bins_out, w_out, precision=self.precision)
             if req.sample_weights:
                 res.bins_list.append(bins if bins.dim() > 1 else bins.expand(b, r, -1))
                 res.weights_list.append(w_out[..., None])
@@ -181,7 +185,7 @@ class FusedRenderer:
                 outs["jacobian"] = torch.empty(b, r, s, 3 * self.action_dim, **f32)
         hip.render_forward(origins, directions, cams, fmap, self.goff_density, self.goff_jacobian, self.w_dec,
                            self.b_density, self.b_color, self.b_jacobian, bins, s, outs,
-                           jacobian_kind=hip.JACOBIAN_MLP if with_j else hip.JACOBIAN_NONE)
+                           jacobian_kind=hip.JACOBIAN_MLP if with_j else hip.JACOBIAN_NONE, precision=self.precision)
         if _events:
             _events[2].record()
         depth = outs["depth"]
