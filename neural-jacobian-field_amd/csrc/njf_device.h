@@ -26,7 +26,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Workgroup = 4 waves (one per SIMD), two workgroups resident per CU: the two waves sharing a SIMD's
 // MFMA pipe belong to DIFFERENT workgroups, so one workgroup's barrier / gather / encoding phases are
 // covered by the other's MFMA stream (with one 8-wave workgroup both waves of a SIMD stall together).
+#ifndef NJF_WAVES
 #define NJF_WAVES 4
+#endif
 #define NJF_THREADS (NJF_WAVES * 64)
 #define NJF_CHUNK 8192  // floats per weight chunk (32 KiB)
 
@@ -129,28 +131,102 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
   } else {
     // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
     // Lane (j,hh) supplies its own registers 8*tt .. 8*tt+7 of block kb as the 8 k-values of step t = 2*kb + tt.
+    // Software pipeline per K-step: (1) all 2*MBO A fragments of step t are requested from LDS up front,
+    // (2) the hi/lo split of step t+1's B operand (VALU) is spread between the MFMA triples of step t, so LDS
+    // latency and conversion work hide under the matrix pipe instead of preceding every triple.
     const f16x8* base = (const f16x8*)wl + lane;
+    constexpr int T = NKB * 2;
+    f16x8 bh, bl;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+    for (int i = 0; i < 8; ++i) {
+      float x = in[KB0][i];
+      if (RELU) x = fmaxf(x, 0.f);
+      const _Float16 h = (_Float16)x;
+      bh[i] = h;
+      bl[i] = (_Float16)(x - (float)h);
+    }
+    if constexpr (MBO == 4) {
+      // units u = (K-step t, pair of output blocks): the 4 A fragments of unit u+1 are requested (and pinned there
+      // with sched_barrier) before the 6 MFMAs of unit u, which cover the LDS latency; 2 x 16 VGPRs of A live.
+      // The hi/lo split of step t+1's B operand is spread behind the MFMA triples of step t (2 values each).
+      f16x8 a[4];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        f16x8 bh, bl;
+      for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float x = in[KB0 + kb][8 * tt + i];
-          if (RELU) x = fmaxf(x, 0.f);
-          const _Float16 h = (_Float16)x;
-          bh[i] = h;
-          bl[i] = (_Float16)(x - (float)h);
+      for (int t = 0; t < T; ++t) {
+        f16x8 nh = bh, nl = bl;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int u = 2 * t + half;
+          f16x8 n[4] = {a[0], a[1], a[2], a[3]};
+          if (u + 1 < 2 * T) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) n[i] = base[((u + 1) * 4 + i) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const int m = 2 * half + mm;
+#ifdef NJF_ABLATE_MFMA  // experiment builds only: keep operands alive, skip the matrix work
+            asm volatile("" :: "v"(a[2 * mm]), "v"(a[2 * mm + 1]), "v"(bh), "v"(bl));
+#else
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * mm + 1], bh, out[m], 0, 0, 0);
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * mm], bl, out[m], 0, 0, 0);
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * mm], bh, out[m], 0, 0, 0);
+#endif
+            if (t + 1 < T) {
+              const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
+#pragma unroll
+              for (int i = 2 * m; i < 2 * m + 2; ++i) {
+                float x = in[KB0 + kb2][8 * tt2 + i];
+                if (RELU) x = fmaxf(x, 0.f);
+#ifdef NJF_ABLATE_SPLIT  // experiment builds only: no hi/lo conversion work
+                nh[i] = (_Float16)1.0f;
+                nl[i] = (_Float16)0.0f;
+                asm volatile("" :: "v"(x));
+#else
+                const _Float16 h = (_Float16)x;
+                nh[i] = h;
+                nl[i] = (_Float16)(x - (float)h);
+#endif
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = n[i];
+        }
+        bh = nh;
+        bl = nl;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f16x8 ah[MBO], al[MBO];
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) {
+          ah[m] = base[((t * MBO + m) * 2 + 0) * 64];
+          al[m] = base[((t * MBO + m) * 2 + 1) * 64];
+        }
+        f16x8 nh = bh, nl = bl;
+        if (t + 1 < T) {
+          const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float x = in[KB0 + kb2][8 * tt2 + i];
+            if (RELU) x = fmaxf(x, 0.f);
+            const _Float16 h = (_Float16)x;
+            nh[i] = h;
+            nl[i] = (_Float16)(x - (float)h);
+          }
         }
 #pragma unroll
         for (int m = 0; m < MBO; ++m) {
-          const f16x8 ah = base[(((kb * 2 + tt) * MBO + m) * 2 + 0) * 64];
-          const f16x8 al = base[(((kb * 2 + tt) * MBO + m) * 2 + 1) * 64];
-          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[m], 0, 0, 0);
-          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[m], 0, 0, 0);
-          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[m], 0, 0, 0);
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, out[m], 0, 0, 0);
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, out[m], 0, 0, 0);
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, out[m], 0, 0, 0);
         }
+        bh = nh;
+        bl = nl;
       }
     }
   }
@@ -257,28 +333,34 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
   return;
 #endif
-  const float* p00 = gz + g.t00 + 4 * hh;
-  const float* p01 = gz + g.t01 + 4 * hh;
-  const float* p10 = gz + g.t10 + 4 * hh;
-  const float* p11 = gz + g.t11 + 4 * hh;
+  const float* p[4] = {gz + g.t00 + 4 * hh, gz + g.t01 + 4 * hh, gz + g.t10 + 4 * hh, gz + g.t11 + 4 * hh};
+  const float w[4] = {g.w00, g.w01, g.w10, g.w11};
+  // The gather is latency-bound: with NJF_GATHER_BATCH texels per batch, 4*MB*BATCH float4 loads are in flight
+  // together (the registers `net` vacates at this point of the block), then folded into h.  The asm fence makes
+  // the fmas retire into h before the next batch's loads are issued (otherwise the scheduler either hoists all
+  // 16*MB loads -> 256 VGPRs -> scratch, or serialises them 4 at a time -> 16 L2 round trips per gather).
+#ifndef NJF_GATHER_BATCH
+#define NJF_GATHER_BATCH 1
+#endif
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
+  for (int t0 = 0; t0 < 4; t0 += NJF_GATHER_BATCH) {
+    f32x4 v[NJF_GATHER_BATCH][MB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int o = 32 * m + 8 * q;
-      const f32x4 a = *(const f32x4*)(p00 + o);
-      const f32x4 b = *(const f32x4*)(p01 + o);
-      const f32x4 c = *(const f32x4*)(p10 + o);
-      const f32x4 d = *(const f32x4*)(p11 + o);
+    for (int t = 0; t < NJF_GATHER_BATCH; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = a[e] * g.w00;
-        t = fmaf(b[e], g.w01, t);
-        t = fmaf(c[e], g.w10, t);
-        t = fmaf(d[e], g.w11, t);
-        h[m][4 * q + e] += t;
-      }
-    }
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[t][m][q] = *(const f32x4*)(p[t0 + t] + 32 * m + 8 * q);
+#pragma unroll
+    for (int t = 0; t < NJF_GATHER_BATCH; ++t)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[m][4 * q + e] = fmaf(v[t][m][q][e], w[t0 + t], h[m][4 * q + e]);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) asm volatile("" : "+v"(h[m]) : : "memory");
   }
 }
 

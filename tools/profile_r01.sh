@@ -1,18 +1,21 @@
 #!/bin/bash
 # rocprofv3 recipe for the round-1 profiles (run on the GPU box through gpurun, from the repo root).
+#   bash tools/profile_r01.sh <precision: f16x2|f32>
 # Kernel-trace/stats and each PMC group are separate runs (PMC is never combined with other trace domains).
 set -u
+PREC=${1:-f16x2}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/prof_r01
+OUT=$REPO/gpurun_out/prof_r01_$PREC
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+export NJF_PRECISION=$PREC
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
-           "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
+           "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
 done
-find $OUT -name "*.csv" | head -40
+ls $OUT

@@ -14,12 +14,16 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
+prec = sys.argv[2] if len(sys.argv) > 2 else "f16x2"
+src = f"gpurun_out/prof_{tag}_{prec}"
+tag = f"{tag}_{prec}"
+MFMA_FLOP = 4096 if prec == "f32" else 32768      # v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16
+MFMA_CYCLES = 64 if prec == "f32" else 32
 os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
-KERNELS = {"render_kernel<true>": "render", "proposal_kernel": "proposal", "project_kernel": "project"}
+KERNELS = {"render_kernel<1": "render", "proposal_kernel": "proposal", "project_kernel": "project"}
 agg = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"{src}/pmc*/*/*_counter_collection.csv"):
@@ -36,7 +40,7 @@ for r in csv.DictReader(open(stats)):
             dur[short] = float(r["AverageNs"]) * 1e-9
 
 lines = [f"# {tag}: rocprofv3 PMC summary (MI355X, `python bench.py --steps 2 --warmup 1`, per-launch means)", "",
-         "Collected by `tools/profile_r01.sh`: kernel-trace/stats and each PMC group in separate runs.", "",
+         f"Collected by `tools/profile_r01.sh {prec}`: kernel-trace/stats and each PMC group in separate runs.", "",
          "| kernel | avg duration (kernel-trace) | launch config |", "|---|---|---|"]
 for k in ("project", "proposal", "render"):
     lines.append(f"| {k} | {dur[k]*1e3:.3f} ms | {meta.get(k)} |")
@@ -49,7 +53,7 @@ for k in ("proposal", "render"):
     xcd_cycles = mean[(k, "GRBM_GUI_ACTIVE")] / 8.0          # one GRBM per XCD, summed by rocprofv3
     clock = xcd_cycles / dur[k]
     mfma_util = mean[(k, "SQ_VALU_MFMA_BUSY_CYCLES")] / (xcd_cycles * 1024)   # 1024 SIMDs
-    flop = mean[(k, "SQ_INSTS_MFMA")] * 4096                  # v_mfma_f32_32x32x2_f32 = 4096 FLOP
+    flop = mean[(k, "SQ_INSTS_MFMA")] * MFMA_FLOP
     fetch, write = mean[(k, "FETCH_SIZE")] * 1024, mean[(k, "WRITE_SIZE")] * 1024
     hbm = 2 * fetch + write   # gfx950: FETCH_SIZE reports half of wide (16 B/lane) reads (MI355X_MICROARCH.md, HBM)
     l2 = mean[(k, "TCC_HIT_sum")] / (mean[(k, "TCC_HIT_sum")] + mean[(k, "TCC_MISS_sum")])
@@ -59,16 +63,20 @@ for k in ("proposal", "render"):
               f"= {flop/dur[k]/1e12:.1f} TFLOP/s",
               f"* MFMA pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)) = {100*mfma_util:.1f} %",
               f"* wave time: issue-stall {100*mean[(k,'SQ_WAIT_INST_ANY')]/wc:.0f} %, waitcnt/barrier "
-              f"{100*mean[(k,'SQ_WAIT_ANY')]/wc:.0f} %, issuing {100*mean[(k,'SQ_ACTIVE_INST_ANY')]/wc:.0f} %",
+              f"{100*mean[(k,'SQ_WAIT_ANY')]/wc:.0f} %, issuing {100*mean[(k,'SQ_ACTIVE_INST_ANY')]/wc:.0f} % "
+              f"(VALU {100*mean.get((k,'SQ_ACTIVE_INST_VALU'),0)/wc:.0f} %, LDS {100*mean.get((k,'SQ_ACTIVE_INST_LDS'),0)/wc:.0f} %, "
+              f"VMEM {100*mean.get((k,'SQ_ACTIVE_INST_VMEM'),0)/wc:.0f} %); LDS-issue stall {100*mean.get((k,'SQ_WAIT_INST_LDS'),0)/wc:.0f} %",
+              f"* instructions per launch: MFMA {mean[(k,'SQ_INSTS_MFMA')]:.3g}, VALU {mean[(k,'SQ_INSTS_VALU')]:.3g}, "
+              f"LDS {mean.get((k,'SQ_INSTS_LDS'),0):.3g}, VMEM {mean.get((k,'SQ_INSTS_VMEM'),0):.3g}",
               f"* LDS bank-conflict cycles {mean[(k,'SQ_LDS_BANK_CONFLICT')]:.3g} of {mean[(k,'SQ_LDS_IDX_ACTIVE')]:.3g} active",
               f"* L2 hit rate {100*l2:.1f} %; memory-side traffic: FETCH_SIZE {fetch/1e9:.2f} GB (x2 correction -> "
               f"{2*fetch/1e9:.2f} GB), WRITE_SIZE {write/1e9:.2f} GB -> {hbm/1e9:.2f} GB per launch "
               f"({hbm/dur[k]/1e12:.2f} TB/s; includes Infinity-Cache hits and scratch spill traffic)", ""]
     if k == "render":
-        out_json = {"kernel": "render_kernel<true>", "hbm_bytes_per_launch": hbm, "fetch_size_bytes_raw": fetch,
+        out_json = {"kernel": f"render_kernel<jacobian_mlp, {prec}>", "hbm_bytes_per_launch": hbm, "fetch_size_bytes_raw": fetch,
                     "write_size_bytes": write, "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), rocprofv3 --pmc, "
                     "separate passes; counts L2 memory-side requests incl. Infinity-Cache hits and scratch traffic",
                     "avg_duration_s": dur[k], "mfma_util": mfma_util, "clock_hz": clock}
 open(f"profiles/{tag}_pmc_summary.md", "w").write("\n".join(lines) + "\n")
-json.dump(out_json, open(f"profiles/{tag}_render_kernel_hbm_bytes.json", "w"), indent=1)
+json.dump(out_json, open(f"profiles/r01_render_kernel_hbm_bytes_{prec}.json", "w"), indent=1)
 print("\n".join(lines[-16:]))
