@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rays", type=int, default=1024)
+    ap.add_argument("--cpu-sample-rays", type=int, default=8192)
     ap.add_argument("--precision", choices=["f16x2", "f32"], default=None,
                     help="MFMA precision of the fused MLPs (default: package default, f16x2 split with fp32 accumulate)")
     return ap.parse_args()
@@ -58,7 +58,9 @@ def cpu_baseline(case, sample_rays: int):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity_harness as ph
 
-    cores = os.cpu_count() or 1
+    # 32 threads is the fastest setting on the GPU box's 256-core host (tools/cpu_threads_probe.py: 8/16/32/64/128
+    # threads -> 760/762/808/707/337 rays/s; all 256 threads oversubscribe these small ops and drop to ~20 rays/s)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sub = dict(case)
     sub["origins"] = case["origins"][:, :sample_rays].contiguous()
@@ -111,8 +113,12 @@ def main():
     dev = lambda t: t.to(device)
     from neural_jacobian_field_amd import hip
     precision = args.precision or hip.DEFAULT_PRECISION
-    fr = FusedRenderer(device, 1, ACTION_DIM, precision=precision)
-    fr.load_weights({k: dev(v) for k, v in case["params"].items()})
+    dev_params = {k: dev(v) for k, v in case["params"].items()}
+    renderers = {}
+    for prec in ("f16x2", "f32"):
+        renderers[prec] = FusedRenderer(device, 1, ACTION_DIM, precision=prec)
+        renderers[prec].load_weights(dev_params)
+    fr = renderers[precision]
     feats = dev(case["feats"])
     origins, directions = dev(case["origins"]), dev(case["directions"])
     ctxt_w2c, trgt_w2c = dev(torch.inverse(cams["ctxt_c2w"])), dev(torch.inverse(cams["trgt_c2w"]))
@@ -126,7 +132,7 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     loss_buf = torch.zeros(2, device=device)
 
-    def step(events=None):
+    def step(events=None, fr=fr):
         if events:
             events[0].record()
         gmap = fr.project(feats)
@@ -160,6 +166,16 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+
+    # the other MFMA precision, measured briefly in the same process (not part of `value`)
+    alt = "f32" if precision == "f16x2" else "f16x2"
+    alt_steps = max(2, args.steps // 4)
+    alt_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(alt_steps)]
+    step(fr=renderers[alt])
+    torch.cuda.synchronize()
+    for i in range(alt_steps):
+        step(alt_ev[i], fr=renderers[alt])
+    torch.cuda.synchronize()
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -196,6 +212,12 @@ def main():
                          "mfma_issue_factor": ISSUE_FACTOR[precision],
                          "frac_of_fp32_mfma_peak": round(achieved / PEAK_TFLOPS["f32"], 4)},
         }
+        alt_ms = sum(e[0].elapsed_time(e[5]) for e in alt_ev) / alt_steps
+        alt_render = sum(e[3].elapsed_time(e[4]) for e in alt_ev) / alt_steps
+        alt_ach = render_flop / (alt_render * 1e-3) / 1e12
+        out["other_precision"] = {"precision": alt, "ms_per_step": round(alt_ms, 3), "rays_per_s_per_gpu": round(rays / (alt_ms * 1e-3), 1),
+                                  "render_kernel_ms": round(alt_render, 3), "roofline_achieved_tflops": round(alt_ach, 2),
+                                  "roofline_peak_tflops": PEAK_TFLOPS[alt], "roofline_frac": round(alt_ach / PEAK_TFLOPS[alt], 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case, args.cpu_sample_rays)
         print(json.dumps(out), flush=True)
