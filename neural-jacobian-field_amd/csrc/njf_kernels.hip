@@ -1067,3 +1067,4 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, PREC_F32>, a, tiles, s);
   return launch_fused(points_kernel<1, PREC_F32>, a, tiles, s);
 }
+
