@@ -22,6 +22,9 @@ def device():
     dict(batch=1, height=32, width=32, rays=None, s_prop=64, s_final=64, action_dim=6),
     dict(batch=2, height=16, width=16, rays=40, s_prop=32, s_final=32, identity_context=False),
     dict(batch=1, height=16, width=16, rays=40, s_prop=32, s_final=32, anneal=0.35),
+    dict(batch=4, height=16, width=16, rays=48, s_prop=128, s_final=128),         # BASELINE config 3 shape (B=4, 128+128)
+    dict(batch=1, height=16, width=16, rays=24, s_prop=256, s_final=256),         # the reference's shipped 256+256 samples
+    dict(batch=1, height=16, width=16, rays=1, s_prop=1, s_final=1),              # degenerate: one ray, one sample
 ])
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
 def test_fused_forward_matches_oracle(device, cfg, precision):

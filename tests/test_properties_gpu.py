@@ -1,0 +1,142 @@
+"""Size-independent properties at BASELINE.json's full size (C2: 256x256 rays, 64+64 samples), randomised checks of
+the stand-alone sampler ops against the oracle, and error behaviour of the binding.  Run with -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def full_frame(dev):
+    """One full C2 frame through the fused path (default precision), with per-sample outputs."""
+    import parity_harness as ph
+    from neural_jacobian_field_amd.renderer import RenderRequest
+    case = ph.make_case(1, 256, 256, None, 8, seed=0)
+    res, fr, gmap = ph.hip_forward(case, 64, 64, dev, request=RenderRequest(vis=True, sample_weights=True, per_sample=True))
+    torch.cuda.synchronize()
+    return case, res, fr, gmap
+
+
+def test_full_size_outputs_are_sane(full_frame):
+    case, res, _, _ = full_frame
+    for t in [res.rgb, res.depth, res.optical_flow, *res.extras.values()]:
+        assert torch.isfinite(t).all()
+    w = res.extras["weights"]
+    assert (w >= 0).all() and (w <= 1 + 1e-6).all()
+    assert (w.sum(-1) <= 1 + 1e-5).all()                       # alpha compositing never exceeds full opacity
+    assert (res.rgb >= -1e-6).all() and (res.rgb <= 1 + 1e-5).all()
+    near, far = case["cams"]["z_near"].item(), case["cams"]["z_far"].item()
+    assert (res.depth >= near - 1e-4).all() and (res.depth <= far + 1e-4).all()
+    for bins in res.bins_list:                                   # bin edges sorted inside [0, 1]
+        assert (bins[..., 1:] >= bins[..., :-1]).all() and (bins >= 0).all() and (bins <= 1).all()
+    assert (res.weights_list[0] >= 0).all() and (res.weights_list[0].sum(-2) <= 1 + 1e-5).all()
+
+
+def test_full_size_ray_sharding_is_exact(full_frame, dev):
+    """Rays are independent units: rendering the frame in uneven shards reproduces the full-frame result bit for bit
+    (this is what makes the data-parallel ray sharding of parallel.py exact)."""
+    import parity_harness as ph
+    case, res, _, _ = full_frame
+    bounds = [0, 7, 20000, 20031, 65536]
+    rgb, flow, depth = [], [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        sub = dict(case)
+        sub["origins"], sub["directions"] = case["origins"][:, lo:hi].contiguous(), case["directions"][:, lo:hi].contiguous()
+        # depth: compare before the tensor-global clip (per-shard bounds differ; parallel.global_depth_clip all-reduces them)
+        r, fr, gmap = ph.hip_forward(sub, 64, 64, dev)
+        rgb.append(r.rgb); flow.append(r.optical_flow); depth.append(r.depth)
+    assert torch.equal(torch.cat(rgb, 1), res.rgb)
+    assert torch.equal(torch.cat(flow, 1), res.optical_flow)
+    assert torch.equal(torch.cat(depth, 1), res.depth)          # clip is inactive here: depth lies inside every shard's bounds
+
+
+def test_full_size_flow_is_linear_in_the_action(full_frame, dev):
+    """flow_s = J_s . a (action_decoder_jacobian.py:128-145): per-sample 3-D flow scales linearly with the command, and
+    density / colour / weights do not depend on it."""
+    import parity_harness as ph
+    from neural_jacobian_field_amd.renderer import RenderRequest
+    case, res, _, _ = full_frame
+    sub = dict(case)
+    sub["origins"], sub["directions"] = case["origins"][:, :4096].contiguous(), case["directions"][:, :4096].contiguous()
+    req = RenderRequest(per_sample=True)
+    a = ph.hip_forward(sub, 64, 64, dev, request=req)[0]
+    sub2 = dict(sub); sub2["action"] = case["action"] * -2.5
+    b = ph.hip_forward(sub2, 64, 64, dev, request=req)[0]
+    assert torch.equal(a.extras["density"], b.extras["density"]) and torch.equal(a.rgb, b.rgb)
+    assert torch.equal(a.extras["jacobian"], b.extras["jacobian"])
+    scale = a.extras["sample_flow"].abs().max()
+    assert ((b.extras["sample_flow"] + 2.5 * a.extras["sample_flow"]).abs().max() / scale) < 1e-5
+
+
+def test_full_size_checksums_are_reproducible(full_frame, dev):
+    import parity_harness as ph
+    case, res, _, _ = full_frame
+    again = ph.hip_forward(case, 64, 64, dev)[0]
+    assert torch.equal(again.rgb, res.rgb) and torch.equal(again.depth, res.depth)
+    assert torch.equal(again.optical_flow, res.optical_flow)
+
+
+def test_sampler_ops_randomised_vs_oracle(dev):
+    """alpha_weights / pdf_resample on random, ragged and degenerate inputs (zero widths, zero weights, delta pdfs,
+    sample counts that are not multiples of the 32-lane tile)."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import hip
+    g = torch.Generator().manual_seed(7)
+    for trial in range(12):
+        rays = int(torch.randint(1, 70, (1,), generator=g))
+        s_in = int(torch.randint(1, 257, (1,), generator=g))
+        s_out = int(torch.randint(1, 300, (1,), generator=g))
+        bins = torch.sort(torch.rand(rays, s_in + 1, generator=g), -1).values
+        bins[:, 0], bins[:, -1] = 0.0, 1.0
+        deltas = (bins[:, 1:] - bins[:, :-1]) * 9.5
+        dens = torch.exp(2.0 * torch.randn(rays, s_in, generator=g))
+        if trial % 3 == 0:
+            deltas[:, ::5] = 0.0
+            deltas[:, 1::7] = -0.1
+        ref_w = orc.alpha_weights(deltas[..., None], dens[..., None])[..., 0]
+        out_w = torch.empty(rays, s_in, device=dev)
+        hip.alpha_weights(deltas.to(dev).contiguous(), dens.to(dev).contiguous(), out_w)
+        assert ((out_w.cpu() - ref_w).abs().max() / (ref_w.abs().max() + 1e-30)) < 1e-5
+        w = ref_w.clone()
+        if trial % 4 == 1:
+            w[: rays // 2] = 0.0                                   # all-zero rays: padding path
+        if trial % 4 == 2:
+            w.zero_(); w[:, s_in // 2] = 1.0                       # delta pdf
+        o = torch.zeros(rays, 3); d = torch.zeros(rays, 3); d[:, 2] = 1
+        near, far = torch.full((rays, 1), 0.5), torch.full((rays, 1), 10.0)
+        prev = orc._samples_from_bins(o, d, near, far, bins)
+        ref = orc.pdf_resample(prev, w[..., None], s_out)
+        ref_bins = torch.cat([ref.spacing_starts[..., 0], ref.spacing_ends[..., -1:, 0]], -1)
+        nb = s_out + 1
+        u = (torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb) + 1.0 / (2 * nb)).to(dev)
+        out_bins = torch.empty(rays, nb, device=dev)
+        hip.pdf_resample(w.to(dev).contiguous(), bins.to(dev).contiguous(), u, s_out, 1.0, out_bins)
+        # an inverse-CDF sample can flip bins when u lands within an ulp of a cdf value; compare robustly
+        err = (out_bins.cpu() - ref_bins).abs()
+        assert err.max() < 1e-5 or (err > 1e-5).float().mean() < 2e-3, (trial, err.max())
+        assert (out_bins[:, 1:] >= out_bins[:, :-1]).all()
+
+
+def test_binding_error_behaviour(dev):
+    from neural_jacobian_field_amd import hip
+    z = torch.zeros(2, 300, device=dev)
+    with pytest.raises(ValueError, match="samples"):
+        hip.pdf_resample(z, torch.zeros(301, device=dev), torch.zeros(9, device=dev), 8, 1.0, torch.zeros(2, 9, device=dev))
+    with pytest.raises(ValueError, match="contiguous"):
+        hip.alpha_weights(z.t(), z.t(), z.t())
+    with pytest.raises(ValueError, match="float32"):
+        hip.alpha_weights(z.double(), z.double(), z.double())
+    with pytest.raises(ValueError, match="precision"):
+        hip.precision_code("fp8")
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    with pytest.raises(ValueError, match="action_dim"):
+        Model(model_cfg_from_dict({"action_dim": 11}))
