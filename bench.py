@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=8192)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=S_FINAL, help="proposal and final samples per ray")
     ap.add_argument("--precision", choices=["f16x2", "f32"], default=None,
                     help="MFMA precision of the fused MLPs (default: package default, f16x2 split with fp32 accumulate)")
     return ap.parse_args()
@@ -91,10 +96,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
+        if "MASTER_ADDR" not in os.environ:  # --force-dist without torchrun
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     import __graft_entry__ as entry
@@ -108,7 +116,8 @@ def main():
     from neural_jacobian_field_amd.renderer import FusedRenderer
 
     # ---- synthetic frame (seeded per rank: every rank renders its own image) -------------------
-    case = ph.make_case(1, H, W, None, ACTION_DIM, seed=rank)
+    HH, WW, BB, SS = args.height, args.width, args.batch, args.samples
+    case = ph.make_case(BB, HH, WW, None, ACTION_DIM, seed=rank)
     cams = case["cams"]
     dev = lambda t: t.to(device)
     from neural_jacobian_field_amd import hip
@@ -125,9 +134,9 @@ def main():
     ctxt_c2w, ctxt_k, trgt_c2w = dev(cams["ctxt_c2w"]), dev(cams["ctxt_k_norm"]), dev(cams["trgt_c2w"])
     z_near, z_far, k_pix, action = dev(cams["z_near"]), dev(cams["z_far"]), dev(case["k_pix"]), dev(case["action"])
     g = torch.Generator().manual_seed(100 + rank)
-    trgt_rgb = dev(torch.rand(1, H * W, 3, generator=g))
-    trgt_flow = dev(torch.randn(1, H * W, 2, generator=g))
-    rays = H * W
+    trgt_rgb = dev(torch.rand(BB, HH * WW, 3, generator=g))
+    trgt_flow = dev(torch.randn(BB, HH * WW, 2, generator=g))
+    rays = BB * HH * WW
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     loss_buf = torch.zeros(2, device=device)
@@ -138,7 +147,7 @@ def main():
         gmap = fr.project(feats)
         if events:
             events[1].record()
-        res = fr.render(gmap, origins, directions, ctxt_c2w, ctxt_k, z_near, z_far, [S_PROP], S_FINAL,
+        res = fr.render(gmap, origins, directions, ctxt_c2w, ctxt_k, z_near, z_far, [SS], SS,
                         trgt_c2w=trgt_c2w, trgt_k_pix=k_pix, action=action, ctxt_w2c=ctxt_w2c, trgt_w2c=trgt_w2c,
                         _events=events[2:5] if events else None)
         # photometric + flow loss (model_wrapper.py:117-163), summed locally then all-reduced
@@ -186,7 +195,7 @@ def main():
             k_ms["proposal"] += e[2].elapsed_time(e[3])
             k_ms["render"] += e[3].elapsed_time(e[4])
         k_ms = {k: v / args.steps for k, v in k_ms.items()}
-        render_flop = 2.0 * rays * S_FINAL * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
+        render_flop = 2.0 * rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
         achieved = render_flop / (k_ms["render"] * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"r01_render_kernel_hbm_bytes_{precision}.json")
@@ -200,9 +209,10 @@ def main():
             "dtype": "f32" if precision == "f32" else "f32 in/out + fp32 accumulate; MFMA operands split hi+lo into 2 x f16 "
                      "(3 f16 MFMAs per product block, fp32-class accuracy: same parity bound as the f32-MFMA path)",
             "data": "synthetic",
-            "config": {"workload": "C2: Allegro single-view PixelNeRF, B=1, 256x256 rays, 64 proposal + 64 final "
+            "config": {"workload": ("C2: " if (BB, HH, WW, SS) == (1, 256, 256, 64) else "") +
+                                   f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final "
                                    "samples/ray, jacobian_mlp, A=8, eval-mode Model.forward (encoder excluded), "
-                                   "+ rgb/flow loss" + (" + RCCL all-reduce" if world > 1 else ""),
+                                   "+ rgb/flow loss" + (" + RCCL all-reduce" if dist is not None else ""),
                        "rays_per_gpu": rays, "parallelism": f"dp{world} (ray-sharded, replicated weights)"},
             "kernel_ms": {k: round(v, 3) for k, v in k_ms.items()},
             "roofline": {"kernel": f"render_kernel<jacobian_mlp, {precision}> (density+colour+Jacobian MLPs + compositing)",
@@ -218,8 +228,11 @@ def main():
         out["other_precision"] = {"precision": alt, "ms_per_step": round(alt_ms, 3), "rays_per_s_per_gpu": round(rays / (alt_ms * 1e-3), 1),
                                   "render_kernel_ms": round(alt_render, 3), "roofline_achieved_tflops": round(alt_ach, 2),
                                   "roofline_peak_tflops": PEAK_TFLOPS[alt], "roofline_frac": round(alt_ach / PEAK_TFLOPS[alt], 4)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and (BB, HH, WW, SS) == (1, 256, 256, 64):
             out["cpu_baseline"] = cpu_baseline(case, args.cpu_sample_rays)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # anything native libraries buffered on stdout goes out BEFORE the JSON line
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
