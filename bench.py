@@ -117,7 +117,9 @@ def main():
 
     # ---- synthetic frame (seeded per rank: every rank renders its own image) -------------------
     HH, WW, BB, SS = args.height, args.width, args.batch, args.samples
-    case = ph.make_case(BB, HH, WW, None, ACTION_DIM, seed=rank)
+    case = ph.make_case(BB, HH, WW, None, ACTION_DIM, seed=0)  # weights/cameras replicated on every rank (data parallel)
+    from neural_jacobian_field_amd import synthetic
+    case["feats"] = synthetic.synthetic_features(BB, HH, WW, seed=1 + rank)  # ... each rank renders its own image
     cams = case["cams"]
     dev = lambda t: t.to(device)
     from neural_jacobian_field_amd import hip
