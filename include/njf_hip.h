@@ -171,6 +171,11 @@ typedef struct NjfRenderOutputs {
   float* color;           /* [B*R,S,3]; NULL to skip */
   float* sample_flow;     /* [B*R,S,3] per-sample 3-D flow; NULL to skip */
   float* jacobian;        /* [B*R,S,3A] per-sample action features (encode_image, model.py:458-495); NULL to skip */
+  /* training forward (jacobian_mlp only): inputs of the backward pass of the Jacobian head; all NULL for inference */
+  float* jac_act;         /* [11, B*R*S, 128] ReLU'd input of fc_0 / fc_1 of block b at 2b / 2b+1, of lin_out at 10 */
+  float* jac_pe;          /* [B*R*S, 64] positional encoding in slot order [sin 30 | x | y | cos 30 | z | 1] */
+  int* foot_idx;          /* [B*R*S, 4] texel indices (b*Hf*Wf + y*Wf + x) of the bilinear footprint; may be NULL */
+  float* foot_w;          /* [B*R*S, 4] bilinear weights (nw, ne, sw, se) */
 } NjfRenderOutputs;
 
 /* bins [B*R, S+1] are spacing-domain bin edges in [0,1] (output of njf_proposal_forward or a

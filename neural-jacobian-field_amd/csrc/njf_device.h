@@ -435,20 +435,56 @@ __device__ __forceinline__ void sh4(float dx, float dy, float dz, float (&o)[16]
 // One ResnetFC (resnet_fc.py:130-154) on a 32-point tile: 22 weight chunks.
 // bias layout (LDS): [blk: fc0 (128) | fc1 (128)] x 5 | lin_out (32).
 // ------------------------------------------------------------------------------------------
-template <int PREC>
+// Activation dump for the backward pass (training only): the ReLU'd input of every layer of the net, written in
+// logical feature order as [layer][point][128] (+ the 64-slot positional encoding).  `dump` addresses layer 0 of
+// this lane's point (+ 64*hh), `stride` = floats between layers; nullptr lanes (padding samples) skip the stores.
+struct ActDump {
+  float* act;     // [11][P][128] : r0_b = 2b, r1_b = 2b+1 (b = 0..4), r_out = 10
+  float* pe;      // [P][64] slot order
+  size_t stride;  // P * 128
+};
+
+template <bool DO_RELU>
+__device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x16 (&v)[4]) {
+  if (dst == nullptr) return;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = DO_RELU ? fmaxf(v[m][4 * q + e], 0.f) : v[m][4 * q + e];
+      *(f32x4*)(dst + 16 * m + 4 * q) = o;
+    }
+}
+
+template <int PREC, bool DUMP = false>
 __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __restrict__ bias,
                                             const float* __restrict__ gz, const PointGeom& g,
-                                            const f32x16 (&pe)[2], int wave, int lane, f32x16 (&out)[1]) {
+                                            const f32x16 (&pe)[2], int wave, int lane, f32x16 (&out)[1],
+                                            ActDump dump = ActDump{nullptr, nullptr, 0}) {
   const int hh = lane >> 5;
   f32x16 h[4], net[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) h[m] = (f32x16)(0.f);
+  if (DUMP && dump.pe != nullptr) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pe[kb][4 * q + e];
+        *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
+      }
+  }
   {
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 4, 2, 0, false, 2>(wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
   for (int blk = 0; blk < 5; ++blk) {
     if (blk < 3) add_hoisted_latent<4>(gz + blk * 128, g, hh, h);
+    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
     const float* bl = bias + blk * 256;
     bias_init<4, true>(bl, hh, net);
     {
@@ -459,6 +495,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 2, true, 4>(wl, lane, h, net);
     }
+    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
     bias_init<4, false>(bl + 128, hh, h);
     {
       const float* wl = stream_step(st, wave, lane);
@@ -469,6 +506,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
       mma_chunk<PREC, 4, 2, 2, true, 4>(wl, lane, net, h);
     }
   }
+  if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h);
   bias_init<1, true>(bias + 1280, hh, out);
   {
     const float* wl = stream_step(st, wave, lane);

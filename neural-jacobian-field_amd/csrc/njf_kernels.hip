@@ -498,11 +498,12 @@ struct TileOut {
 
 // bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian head (MLP 1312 / transformer 800)]
 // JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
-template <int JKIND, int PREC>
+template <int JKIND, int PREC, bool DUMP = false>
 __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __restrict__ gz_d,
                                              const float* __restrict__ gz_j, const PointGeom& g, float dirx, float diry,
                                              float dirz, const float* __restrict__ action, int action_dim, int wave,
-                                             int lane, TileOut& o, f32x16 (&geo)[1], f32x16 (&jac)[1]) {
+                                             int lane, TileOut& o, f32x16 (&geo)[1], f32x16 (&jac)[1],
+                                             ActDump dump = ActDump{nullptr, nullptr, 0}) {
   const int j = lane & 31, hh = lane >> 5;
   const float* bias = njf_lds + LDS_BIAS;
   {
@@ -529,7 +530,8 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     asm volatile("" ::: "memory");
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    if (JKIND == 1) resnet_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac);
+    if (JKIND == 1)
+      resnet_tile<PREC, DUMP>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac, dump);
     else transformer_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
     // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
     // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
@@ -569,7 +571,7 @@ struct RenderArgs {
   NjfRenderOutputs out;
 };
 
-template <int JKIND, int PREC>
+template <int JKIND, int PREC, bool DUMP = false>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   constexpr bool WITH_J = JKIND != 0;
   constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
@@ -626,7 +628,28 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
     TileOut o;
     f32x16 geo[1], jac[1];
-    decoder_tile<JKIND, PREC>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac);
+    ActDump dump{nullptr, nullptr, 0};
+    if (DUMP && valid && ray_ok) {
+      const size_t pidx = (size_t)ray * S + s;
+      dump.stride = (size_t)a.rc.total_rays * S * 128;
+      dump.act = a.out.jac_act + pidx * 128 + 64 * hh;
+      dump.pe = a.out.jac_pe + pidx * 64 + 32 * hh;
+      if (hh == 0 && a.out.foot_idx != nullptr) {
+        const int tex0 = b * a.rc.gmap.height * a.rc.gmap.width;
+        const int st_ = a.rc.gmap.stride;
+        int* fi = a.out.foot_idx + pidx * 4;
+        fi[0] = tex0 + g.t00 / st_;
+        fi[1] = tex0 + g.t01 / st_;
+        fi[2] = tex0 + g.t10 / st_;
+        fi[3] = tex0 + g.t11 / st_;
+        float* fw = a.out.foot_w + pidx * 4;
+        fw[0] = g.w00;
+        fw[1] = g.w01;
+        fw[2] = g.w10;
+        fw[3] = g.w11;
+      }
+    }
+    decoder_tile<JKIND, PREC, DUMP>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac, dump);
     const float w = tile_weights(end - start, o.sigma, valid, j, carry);
     if (valid) {
       acc_w += w;
@@ -1010,6 +1033,11 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.out = *out;
   hipStream_t s = (hipStream_t)stream;
   const int n = a.rc.total_rays;
+  if (out->jac_act != nullptr) {  // training forward: dump the Jacobian head's activations for the backward pass
+    if (jacobian_kind != NJF_JACOBIAN_MLP || !out->jac_pe) return NJF_E_MODE;
+    if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<1, PREC_F16X2, true>, a, n, s);
+    return launch_fused(render_kernel<1, PREC_F32, true>, a, n, s);
+  }
   if (precision == NJF_PRECISION_F16X2) {
     if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F16X2>, a, n, s);
     if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F16X2>, a, n, s);

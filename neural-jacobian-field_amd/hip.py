@@ -68,7 +68,7 @@ class FeatureMap(C.Structure):
 class RenderOutputs(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "rgb", "depth", "step_minmax", "flow", "pos", "pos_warped", "action_features",
-        "weights", "density", "color", "sample_flow", "jacobian")]
+        "weights", "density", "color", "sample_flow", "jacobian", "jac_act", "jac_pe", "foot_idx", "foot_w")]
 
 
 _lib = None
@@ -242,7 +242,13 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     rays_per_batch = origins.shape[1]
     out = RenderOutputs()
     for name, _ in RenderOutputs._fields_:
-        setattr(out, name, _ptr(outputs.get(name), name))
+        t = outputs.get(name)
+        if name == "foot_idx" and t is not None:  # the only non-float output
+            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+                raise ValueError("njf_hip: foot_idx must be a contiguous int32 device tensor")
+            setattr(out, name, t.data_ptr())
+        else:
+            setattr(out, name, _ptr(t, name))
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS
     with_j = jacobian_kind != JACOBIAN_NONE

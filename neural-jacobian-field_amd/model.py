@@ -207,7 +207,8 @@ class Model(nn.Module):
 
     # ---- fused forward -------------------------------------------------------------------
     def _fused_render(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
-                      features: torch.Tensor, want_lists: bool, want_vis: bool, want_samples: bool):
+                      features: torch.Tensor, want_lists: bool, want_vis: bool, want_samples: bool,
+                      dump_jacobian: bool = False):
         enc = PixelEncoding(features=features, extrinsics=camera_input.ctxt_extrinsics,
                             intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action)
         ray_bundle = self.compute_ray_bundle(rendering_input)
@@ -231,6 +232,14 @@ class Model(nn.Module):
         if want_samples:
             outs["density"] = torch.empty(b, r, s, 1, **f32)
             outs["jacobian"] = torch.empty(b, r, s, a3, **f32)
+        if dump_jacobian:  # inputs of the Jacobian head's backward pass (training.py)
+            pts = b * r * s
+            outs["weights"] = outs.get("weights", torch.empty(b, r, s, **f32))
+            outs["pos_warped"] = outs.get("pos_warped", torch.empty(b, r, 3, **f32))
+            outs["jac_act"] = torch.empty(11, pts, 128, **f32)
+            outs["jac_pe"] = torch.empty(pts, 64, **f32)
+            outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
+            outs["foot_w"] = torch.empty(pts, 4, **f32)
         w, bd, bc, bj = self.decoder.packed()
         fmap = hip.make_feature_map(self.decoder.hoisted_map(features))
         cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
@@ -243,15 +252,39 @@ class Model(nn.Module):
                                     max=outs["step_minmax"][..., 1].max())
         return outs, bins, weights_list, bins_list, ray_bundle
 
-    @torch.no_grad()
     def forward(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
                 compute_vis_features: bool = False) -> ModelOutput:
-        """model.py:316-396."""
-        features = self.encoder.forward(camera_input.input_image)
-        outs, bins, weights_list, bins_list, ray_bundle = self._fused_render(
-            camera_input, rendering_input, robot_input, features, want_lists=self.training, want_vis=compute_vis_features,
-            want_samples=False)
-        out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=outs["flow"]), None, None)
+        """model.py:316-396.  With gradients enabled and trainable parameters (reference action mode: only the
+        Jacobian head, model_wrapper.py:75-85) ``optical_flow`` carries an autograd graph (training.py); every other
+        output, and every call under ``torch.no_grad()`` / with frozen parameters, is a plain inference pass."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_action_grad(camera_input, rendering_input, robot_input, compute_vis_features)
+        return self._forward_inference(camera_input, rendering_input, robot_input, compute_vis_features)
+
+    def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
+        from . import training
+        jparams = training.check_action_mode(self)
+        with torch.no_grad():
+            features = self.encoder.forward(camera_input.input_image)
+        box = {}
+
+        def run():
+            with torch.no_grad():
+                outs, bins, wl, bl, rb = self._fused_render(camera_input, rendering_input, robot_input, features,
+                                                            want_lists=self.training, want_vis=True, want_samples=False,
+                                                            dump_jacobian=True)
+            box.update(outs=outs, bins=bins, weights_list=wl, bins_list=bl, ray_bundle=rb)
+            return outs
+
+        project = lambda x: self._project(x, camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
+        flow = training.ActionFlowFunction.apply(run, project, robot_input.robot_action.detach(), features, *jparams)
+        outs = box["outs"]
+        out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=flow), None, None)
+        self._attach_optional_outputs(out, outs, box["bins"], box["weights_list"], box["bins_list"], box["ray_bundle"],
+                                      compute_vis_features)
+        return out
+
+    def _attach_optional_outputs(self, out, outs, bins, weights_list, bins_list, ray_bundle, compute_vis_features):
         if self.training:
             weights_list.append(outs["weights"][..., None])
             bins_list.append(bins)
@@ -262,6 +295,16 @@ class Model(nn.Module):
             out.vis_output = ModelVisOutput(
                 action_features=outs["action_features"], steps=((smp.starts + smp.ends) / 2).squeeze(-1),
                 weights=outs["weights"], ray_positions=outs["pos"], ray_positions_warped=outs["pos_warped"])
+
+    @torch.no_grad()
+    def _forward_inference(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
+                           compute_vis_features: bool = False) -> ModelOutput:
+        features = self.encoder.forward(camera_input.input_image)
+        outs, bins, weights_list, bins_list, ray_bundle = self._fused_render(
+            camera_input, rendering_input, robot_input, features, want_lists=self.training, want_vis=compute_vis_features,
+            want_samples=False)
+        out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=outs["flow"]), None, None)
+        self._attach_optional_outputs(out, outs, bins, weights_list, bins_list, ray_bundle, compute_vis_features)
         return out
 
     # ---- inference helpers (model.py:398-525) -----------------------------------------------

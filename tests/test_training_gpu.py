@@ -1,0 +1,106 @@
+"""Action-mode training: gradients of the flow loss w.r.t. the Jacobian head (HIP forward + dumped activations +
+library-GEMM backward) against autograd of the CPU oracle.  Run with -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def setup():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    g.build()
+    import parity_harness as ph
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    dev = torch.device("cuda:0")
+    B, H, W, R, S = 2, 16, 16, 40, 32
+    case = ph.make_case(B, H, W, R, 8, seed=4)
+    full = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", 8), seed=4)
+    full.update(case["params"])  # decoder / proposal weights of the case + a seeded encoder
+    model = Model(model_cfg_from_dict({"action_dim": 8, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                                       "action_decoder": {"name": "jacobian_mlp"}}))
+    model.load_state_dict(full, strict=True)
+    model.to(dev).eval()
+    # reference action mode: only the Jacobian head trains (models/model_wrapper.py:75-85)
+    model.decoder.freeze_non_action_parameters()
+    for n, p in model.named_parameters():
+        if "decoder" not in n:
+            p.requires_grad = False
+    g2 = torch.Generator().manual_seed(9)
+    image = torch.rand(B, 3, H, W, generator=g2)
+    target = torch.randn(B, R, 2, generator=g2) * 3
+    c = case["cams"]
+    d = lambda t: t.to(dev)
+    cam = CameraInput(d(image), d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+    rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
+    rob = RobotInput(d(case["action"]))
+    return dict(model=model, case=case, full=full, image=image, target=target, cam=cam, rin=rin, rob=rob, dev=dev, S=S)
+
+
+def test_action_mode_gradients_match_oracle_autograd(setup):
+    import njf_oracle as orc
+    import parity_harness as ph
+    from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
+    s = setup
+    model, case, dev = s["model"], s["case"], s["dev"]
+    out = model.forward(s["cam"], s["rin"], s["rob"])
+    assert out.standard_output.optical_flow.requires_grad and not out.standard_output.rgb.requires_grad
+    loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))
+    loss.backward()
+    # oracle: same weights, encoder features from the oracle's own encoder, autograd through everything
+    params = {k: v.clone() for k, v in s["full"].items()}
+    for k in params:
+        if k.startswith("decoder.jacobian_head."):
+            params[k].requires_grad_(True)
+    c = case["cams"]
+    ref = orc.model_forward(params, input_image=s["image"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
+                            trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
+                            directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=case["action"],
+                            num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_mlp")
+    ref_loss = orc.flow_loss(ref.optical_flow, s["target"])
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3
+    head = dict(model.decoder.jacobian_head.named_parameters())
+    worst = 0.0
+    for name in JACOBIAN_PARAM_ORDER:
+        g_hip, g_ref = head[name].grad, params["decoder.jacobian_head." + name].grad
+        assert g_hip is not None and torch.isfinite(g_hip).all(), name
+        worst = max(worst, rel(g_hip, g_ref))
+    # bound: sample locations differ by ~1e-6 between the two implementations and feed a 2*pi*512-gain encoding
+    assert worst < 5e-3, worst
+    # frozen parameters received no gradient
+    assert all(p.grad is None for n, p in model.named_parameters() if "jacobian_head" not in n)
+
+
+def test_one_adam_step_reduces_the_flow_loss_and_repacks_weights(setup):
+    s = setup
+    model, dev = s["model"], s["dev"]
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        out = model.forward(s["cam"], s["rin"], s["rob"])
+        loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses        # packed weights are refreshed after every optimiser step
+
+
+def test_perception_mode_backward_is_refused_loudly(setup):
+    model = setup["model"]
+    p = model.decoder.density_head.lin_out.weight
+    p.requires_grad = True
+    try:
+        with pytest.raises(NotImplementedError, match="Jacobian head"):
+            model.forward(setup["cam"], setup["rin"], setup["rob"])
+    finally:
+        p.requires_grad = False
