@@ -933,6 +933,7 @@ static int check_common(const float* origins, const float* directions, int rays_
   if (!cams->ctxt_w2c || !cams->ctxt_k || !cams->z_near || !cams->z_far || !gmap->data) return NJF_E_NULL;
   if (rays_per_batch < 1 || cams->batch < 1 || gmap->height < 1 || gmap->width < 1) return NJF_E_SHAPE;
   if ((long long)rays_per_batch * cams->batch > 0x7fffffffLL / 64) return NJF_E_SHAPE;
+  if ((long long)gmap->height * gmap->width * gmap->stride > 0x7fffffffLL) return NJF_E_SHAPE;  // texel offsets are int32
   return NJF_OK;
 }
 

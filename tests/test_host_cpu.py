@@ -143,8 +143,14 @@ def _gloo_worker(rank, world, port, tmp):
     ref_rgb = torch.nn.functional.mse_loss(rgb, trg)
     ref_flow = 0.01 * torch.nn.functional.mse_loss(flow, tflow)
     ref_depth = torch.clip(depth, mm[..., 0].min(), mm[..., 1].max())
+    # gradient bucket all-reduce == mean of the per-rank gradients
+    lin = torch.nn.Linear(5, 3)
+    for q in lin.parameters():
+        q.grad = torch.full_like(q, float(rank + 1))
+    par.allreduce_gradients(lin.parameters())
+    grads_ok = all(torch.allclose(q.grad, torch.full_like(q, (1 + world) / 2)) for q in lin.parameters())
     ok = (abs(losses["loss/rgb"] - ref_rgb) < 1e-6 and abs(losses["loss/flow_loss"] - ref_flow) < 1e-6
-          and torch.equal(frame, ref_depth))
+          and torch.equal(frame, ref_depth) and grads_ok)
     open(os.path.join(tmp, f"ok{rank}"), "w").write(str(bool(ok)))
     dist.destroy_process_group()
 

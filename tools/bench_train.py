@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Action-mode training-step timing (not the headline metric): reference batch shape (7 scenes x 256 rays,
+configurations/config.yaml:18-20) with the benchmark's 64+64 samples, encoder included, forward + backward + Adam."""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import parity_harness as ph
+from neural_jacobian_field_amd import synthetic
+from neural_jacobian_field_amd.config import model_cfg_from_dict
+from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+
+dev = torch.device("cuda:0")
+B, H, W, R, S = 7, 256, 256, 256, 64
+case = ph.make_case(B, H, W, R, 8, seed=0)
+model = Model(model_cfg_from_dict({"action_dim": 8, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                                   "action_decoder": {"name": "jacobian_mlp"}}))
+sd = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", 8), seed=0)
+model.load_state_dict(sd)
+model.to(dev).train()
+model.encoder.eval()
+model.decoder.freeze_non_action_parameters()
+for n, p in model.named_parameters():
+    if "decoder" not in n:
+        p.requires_grad = False
+opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-5)
+c = case["cams"]; d = lambda t: t.to(dev)
+cam = CameraInput(d(torch.rand(B, 3, H, W)), d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
+rob = RobotInput(d(case["action"]))
+target = d(torch.randn(B, R, 2))
+
+def step(i):
+    model.step_before_iter(i)
+    opt.zero_grad(set_to_none=True)
+    out = model.forward(cam, rin, rob)
+    loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, target)
+    loss.backward()
+    opt.step()
+    model.step_after_iter(i)
+    return loss
+
+for i in range(3):
+    step(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+N = 10
+for i in range(N):
+    step(3 + i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+print(json.dumps({"training_step_ms": round(1e3 * dt, 2), "rays_per_step": B * R, "samples": f"{S}+{S}",
+                  "train_rays_per_s": round(B * R / dt, 1), "mode": "action (Jacobian head only), encoder fwd included"}))
