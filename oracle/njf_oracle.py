@@ -645,3 +645,15 @@ def ds_nerf_depth_loss(weights, termination_depth, steps, lengths, sigma) -> Ten
     mask = termination_depth > 0
     loss = -torch.log(weights + 1.0e-7) * torch.exp(-((steps - termination_depth[..., None, :]) ** 2) / (2 * sigma)) * lengths
     return torch.mean(loss.sum(-2) * mask)
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE.json config 0 ("C1", PR1 plumbing reference): the 2D tutorial model's flow composition
+# --------------------------------------------------------------------------------------
+def flow_from_jacobian_2d(jacobian_raw: Tensor, cmd: Tensor, command_dim: int, spatial_dim: int) -> Tensor:
+    """project/jacobian/models/jacobian_models/unet_jacobian.py:38-66: the UNet output
+    [B, command_dim*spatial_dim, H, W] viewed command-major, contracted with the command [B, command_dim]
+    -> per-pixel flow [B, spatial_dim, H, W].  (The UNet itself is a conv net on MIOpen/CPU: out of scope.)"""
+    b, _, h, w = jacobian_raw.shape
+    jac = jacobian_raw.reshape(b, command_dim, spatial_dim, h, w)
+    return torch.einsum("bcshw,bc->bshw", jac, cmd)

@@ -372,5 +372,22 @@ def main():
     save("losses", weights=wts, depth_target=depth_t, steps=c_steps, lengths=rs.ends - rs.starts, depth_loss=dl)
 
 
+def config1_plumbing():
+    """BASELINE.json config 0/C1: the 2D tutorial model's CPU plumbing -- UnetJacobianField.forward =
+    UNet -> rearrange -> einsum with the command (project/jacobian/models/jacobian_models/unet_jacobian.py:38-66)."""
+    import importlib.util
+    pkg = types.ModuleType("jacobian"); pkg.__path__ = [os.path.join(REF, "jacobian")]; sys.modules["jacobian"] = pkg
+    mods = types.ModuleType("jacobian.models"); mods.__path__ = [os.path.join(REF, "jacobian", "models")]
+    sys.modules["jacobian.models"] = mods  # bypass jacobian/models/__init__.py (imports wandb)
+    from jacobian.models.jacobian_models.unet_jacobian import UnetJacobianField, UnetJacobianFieldCfg
+    torch.manual_seed(7)
+    net = UnetJacobianField(UnetJacobianFieldCfg(command_dim=2, spatial_dim=2)).eval()
+    img, cmd = rand(40, 1, 3, 128, 128), randn(41, 1, 2)
+    with torch.no_grad():
+        out = net(img, cmd)
+    save("config1_unet2d", jacobian=out.jacobian, cmd=cmd, flow=out.flow)
+
+
 if __name__ == "__main__":
     main()
+    config1_plumbing()

@@ -1,0 +1,59 @@
+"""CPU property tests of the oracle (hypothesis), and the config-0 plumbing fixture.  No GPU needed."""
+import torch
+from hypothesis import given, settings, strategies as st
+
+import njf_oracle as orc
+
+torch.set_num_threads(1)
+
+
+def test_config1_unet2d_plumbing(golden):
+    g = golden("config1_unet2d")
+    jac = g["jacobian"]                                   # [1, 2, 2, 128, 128] (command, spatial)
+    flow = orc.flow_from_jacobian_2d(jac.reshape(1, 4, 128, 128), g["cmd"], 2, 2)
+    assert torch.equal(flow, g["flow"])
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 5), st.integers(1, 70), st.integers(0, 2 ** 31 - 1), st.floats(0.0, 3.0))
+def test_alpha_weights_properties(rays, samples, seed, log_scale):
+    gen = torch.Generator().manual_seed(seed)
+    edges = torch.sort(torch.rand(rays, samples + 1, generator=gen) * 9.5 + 0.5, -1).values
+    deltas = (edges[:, 1:] - edges[:, :-1])[..., None]
+    dens = torch.exp(log_scale * torch.randn(rays, samples, 1, generator=gen))
+    w = orc.alpha_weights(deltas, dens)
+    assert (w >= 0).all() and (w.sum(-2) <= 1 + 1e-5).all()          # never more than full opacity
+    # transmittance in front of each sample is non-increasing along the ray
+    ds = deltas * dens
+    trans = torch.exp(-torch.cumsum(torch.cat([torch.zeros(rays, 1, 1), ds[:, :-1]], 1), 1))
+    assert (trans[:, 1:] <= trans[:, :-1] + 1e-7).all()
+    # opaque limit: a huge density in the first bin takes (almost) all the weight
+    dens2 = dens.clone(); dens2[:, 0] = 1e6
+    assert (orc.alpha_weights(deltas, dens2)[:, 0, 0] > 0.99).all() or (deltas[:, 0, 0] < 1e-5).any()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 4), st.integers(1, 64), st.integers(1, 80), st.integers(0, 2 ** 31 - 1), st.booleans())
+def test_pdf_resample_properties(rays, s_in, s_out, seed, zero_weights):
+    gen = torch.Generator().manual_seed(seed)
+    o = torch.zeros(rays, 3); d = torch.zeros(rays, 3); d[:, 2] = 1.0
+    near, far = torch.full((rays, 1), 0.5), torch.full((rays, 1), 10.0)
+    prev = orc.uniform_samples(o, d, near, far, s_in)
+    w = torch.zeros(rays, s_in, 1) if zero_weights else torch.rand(rays, s_in, 1, generator=gen) ** 4
+    new = orc.pdf_resample(prev, w, s_out)
+    bins = torch.cat([new.spacing_starts[..., 0], new.spacing_ends[..., -1:, 0]], -1)
+    assert bins.shape == (rays, s_out + 1)
+    assert (bins >= 0).all() and (bins <= 1).all()                    # stays inside the spacing domain
+    assert (bins[:, 1:] >= bins[:, :-1] - 1e-7).all()                 # sorted
+    assert (new.starts >= 0.5 - 1e-5).all() and (new.ends <= 10 + 1e-5).all()
+    if zero_weights:  # uniform pdf -> (almost) uniform bins
+        ref = (torch.arange(s_out + 1) + 0.5) / (s_out + 1)
+        assert (bins - ref).abs().max() < 1e-5
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1), st.integers(0, 1000), st.integers(1, 2000), st.floats(1.5, 50.0))
+def test_anneal_schedule_is_monotone_bias(seed, step, max_iters, slope):
+    a0, a1 = orc.anneal_value(step, max_iters, slope), orc.anneal_value(step + 1, max_iters, slope)
+    assert 0.0 <= a0 <= 1.0 and a1 >= a0 - 1e-12
+    assert orc.anneal_value(0, max_iters, slope) == 0.0 and abs(orc.anneal_value(max_iters, max_iters, slope) - 1.0) < 1e-12
