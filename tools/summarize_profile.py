@@ -23,7 +23,8 @@ os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
-KERNELS = {"render_kernel<1": "render", "proposal_kernel": "proposal", "project_kernel": "project"}
+PCODE = 1 if prec == "f16x2" else 0  # bench.py runs both precisions in one process: pick this one's instantiations
+KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PCODE}>": "proposal", "project_kernel": "project"}
 agg = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"{src}/pmc*/*/*_counter_collection.csv"):
