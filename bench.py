@@ -57,6 +57,7 @@ def parse():
 
 
 def cpu_baseline(case, sample_rays: int):
+    # the ONLY place bench.py touches oracle/: the reported CPU baseline (never the thing measured as `value`)
     """Time the CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the SAME
     workload: `sample_rays` rays of the 256x256 frame, 64+64 samples, chunked at 2048 rays exactly as
     Model.patch_render does (models/model.py:533)."""
@@ -111,30 +112,30 @@ def main():
         entry.build()
     if dist is not None:
         dist.barrier()
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))  # only make_case (input synthesis) + cpu_baseline use it
-    import parity_harness as ph
+    from neural_jacobian_field_amd import geometry, hip, synthetic
     from neural_jacobian_field_amd.renderer import FusedRenderer
 
-    # ---- synthetic frame (seeded per rank: every rank renders its own image) -------------------
+    # ---- synthetic frame: seeded weights/cameras replicated on every rank (data parallel), a per-rank
+    # feature map (each rank renders its own image); rays come from the HIP ray-generation kernel -------------------
     HH, WW, BB, SS = args.height, args.width, args.batch, args.samples
-    case = ph.make_case(BB, HH, WW, None, ACTION_DIM, seed=0)  # weights/cameras replicated on every rank (data parallel)
-    from neural_jacobian_field_amd import synthetic
-    case["feats"] = synthetic.synthetic_features(BB, HH, WW, seed=1 + rank)  # ... each rank renders its own image
-    cams = case["cams"]
     dev = lambda t: t.to(device)
-    from neural_jacobian_field_amd import hip
+    params = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", ACTION_DIM, with_encoder=False), seed=0)
+    cams = synthetic.synthetic_cameras(BB)
+    feats_cpu = synthetic.synthetic_features(BB, HH, WW, seed=1 + rank)
+    action_cpu = synthetic.synthetic_action(BB, ACTION_DIM, seed=2)
+    ctxt_c2w, ctxt_k, trgt_c2w = dev(cams["ctxt_c2w"]), dev(cams["ctxt_k_norm"]), dev(cams["trgt_c2w"])
+    z_near, z_far, action = dev(cams["z_near"]), dev(cams["z_far"]), dev(action_cpu)
+    origins, directions, _ = geometry.full_frame_rays(HH, WW, dev(cams["trgt_k_norm"]), trgt_c2w)
+    k_pix = geometry.denormalize_intrinsics(dev(cams["trgt_k_norm"]), WW, HH)
+    ctxt_w2c, trgt_w2c = torch.linalg.inv(ctxt_c2w), torch.linalg.inv(trgt_c2w)
+    feats = dev(feats_cpu)
     precision = args.precision or hip.DEFAULT_PRECISION
-    dev_params = {k: dev(v) for k, v in case["params"].items()}
+    dev_params = {k: dev(v) for k, v in params.items()}
     renderers = {}
     for prec in ("f16x2", "f32"):
         renderers[prec] = FusedRenderer(device, 1, ACTION_DIM, precision=prec)
         renderers[prec].load_weights(dev_params)
     fr = renderers[precision]
-    feats = dev(case["feats"])
-    origins, directions = dev(case["origins"]), dev(case["directions"])
-    ctxt_w2c, trgt_w2c = dev(torch.inverse(cams["ctxt_c2w"])), dev(torch.inverse(cams["trgt_c2w"]))
-    ctxt_c2w, ctxt_k, trgt_c2w = dev(cams["ctxt_c2w"]), dev(cams["ctxt_k_norm"]), dev(cams["trgt_c2w"])
-    z_near, z_far, k_pix, action = dev(cams["z_near"]), dev(cams["z_far"]), dev(case["k_pix"]), dev(case["action"])
     g = torch.Generator().manual_seed(100 + rank)
     trgt_rgb = dev(torch.rand(BB, HH * WW, 3, generator=g))
     trgt_flow = dev(torch.randn(BB, HH * WW, 2, generator=g))
@@ -231,6 +232,8 @@ def main():
                                   "render_kernel_ms": round(alt_render, 3), "roofline_achieved_tflops": round(alt_ach, 2),
                                   "roofline_peak_tflops": PEAK_TFLOPS[alt], "roofline_frac": round(alt_ach / PEAK_TFLOPS[alt], 4)}
         if world == 1 and not args.no_cpu_baseline and (BB, HH, WW, SS) == (1, 256, 256, 64):
+            case = {"params": params, "feats": feats_cpu, "cams": cams, "origins": origins.cpu(), "directions": directions.cpu(),
+                    "k_pix": k_pix.cpu(), "action": action_cpu}
             out["cpu_baseline"] = cpu_baseline(case, args.cpu_sample_rays)
         import ctypes
         ctypes.CDLL(None).fflush(None)  # anything native libraries buffered on stdout goes out BEFORE the JSON line

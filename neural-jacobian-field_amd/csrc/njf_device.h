@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ReLU as one integer max on the bit pattern (negative floats are negative ints; -0.0 -> +0.0; NaN passes through):
+// avoids the canonicalising v_max_f32 x,x that fmaxf() emits in front of every v_max_f32.
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -122,7 +126,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float b = in[KB0 + kb][q * 4 + e];
-          if (RELU) b = fmaxf(b, 0.f);
+          if (RELU) b = relu_bits(b);
 #pragma unroll
           for (int m = 0; m < MBO; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][e], b, out[m], 0, 0, 0);
         }
@@ -140,7 +144,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float x = in[KB0][i];
-      if (RELU) x = fmaxf(x, 0.f);
+      if (RELU) x = relu_bits(x);
       const _Float16 h = (_Float16)x;
       bh[i] = h;
       bl[i] = (_Float16)(x - (float)h);
@@ -179,7 +183,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
 #pragma unroll
               for (int i = 2 * m; i < 2 * m + 2; ++i) {
                 float x = in[KB0 + kb2][8 * tt2 + i];
-                if (RELU) x = fmaxf(x, 0.f);
+                if (RELU) x = relu_bits(x);
 #ifdef NJF_ABLATE_SPLIT  // experiment builds only: no hi/lo conversion work
                 nh[i] = (_Float16)1.0f;
                 nl[i] = (_Float16)0.0f;
@@ -213,7 +217,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             float x = in[KB0 + kb2][8 * tt2 + i];
-            if (RELU) x = fmaxf(x, 0.f);
+            if (RELU) x = relu_bits(x);
             const _Float16 h = (_Float16)x;
             nh[i] = h;
             nl[i] = (_Float16)(x - (float)h);

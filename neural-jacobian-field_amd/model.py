@@ -258,7 +258,16 @@ class Model(nn.Module):
         Jacobian head, model_wrapper.py:75-85) ``optical_flow`` carries an autograd graph (training.py); every other
         output, and every call under ``torch.no_grad()`` / with frozen parameters, is a plain inference pass."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._forward_action_grad(camera_input, rendering_input, robot_input, compute_vis_features)
+            from . import training
+            if training.is_action_mode(self):
+                return self._forward_action_grad(camera_input, rendering_input, robot_input, compute_vis_features)
+            # any other trainable set: the values are computed, and back-propagating through them raises
+            out = self._forward_inference(camera_input, rendering_input, robot_input, compute_vis_features)
+            anchor = next(p for p in self.parameters() if p.requires_grad)
+            so = out.standard_output
+            so.rgb, so.depth, so.optical_flow = (training.RefuseBackward.apply(t, anchor, training.PERCEPTION_MESSAGE)
+                                                 for t in (so.rgb, so.depth, so.optical_flow))
+            return out
         return self._forward_inference(camera_input, rendering_input, robot_input, compute_vis_features)
 
     def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:

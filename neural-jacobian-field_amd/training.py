@@ -92,6 +92,31 @@ class ActionFlowFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads[k] for k in JACOBIAN_PARAM_ORDER)
 
 
+class RefuseBackward(torch.autograd.Function):
+    """Identity whose backward raises: attached to the outputs of a forward pass whose trainable set the fused path
+    cannot differentiate, so inference-style calls work and any attempt to back-propagate fails loudly."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, anchor: torch.Tensor, message: str):
+        ctx.message = message
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError(ctx.message)
+
+
+def is_action_mode(model) -> bool:
+    names = trainable_names(model)
+    return (bool(names) and all(n.startswith("decoder.jacobian_head.") for n in names)
+            and model.cfg.action_decoder.name == "jacobian_mlp")
+
+
+PERCEPTION_MESSAGE = ("the fused HIP path differentiates only the Jacobian head of a jacobian_mlp decoder (reference action "
+                      "mode, ModelWrapper.freeze_parameters); gradients w.r.t. other parameters (perception mode, "
+                      "jacobian_transformer) are not implemented -- SURVEY.md section 8f #2")
+
+
 def trainable_names(module: torch.nn.Module) -> List[str]:
     return [n for n, q in module.named_parameters() if q.requires_grad]
 

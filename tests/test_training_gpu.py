@@ -101,7 +101,9 @@ def test_perception_mode_backward_is_refused_loudly(setup):
     p = model.decoder.density_head.lin_out.weight
     p.requires_grad = True
     try:
-        with pytest.raises(NotImplementedError, match="Jacobian head"):
-            model.forward(setup["cam"], setup["rin"], setup["rob"])
+        out = model.forward(setup["cam"], setup["rin"], setup["rob"])      # values are fine ...
+        assert torch.isfinite(out.standard_output.rgb).all()
+        with pytest.raises(NotImplementedError, match="Jacobian head"):    # ... back-propagation is refused
+            out.standard_output.rgb.sum().backward()
     finally:
         p.requires_grad = False
