@@ -107,19 +107,22 @@ def _version(module: nn.Module) -> Tuple:
 
 
 class _HoistCache:
-    """One hoisted feature map per (feature tensor, weight version)."""
+    """One hoisted feature map per (feature tensor object, its version counter, weight version).  The cache keeps a
+    reference to the feature tensor: a freed tensor's address can be recycled by the allocator for the next image,
+    so an address-based key would silently serve a stale map."""
 
     def __init__(self):
         self.key = None
+        self.features = None
         self.gmap = None
 
     def get(self, features: torch.Tensor, wversion, wz: torch.Tensor, bz: torch.Tensor) -> torch.Tensor:
-        key = (features.data_ptr(), features._version, tuple(features.shape), wversion)
-        if key != self.key:
+        key = (features._version, tuple(features.shape), wversion)
+        if features is not self.features or key != self.key:
             b, _, hf, wf = features.shape
             gmap = torch.empty(b, hf, wf, wz.shape[1], dtype=torch.float32, device=features.device)
             hip.project_features(features.contiguous(), wz, bz, gmap)
-            self.key, self.gmap = key, gmap
+            self.key, self.features, self.gmap = key, features, gmap
         return self.gmap
 
 

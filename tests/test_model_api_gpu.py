@@ -237,3 +237,22 @@ def test_transformer_model_forward_vs_reference_golden(transformer_model_and_gol
     assert rel(out.standard_output.depth, g["depth"]) < 5e-4
     assert rel(out.standard_output.optical_flow, g["optical_flow"]) < 1e-3
     assert rel(out.vis_output.action_features, g["vis_action_features"]) < 1e-3
+
+
+def test_hoisted_map_cache_is_not_fooled_by_recycled_memory(model_and_golden):
+    """Consecutive forwards on different images (the freed feature tensor's address is typically reused by the
+    allocator) must re-project the feature map."""
+    from neural_jacobian_field_amd.model import CameraInput
+    model, g = model_and_golden
+    cam, rin, rob = _inputs(g)
+    outs = []
+    for k in range(3):
+        img = torch.rand(g["image"].shape, generator=torch.Generator().manual_seed(50 + k)).to(g["image"].device)
+        c = CameraInput(img, cam.ctxt_extrinsics, cam.ctxt_intrinsics, cam.trgt_extrinsics, cam.trgt_intrinsics)
+        with torch.no_grad():
+            outs.append(model.forward(c, rin, rob).standard_output.rgb.clone())
+    assert rel(outs[0], outs[1]) > 1e-4 and rel(outs[1], outs[2]) > 1e-4
+    with torch.no_grad():   # and the same image again reproduces its result
+        img = torch.rand(g["image"].shape, generator=torch.Generator().manual_seed(50)).to(g["image"].device)
+        c = CameraInput(img, cam.ctxt_extrinsics, cam.ctxt_intrinsics, cam.trgt_extrinsics, cam.trgt_intrinsics)
+        assert rel(model.forward(c, rin, rob).standard_output.rgb, outs[0]) < 1e-5
