@@ -130,7 +130,7 @@ def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trg
     b = enc.extrinsics.shape[0]
     dev = enc.extrinsics.device
     zeros = torch.zeros(b, dtype=torch.float32, device=dev)
-    return hip.make_cameras(torch.linalg.inv(enc.extrinsics).contiguous(), enc.intrinsics.contiguous(),
+    return hip.make_cameras(hip.inverse(enc.extrinsics).contiguous(), enc.intrinsics.contiguous(),
                             zeros if z_near is None else z_near.contiguous(),
                             zeros if z_far is None else z_far.contiguous(), trgt_w2c, trgt_k,
                             enc.action.contiguous() if with_action else None, action_dim)

@@ -33,7 +33,7 @@ def get_world_rays_with_z(coordinates_xy: torch.Tensor, intrinsics: torch.Tensor
     origins = torch.empty(b, r, 3, dtype=torch.float32, device=dev)
     directions = torch.empty(b, r, 3, dtype=torch.float32, device=dev)
     z = torch.empty(b, r, 1, dtype=torch.float32, device=dev)
-    hip.generate_rays(coordinates_xy.contiguous(), 0, 0, torch.linalg.inv(intrinsics).contiguous(),
+    hip.generate_rays(coordinates_xy.contiguous(), 0, 0, hip.inverse(intrinsics).contiguous(),
                       cam2world.contiguous(), origins, directions, z)
     return origins, directions, z
 
@@ -53,7 +53,7 @@ def full_frame_rays(height: int, width: int, intrinsics: torch.Tensor, cam2world
     origins = torch.empty(b, r, 3, dtype=torch.float32, device=dev)
     directions = torch.empty(b, r, 3, dtype=torch.float32, device=dev)
     z = torch.empty(b, r, 1, dtype=torch.float32, device=dev)
-    hip.generate_rays(None, height, width, torch.linalg.inv(intrinsics).contiguous(), cam2world.contiguous(),
+    hip.generate_rays(None, height, width, hip.inverse(intrinsics).contiguous(), cam2world.contiguous(),
                       origins, directions, z)
     return origins, directions, z
 

@@ -134,6 +134,12 @@ def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
     return t.data_ptr()
 
 
+def inverse(m: torch.Tensor) -> torch.Tensor:
+    """Batched small-matrix inverse without the host synchronisation of torch.linalg.inv's error check
+    (camera matrices: torch.inverse in rendering/geometry.py:52,64)."""
+    return torch.linalg.inv_ex(m).inverse
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

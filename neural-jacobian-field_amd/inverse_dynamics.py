@@ -1,0 +1,102 @@
+"""Inverse dynamics on a rendered Jacobian field: find the robot command that produces a desired optical flow.
+
+Reference: notebooks/real_world/2_inverse_dynamics.ipynb (cells 26-29) encodes the image once
+(``Model.encode_image``) and then runs 100 Adam steps through ``Model.infer_optical_flow``; the authors note the
+loop becomes real-time "if a least square solver is used" (1_visualize_jacobian_fields.ipynb:448).  Because the scene
+flow is linear in the command (``flow_s = J_s a``), the composited warped point is ``x_bar + M a`` with
+``M = sum_s w_s J_s`` -- exactly the ``action_features`` the fused render kernel already composites -- so one fused
+render of the tracked rays yields everything a Gauss-Newton / least-squares solve needs; the per-iteration work is a
+[2R x A] least-squares problem.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .model import CameraInput, Model, RenderingInput, RobotInput
+
+
+@dataclass
+class FlowLinearization:
+    """Per-ray composited quantities of one fused render: optical_flow(a) = proj(x_bar + M a) - proj(x_bar)."""
+    mean_position: torch.Tensor  # [B,R,3]  sum_s w_s x_s
+    jacobian: torch.Tensor       # [B,R,3,A] sum_s w_s J_s, spatial-major (J viewed (action, spatial) in the reference)
+    trgt_extrinsics: torch.Tensor
+    trgt_intrinsics: torch.Tensor
+
+    def optical_flow(self, action: torch.Tensor) -> torch.Tensor:
+        warped = self.mean_position + torch.einsum("brca,ba->brc", self.jacobian, action)
+        return (Model._project(warped, self.trgt_extrinsics, self.trgt_intrinsics)
+                - Model._project(self.mean_position, self.trgt_extrinsics, self.trgt_intrinsics))
+
+
+@torch.no_grad()
+def linearize_flow(model: Model, camera_input: CameraInput, rendering_input: RenderingInput,
+                   action_dim: Optional[int] = None) -> FlowLinearization:
+    """One fused render (any command: the composited Jacobian does not depend on it)."""
+    a = action_dim or model.cfg.action_dim
+    b = rendering_input.origins.shape[0]
+    zero = torch.zeros(b, a, dtype=torch.float32, device=rendering_input.origins.device)
+    was_training = model.training
+    model.eval()
+    try:
+        out = model._forward_inference(camera_input, rendering_input, RobotInput(zero), compute_vis_features=True)
+    finally:
+        model.train(was_training)
+    feat = out.vis_output.action_features  # [B,R,3A], (action, spatial) order
+    jac = feat.reshape(*feat.shape[:2], a, 3).transpose(-1, -2).contiguous()
+    return FlowLinearization(out.vis_output.ray_positions, jac, camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
+
+
+def _projection_matrix(lin: FlowLinearization) -> torch.Tensor:
+    """[B,3,4] world -> homogeneous pixel matrix K . inv(E)[:3]."""
+    from . import hip
+    return lin.trgt_intrinsics @ hip.inverse(lin.trgt_extrinsics)[:, :3, :]
+
+
+@torch.no_grad()
+def solve_action(lin: FlowLinearization, target_flow: torch.Tensor, init_action: Optional[torch.Tensor] = None,
+                 iterations: int = 20, damping: float = 1e-3, visible_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Levenberg-Marquardt on ``|| optical_flow(a) - target_flow ||^2`` (pixels).
+
+    target_flow [B,R,2], visible_mask [B,R] (the notebook masks the loss with the tracker's visibility) -> [B,A].
+    The only non-linearity is the perspective divide, so for the few-pixel flows of a control step a handful of
+    iterations reach the minimum; each is a [2R x A] normal-equation solve per batch element.  A step is kept only
+    where it lowers the cost (per batch element, no host synchronisation), which keeps large-flow problems stable."""
+    b, r = target_flow.shape[:2]
+    a_dim = lin.jacobian.shape[-1]
+    dev = target_flow.device
+    action = torch.zeros(b, a_dim, dtype=torch.float32, device=dev) if init_action is None else init_action.clone().float()
+    w = torch.ones(b, r, 1, device=dev) if visible_mask is None else visible_mask[..., None].float()
+    proj = _projection_matrix(lin)[:, None]                                   # [B,1,3,4]
+    p_lin, p_off = proj[..., :3].expand(b, r, 3, 3), proj[..., 3]
+    uv0 = Model._project(lin.mean_position, lin.trgt_extrinsics, lin.trgt_intrinsics)
+
+    def evaluate(act):
+        x = lin.mean_position + torch.einsum("brca,ba->brc", lin.jacobian, act)
+        xyw = torch.einsum("brij,brj->bri", p_lin, x) + p_off
+        depth = xyw[..., 2:] + 1e-9
+        uv = xyw[..., :2] / depth
+        res = ((uv - uv0) - target_flow) * w                                   # [B,R,2]
+        return uv, depth, res, res.square().sum((1, 2))
+
+    lam = torch.full((b, 1, 1), damping, device=dev)
+    uv, depth, res, cost = evaluate(action)
+    for _ in range(iterations):
+        duv_dx = (proj[..., :2, :3] - uv[..., None] * proj[..., 2:3, :3]) / depth[..., None]     # [B,R,2,3]
+        jac = ((duv_dx @ lin.jacobian) * w[..., None]).reshape(b, 2 * r, a_dim)
+        h = jac.transpose(1, 2) @ jac
+        diag = torch.diag_embed(torch.diagonal(h, dim1=1, dim2=2).clamp_min(1e-12))
+        step = torch.linalg.solve(h + lam * diag, jac.transpose(1, 2) @ res.reshape(b, 2 * r, 1))[..., 0]
+        cand = action - step
+        uv_c, depth_c, res_c, cost_c = evaluate(cand)
+        better = cost_c < cost                                                # NaN (point behind the camera) -> rejected
+        sel = better[:, None]
+        action = torch.where(sel, cand, action)
+        uv, depth, res = (torch.where(sel[..., None], n, o) for n, o in ((uv_c, uv), (depth_c, depth), (res_c, res)))
+        cost = torch.where(better, cost_c, cost)
+        lam = torch.where(better[:, None, None], lam / 3.0, lam * 4.0).clamp(1e-9, 1e9)
+    return action

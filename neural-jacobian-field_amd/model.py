@@ -190,7 +190,7 @@ class Model(nn.Module):
     @staticmethod
     def _project(points, trgt_extrinsics, trgt_intrinsics):
         hom = torch.cat([points, torch.ones_like(points[..., :1])], dim=-1)
-        cam = torch.einsum("...ij,...j->...i", torch.linalg.inv(trgt_extrinsics)[..., None, :, :], hom)
+        cam = torch.einsum("...ij,...j->...i", hip.inverse(trgt_extrinsics)[..., None, :, :], hom)
         xyw = torch.einsum("...ij,...j->...i", trgt_intrinsics.unsqueeze(1), cam[..., :3])
         return (xyw / (xyw[..., -1:] + 1e-9))[..., :2]
 
@@ -243,7 +243,7 @@ class Model(nn.Module):
         w, bd, bc, bj = self.decoder.packed()
         fmap = hip.make_feature_map(self.decoder.hoisted_map(features))
         cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
-                        torch.linalg.inv(camera_input.trgt_extrinsics).contiguous(),
+                        hip.inverse(camera_input.trgt_extrinsics).contiguous(),
                         camera_input.trgt_intrinsics.contiguous())
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
                            outs, jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)

@@ -131,9 +131,9 @@ class FusedRenderer:
         dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
         origins, directions = origins.contiguous(), directions.contiguous()
         if ctxt_w2c is None:
-            ctxt_w2c = torch.linalg.inv(ctxt_c2w)
+            ctxt_w2c = hip.inverse(ctxt_c2w)
         if trgt_w2c is None and trgt_c2w is not None:
-            trgt_w2c = torch.linalg.inv(trgt_c2w)
+            trgt_w2c = hip.inverse(trgt_c2w)
         cams = hip.make_cameras(ctxt_w2c.contiguous(), ctxt_k_norm.contiguous(), z_near.contiguous(), z_far.contiguous(),
                                 None if trgt_w2c is None else trgt_w2c.contiguous(),
                                 None if trgt_k_pix is None else trgt_k_pix.contiguous(),

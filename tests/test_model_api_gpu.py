@@ -256,3 +256,20 @@ def test_hoisted_map_cache_is_not_fooled_by_recycled_memory(model_and_golden):
         img = torch.rand(g["image"].shape, generator=torch.Generator().manual_seed(50)).to(g["image"].device)
         c = CameraInput(img, cam.ctxt_extrinsics, cam.ctxt_intrinsics, cam.trgt_extrinsics, cam.trgt_intrinsics)
         assert rel(model.forward(c, rin, rob).standard_output.rgb, outs[0]) < 1e-5
+
+
+def test_inverse_dynamics_least_squares(model_and_golden):
+    """one fused render of the tracked rays, then Gauss-Newton.  The linearisation must reproduce
+    Model.forward's optical flow for any command, and the solve must reproduce the command behind a target flow."""
+    from neural_jacobian_field_amd.inverse_dynamics import linearize_flow, solve_action
+    from neural_jacobian_field_amd.model import RobotInput
+    model, g = model_and_golden
+    cam, rin, rob = _inputs(g)
+    lin = linearize_flow(model, cam, rin)
+    fwd = model.forward(cam, rin, rob).standard_output.optical_flow
+    assert rel(lin.optical_flow(rob.robot_action), fwd) < 1e-4
+    # a control-step sized command (few-pixel flow on this 16-pixel image), compared in flow space
+    truth = torch.randn_like(rob.robot_action) * 0.002
+    target = model.forward(cam, rin, RobotInput(truth)).standard_output.optical_flow
+    got = solve_action(lin, target, iterations=20)
+    assert rel(lin.optical_flow(got), target) < 1e-2
