@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 1
+#define NJF_ABI_VERSION 2
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -144,18 +144,30 @@ int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, cons
 int njf_generate_rays(const float* coords, int height, int width, const float* k_inv, const float* c2w,
                       int batch, int rays, float* origins, float* directions, float* z, void* stream);
 
+/* ---- training forward: inputs of one ResnetFC's backward pass (resnet_fc.py:130-154) --------- */
+/* Written per point p (P = points of the launch) when passed to a forward entry point; all four pointers must be
+ * set.  The backward chain itself runs as library GEMMs on these matrices (host side: training.py). */
+typedef struct NjfActivationDump {
+  float* act;      /* [11, P, 128] ReLU'd input of fc_0 / fc_1 of block b at 2b / 2b+1, of lin_out at 10 */
+  float* pe;       /* [P, 64] positional encoding in slot order [sin 30 | x | y | cos 30 | z | 1] */
+  int* foot_idx;   /* [P, 4] texel indices (b*Hf*Wf + y*Wf + x) of the bilinear footprint */
+  float* foot_w;   /* [P, 4] bilinear weights (nw, ne, sw, se) */
+} NjfActivationDump;
+
 /* ---- fused proposal pass: ray_samplers.py:497-552 (level loop body) ------------------------ */
 /* For every ray: sample `s_in` bins (bins_in: [s_in+1] shared, or [B*R, s_in+1] when
  * bins_per_ray), evaluate DensityDecoderMlp.get_density (density_decoder.py:45-71), get_weights
  * (ray_samplers.py:77-101), weights**anneal (:529), PDFSampler (:351-451) with `u` ([s_out+1]
  * shared or per ray) -> bins_out [B*R, s_out+1].  Optional per-sample outputs (may be NULL):
- * weights_out, density_out [B*R, s_in]. */
+ * weights_out, density_out [B*R, s_in]; `dump` (NULL for inference) receives the proposal net's activations
+ * with P = B*R*s_in. */
 int njf_proposal_forward(const float* origins, const float* directions, int rays_per_batch,
                          const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
                          const float* w_pack, const float* b_pack,
                          const float* bins_in, int bins_per_ray, int s_in,
                          const float* u, int u_per_ray, int s_out, float anneal,
-                         float* bins_out, float* weights_out, float* density_out, int precision, void* stream);
+                         float* bins_out, float* weights_out, float* density_out, const NjfActivationDump* dump,
+                         int precision, void* stream);
 
 /* ---- fused final pass: action_decoder_jacobian.py:147-215 + model.py:257-314 --------------- */
 typedef struct NjfRenderOutputs {
@@ -171,11 +183,16 @@ typedef struct NjfRenderOutputs {
   float* color;           /* [B*R,S,3]; NULL to skip */
   float* sample_flow;     /* [B*R,S,3] per-sample 3-D flow; NULL to skip */
   float* jacobian;        /* [B*R,S,3A] per-sample action features (encode_image, model.py:458-495); NULL to skip */
-  /* training forward (jacobian_mlp only): inputs of the backward pass of the Jacobian head; all NULL for inference */
-  float* jac_act;         /* [11, B*R*S, 128] ReLU'd input of fc_0 / fc_1 of block b at 2b / 2b+1, of lin_out at 10 */
-  float* jac_pe;          /* [B*R*S, 64] positional encoding in slot order [sin 30 | x | y | cos 30 | z | 1] */
-  int* foot_idx;          /* [B*R*S, 4] texel indices (b*Hf*Wf + y*Wf + x) of the bilinear footprint; may be NULL */
-  float* foot_w;          /* [B*R*S, 4] bilinear weights (nw, ne, sw, se) */
+  /* training forward, all NULL for inference (P = B*R*S; layouts as in NjfActivationDump).  Either jac_act
+   * (action mode: backward of the jacobian_mlp head) or den_act + col_* (perception mode: backward of the density
+   * net and the colour head) may be set, together with jac_pe / foot_idx / foot_w, which both modes share. */
+  float* jac_act;         /* [11, P, 128] activations of the Jacobian ResnetFC */
+  float* jac_pe;          /* [P, 64] positional encoding (the density and Jacobian nets see the same one) */
+  int* foot_idx;          /* [P, 4] */
+  float* foot_w;          /* [P, 4] */
+  float* den_act;         /* [11, P, 128] activations of the density ResnetFC */
+  float* col_in;          /* [P, 32] colour-head input [geo 15 | 1 | sh 16] (action_decoder_jacobian.py:315-322) */
+  float* col_act;         /* [2, P, 64] ReLU'd outputs of the colour head's first and second layer */
 } NjfRenderOutputs;
 
 /* bins [B*R, S+1] are spacing-domain bin edges in [0,1] (output of njf_proposal_forward or a

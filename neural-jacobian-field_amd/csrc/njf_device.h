@@ -518,11 +518,33 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
   }
 }
 
+// Colour-head dump for the perception-mode backward pass: `in` addresses this lane's 16 inputs ([P][32]: geo15 | 1 |
+// sh16), `act` its 32 ReLU'd hidden values of layer 1 ([2][P][64], `stride` = P*64 floats to layer 2's input).
+struct ColorDump {
+  float* in;
+  float* act;
+  size_t stride;
+};
+
+template <bool DO_RELU>
+__device__ __forceinline__ void dump_vec32(float* __restrict__ dst, const f32x16 (&v)[2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = DO_RELU ? fmaxf(v[m][4 * q + e], 0.f) : v[m][4 * q + e];
+      *(f32x4*)(dst + 16 * m + 4 * q) = o;
+    }
+}
+
 // colour head (action_decoder_jacobian.py:315-322): one chunk [L0 2048 | L1 4096 | L2 2048],
 // bias (LDS): [L1 (64) | L2 (32)].  cin: hh=0 -> [geo(15), 1], hh=1 -> sh(16).
-template <int PREC>
+template <int PREC, bool DUMP = false>
 __device__ __forceinline__ void color_tile(WeightStream& st, const float* __restrict__ bias, const f32x16 (&cin)[1],
-                                           int wave, int lane, f32x16 (&rgb)[1]) {
+                                           int wave, int lane, f32x16 (&rgb)[1],
+                                           ColorDump dump = ColorDump{nullptr, nullptr, 0}) {
   const int hh = lane >> 5;
   const float* wl = stream_step(st, wave, lane);
   f32x16 a[2], b[2];
@@ -533,6 +555,17 @@ __device__ __forceinline__ void color_tile(WeightStream& st, const float* __rest
   mma_chunk<PREC, 2, 2, 0, true, 2>(wl + 2048, lane, a, b);
   bias_init<1, true>(bias + 64, hh, rgb);
   mma_chunk<PREC, 1, 2, 0, true, 2>(wl + 6144, lane, b, rgb);
+  if (DUMP && dump.in != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = cin[0][4 * q + e];
+      *(f32x4*)(dump.in + 4 * q) = o;
+    }
+    dump_vec32<true>(dump.act, a);
+    dump_vec32<true>(dump.act + dump.stride, b);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -423,9 +423,29 @@ struct ProposalArgs {
   float* bins_out;
   float* weights_out;
   float* density_out;
+  NjfActivationDump dump;  // DUMP instantiation only (training forward)
 };
 
-template <int PREC>
+// this lane's share of a point's backward-pass inputs: activations / encoding (both halves), footprint (half 0)
+__device__ __forceinline__ ActDump point_dump(const NjfActivationDump& d, size_t pidx, size_t points, int hh,
+                                              const PointGeom& g, int tex0, int texel_stride) {
+  ActDump dump{d.act + pidx * 128 + 64 * hh, d.pe + pidx * 64 + 32 * hh, points * 128};
+  if (hh == 0 && d.foot_idx != nullptr) {
+    int* fi = d.foot_idx + pidx * 4;
+    fi[0] = tex0 + g.t00 / texel_stride;
+    fi[1] = tex0 + g.t01 / texel_stride;
+    fi[2] = tex0 + g.t10 / texel_stride;
+    fi[3] = tex0 + g.t11 / texel_stride;
+    float* fw = d.foot_w + pidx * 4;
+    fw[0] = g.w00;
+    fw[1] = g.w01;
+    fw[2] = g.w10;
+    fw[3] = g.w11;
+  }
+  return dump;
+}
+
+template <int PREC, bool DUMP = false>
 __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -468,7 +488,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     f32x16 out[1];
-    resnet_tile<PREC>(st, bias, gz, g, pe, wave, lane, out);
+    ActDump dump{nullptr, nullptr, 0};
+    if (DUMP && valid && ray_ok)
+      dump = point_dump(a.dump, (size_t)ray * a.s_in + s, (size_t)a.rc.total_rays * a.s_in, hh, g,
+                        b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
+    resnet_tile<PREC, DUMP>(st, bias, gz, g, pe, wave, lane, out, dump);
     const float pre = __shfl(out[0][0], j, 64);
     const float sigma = expf(pre - 1.0f);
     const float w = tile_weights(end - start, sigma, valid, j, carry);
@@ -498,18 +522,21 @@ struct TileOut {
 
 // bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian head (MLP 1312 / transformer 800)]
 // JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
-template <int JKIND, int PREC, bool DUMP = false>
+// DUMP: 0 = inference, 1 = dump the Jacobian ResnetFC (action-mode training), 2 = dump the density ResnetFC and the
+// colour head (perception-mode training); `dump` addresses the dumped net, `cdump` the colour head.
+template <int JKIND, int PREC, int DUMP = 0>
 __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __restrict__ gz_d,
                                              const float* __restrict__ gz_j, const PointGeom& g, float dirx, float diry,
                                              float dirz, const float* __restrict__ action, int action_dim, int wave,
                                              int lane, TileOut& o, f32x16 (&geo)[1], f32x16 (&jac)[1],
-                                             ActDump dump = ActDump{nullptr, nullptr, 0}) {
+                                             ActDump dump = ActDump{nullptr, nullptr, 0},
+                                             ColorDump cdump = ColorDump{nullptr, nullptr, 0}) {
   const int j = lane & 31, hh = lane >> 5;
   const float* bias = njf_lds + LDS_BIAS;
   {
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    resnet_tile<PREC>(st, bias, gz_d, g, pe, wave, lane, geo);
+    resnet_tile<PREC, DUMP == 2>(st, bias, gz_d, g, pe, wave, lane, geo, dump);
   }
   o.sigma = expf(__shfl(geo[0][15], j, 64) - 1.0f);
   {
@@ -518,7 +545,7 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     f32x16 cin[1], crgb[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) cin[0][r] = hh ? sh[r] : (r < 15 ? geo[0][r] : 1.0f);
-    color_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb);
+    color_tile<PREC, DUMP == 2>(st, bias + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb, cdump);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float x = __shfl(crgb[0][c], j, 64);
@@ -531,7 +558,7 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     if (JKIND == 1)
-      resnet_tile<PREC, DUMP>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac, dump);
+      resnet_tile<PREC, DUMP == 1>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac, dump);
     else transformer_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
     // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
     // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
@@ -571,7 +598,7 @@ struct RenderArgs {
   NjfRenderOutputs out;
 };
 
-template <int JKIND, int PREC, bool DUMP = false>
+template <int JKIND, int PREC, int DUMP = 0>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   constexpr bool WITH_J = JKIND != 0;
   constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
@@ -629,27 +656,14 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     TileOut o;
     f32x16 geo[1], jac[1];
     ActDump dump{nullptr, nullptr, 0};
-    if (DUMP && valid && ray_ok) {
-      const size_t pidx = (size_t)ray * S + s;
-      dump.stride = (size_t)a.rc.total_rays * S * 128;
-      dump.act = a.out.jac_act + pidx * 128 + 64 * hh;
-      dump.pe = a.out.jac_pe + pidx * 64 + 32 * hh;
-      if (hh == 0 && a.out.foot_idx != nullptr) {
-        const int tex0 = b * a.rc.gmap.height * a.rc.gmap.width;
-        const int st_ = a.rc.gmap.stride;
-        int* fi = a.out.foot_idx + pidx * 4;
-        fi[0] = tex0 + g.t00 / st_;
-        fi[1] = tex0 + g.t01 / st_;
-        fi[2] = tex0 + g.t10 / st_;
-        fi[3] = tex0 + g.t11 / st_;
-        float* fw = a.out.foot_w + pidx * 4;
-        fw[0] = g.w00;
-        fw[1] = g.w01;
-        fw[2] = g.w10;
-        fw[3] = g.w11;
-      }
+    ColorDump cdump{nullptr, nullptr, 0};
+    if (DUMP != 0 && valid && ray_ok) {
+      const size_t pidx = (size_t)ray * S + s, points = (size_t)a.rc.total_rays * S;
+      const NjfActivationDump d{DUMP == 1 ? a.out.jac_act : a.out.den_act, a.out.jac_pe, a.out.foot_idx, a.out.foot_w};
+      dump = point_dump(d, pidx, points, hh, g, b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
+      if (DUMP == 2) cdump = ColorDump{a.out.col_in + pidx * 32 + 16 * hh, a.out.col_act + pidx * 64 + 32 * hh, points * 64};
     }
-    decoder_tile<JKIND, PREC, DUMP>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac, dump);
+    decoder_tile<JKIND, PREC, DUMP>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac, dump, cdump);
     const float w = tile_weights(end - start, o.sigma, valid, j, carry);
     if (valid) {
       acc_w += w;
@@ -961,7 +975,8 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
                                     const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
                                     const float* w_pack, const float* b_pack, const float* bins_in, int bins_per_ray,
                                     int s_in, const float* u, int u_per_ray, int s_out, float anneal, float* bins_out,
-                                    float* weights_out, float* density_out, int precision, void* stream) {
+                                    float* weights_out, float* density_out, const NjfActivationDump* dump,
+                                    int precision, void* stream) {
   int rc = check_common(origins, directions, rays_per_batch, cams, gmap);
   if (rc) return rc;
   if (!w_pack || !b_pack || !bins_in || !u || !bins_out) return NJF_E_NULL;
@@ -983,6 +998,14 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   a.bins_out = bins_out;
   a.weights_out = weights_out;
   a.density_out = density_out;
+  a.dump = NjfActivationDump{nullptr, nullptr, nullptr, nullptr};
+  if (dump != nullptr && dump->act != nullptr) {  // training forward: inputs of the proposal net's backward pass
+    if (!dump->pe || !dump->foot_idx || !dump->foot_w) return NJF_E_NULL;
+    a.dump = *dump;
+    if (precision == NJF_PRECISION_F16X2)
+      return launch_fused(proposal_kernel<PREC_F16X2, true>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+    return launch_fused(proposal_kernel<PREC_F32, true>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+  }
   if (precision == NJF_PRECISION_F16X2)
     return launch_fused(proposal_kernel<PREC_F16X2>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
   return launch_fused(proposal_kernel<PREC_F32>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
@@ -1034,10 +1057,22 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.out = *out;
   hipStream_t s = (hipStream_t)stream;
   const int n = a.rc.total_rays;
-  if (out->jac_act != nullptr) {  // training forward: dump the Jacobian head's activations for the backward pass
-    if (jacobian_kind != NJF_JACOBIAN_MLP || !out->jac_pe) return NJF_E_MODE;
-    if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<1, PREC_F16X2, true>, a, n, s);
-    return launch_fused(render_kernel<1, PREC_F32, true>, a, n, s);
+  if (out->jac_act != nullptr) {  // action-mode training forward: dump the Jacobian head for its backward pass
+    if (jacobian_kind != NJF_JACOBIAN_MLP || out->den_act) return NJF_E_MODE;
+    if (!out->jac_pe || !out->foot_idx || !out->foot_w) return NJF_E_NULL;
+    if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<1, PREC_F16X2, 1>, a, n, s);
+    return launch_fused(render_kernel<1, PREC_F32, 1>, a, n, s);
+  }
+  if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
+    if (!out->jac_pe || !out->foot_idx || !out->foot_w || !out->col_in || !out->col_act) return NJF_E_NULL;
+    if (precision == NJF_PRECISION_F16X2) {
+      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F16X2, 2>, a, n, s);
+      if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F16X2, 2>, a, n, s);
+      return launch_fused(render_kernel<0, PREC_F16X2, 2>, a, n, s);
+    }
+    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F32, 2>, a, n, s);
+    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F32, 2>, a, n, s);
+    return launch_fused(render_kernel<0, PREC_F32, 2>, a, n, s);
   }
   if (precision == NJF_PRECISION_F16X2) {
     if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F16X2>, a, n, s);

@@ -68,7 +68,12 @@ class FeatureMap(C.Structure):
 class RenderOutputs(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "rgb", "depth", "step_minmax", "flow", "pos", "pos_warped", "action_features",
-        "weights", "density", "color", "sample_flow", "jacobian", "jac_act", "jac_pe", "foot_idx", "foot_w")]
+        "weights", "density", "color", "sample_flow", "jacobian", "jac_act", "jac_pe", "foot_idx", "foot_w",
+        "den_act", "col_in", "col_act")]
+
+
+class ActivationDump(C.Structure):
+    _fields_ = [("act", _vp), ("pe", _vp), ("foot_idx", _vp), ("foot_w", _vp)]
 
 
 _lib = None
@@ -84,7 +89,8 @@ _SIGNATURES = {
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
-                              _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
+                              _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.POINTER(ActivationDump), C.c_int, _vp],
+                             C.c_int),
     "njf_render_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), C.c_int, _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
@@ -231,14 +237,26 @@ def generate_rays(coords, height, width, k_inv, c2w, origins, directions, z) -> 
                                             _ptr(origins), _ptr(directions), _ptr(z), _stream()))
 
 
+def _int_ptr(t: torch.Tensor) -> int:
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise ValueError("njf_hip: foot_idx must be a contiguous int32 device tensor")
+    return t.data_ptr()
+
+
 def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_offset: int, w_pack, b_pack,
                      bins_in, s_in: int, u, s_out: int, anneal: float, bins_out, weights_out=None,
-                     density_out=None, precision: Optional[str] = None) -> None:
+                     density_out=None, precision: Optional[str] = None,
+                     dump: Optional[Dict[str, torch.Tensor]] = None) -> None:
+    """``dump`` (training forward): tensors act [11,P,128], pe [P,64], foot_idx [P,4] int32, foot_w [P,4]."""
     rays_per_batch = origins.shape[1]
+    dump_ref = None
+    if dump is not None:
+        dump_ref = C.byref(ActivationDump(_ptr(dump["act"]), _ptr(dump["pe"]), _int_ptr(dump["foot_idx"]),
+                                          _ptr(dump["foot_w"])))
     _check(load_library().njf_proposal_forward(
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), gmap_offset,
         _ptr(w_pack), _ptr(b_pack), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u), int(u.dim() > 1), s_out,
-        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), precision_code(precision), _stream()))
+        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), dump_ref, precision_code(precision), _stream()))
 
 
 def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int,
@@ -250,9 +268,7 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     for name, _ in RenderOutputs._fields_:
         t = outputs.get(name)
         if name == "foot_idx" and t is not None:  # the only non-float output
-            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
-                raise ValueError("njf_hip: foot_idx must be a contiguous int32 device tensor")
-            setattr(out, name, t.data_ptr())
+            setattr(out, name, _int_ptr(t))
         else:
             setattr(out, name, _ptr(t, name))
     base = _ptr(w_all, "w_all")

@@ -208,13 +208,15 @@ class Model(nn.Module):
     # ---- fused forward -------------------------------------------------------------------
     def _fused_render(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
                       features: torch.Tensor, want_lists: bool, want_vis: bool, want_samples: bool,
-                      dump_jacobian: bool = False):
+                      dump_jacobian: bool = False, dump_perception: bool = False):
         enc = PixelEncoding(features=features, extrinsics=camera_input.ctxt_extrinsics,
                             intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action)
         ray_bundle = self.compute_ray_bundle(rendering_input)
         self.proposal_sampler.train(self.training)
+        proposal_dumps = [] if dump_perception else None
         bins, weights_list, bins_list = self.proposal_sampler.generate_ray_samples_fused(
-            ray_bundle, list(self.proposal_networks), enc, rendering_input.z_near, rendering_input.z_far, want_lists)
+            ray_bundle, list(self.proposal_networks), enc, rendering_input.z_near, rendering_input.z_far, want_lists,
+            dump_out=proposal_dumps)
         o, d = rendering_input.origins.contiguous(), rendering_input.directions.contiguous()
         b, r = o.shape[:2]
         s = self.cfg.rendering.num_nerf_samples
@@ -240,13 +242,26 @@ class Model(nn.Module):
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
             outs["foot_w"] = torch.empty(pts, 4, **f32)
+        if dump_perception:  # inputs of the density net's and the colour head's backward pass (training.py)
+            pts = b * r * s
+            outs["proposal_dumps"] = proposal_dumps
+            outs["weights"] = outs.get("weights", torch.empty(b, r, s, **f32))
+            outs["density"] = outs.get("density", torch.empty(b, r, s, 1, **f32))
+            outs["color"] = torch.empty(b, r, s, 3, **f32)
+            outs["den_act"] = torch.empty(11, pts, 128, **f32)
+            outs["jac_pe"] = torch.empty(pts, 64, **f32)
+            outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
+            outs["foot_w"] = torch.empty(pts, 4, **f32)
+            outs["col_in"] = torch.empty(pts, 32, **f32)
+            outs["col_act"] = torch.empty(2, pts, 64, **f32)
         w, bd, bc, bj = self.decoder.packed()
         fmap = hip.make_feature_map(self.decoder.hoisted_map(features))
         cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
                         hip.inverse(camera_input.trgt_extrinsics).contiguous(),
                         camera_input.trgt_intrinsics.contiguous())
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
-                           outs, jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
+                           {k: v for k, v in outs.items() if torch.is_tensor(v)},
+                           jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
         # tensor-global clip of model.py:277
         outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
                                     max=outs["step_minmax"][..., 1].max())
@@ -261,14 +276,58 @@ class Model(nn.Module):
             from . import training
             if training.is_action_mode(self):
                 return self._forward_action_grad(camera_input, rendering_input, robot_input, compute_vis_features)
-            # any other trainable set: the values are computed, and back-propagating through them raises
-            out = self._forward_inference(camera_input, rendering_input, robot_input, compute_vis_features)
-            anchor = next(p for p in self.parameters() if p.requires_grad)
-            so = out.standard_output
-            so.rgb, so.depth, so.optical_flow = (training.RefuseBackward.apply(t, anchor, training.PERCEPTION_MESSAGE)
-                                                 for t in (so.rgb, so.depth, so.optical_flow))
-            return out
+            return self._forward_perception_grad(camera_input, rendering_input, robot_input, compute_vis_features)
         return self._forward_inference(camera_input, rendering_input, robot_input, compute_vis_features)
+
+    def _forward_perception_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
+        """Any trainable set other than action mode (reference perception mode trains everything and reads rgb, depth
+        and the per-level weights, model_wrapper.py:117-146).  rgb / depth / weights_list carry autograd graphs back to
+        the encoder, the density and colour heads and the proposal nets; ``optical_flow`` is a value only -- the
+        perception losses never read it -- and refuses back-propagation."""
+        from . import training
+        features = self.encoder.forward(camera_input.input_image)
+        box = {}
+
+        def run():
+            with torch.no_grad():
+                outs, bins, wl, bl, rb = self._fused_render(camera_input, rendering_input, robot_input, features.detach(),
+                                                            want_lists=True, want_vis=compute_vis_features,
+                                                            want_samples=False, dump_perception=True)
+            box.update(outs=outs, bins=bins, bins_list=bl, ray_bundle=rb)
+            return outs
+
+        params = training.perception_params(self)
+        sigma, color, *sigma_prop = training.FieldFunction.apply(run, features, len(self.proposal_networks), *params)
+        outs, ray_bundle = box["outs"], box["ray_bundle"]
+        # compositing of model.py:257-279 on the differentiable fields (O(B R S) elementwise work, left to autograd)
+        smp = ray_bundle.samples_from_bins(box["bins"])
+        weights = self._weights_from_density(smp.deltas, sigma)
+        rgb = torch.sum(weights * color, dim=-2)
+        depth, _ = self.render_depth(weights, smp)
+        anchor = next(p for p in self.parameters() if p.requires_grad)
+        flow = training.RefuseBackward.apply(outs["flow"], anchor, training.PERCEPTION_MESSAGE)
+        out = ModelOutput(ModelStandardOutput(rgb=rgb, depth=depth, optical_flow=flow), None, None)
+        samples_list = [ray_bundle.samples_from_bins(bn) for bn in box["bins_list"]]
+        weights_list = []
+        for lvl_samples, dump, sg in zip(samples_list, outs["proposal_dumps"], sigma_prop):
+            weights_list.append(self._weights_from_density(lvl_samples.deltas, sg if dump["updated"] else sg.detach()))
+        if self.training:
+            out.training_output = ModelTrainingOutput(weights_list=weights_list + [weights],
+                                                      ray_samples_list=samples_list + [smp])
+        if compute_vis_features:
+            out.vis_output = ModelVisOutput(
+                action_features=outs["action_features"], steps=((smp.starts + smp.ends) / 2).squeeze(-1),
+                weights=outs["weights"], ray_positions=outs["pos"], ray_positions_warped=outs["pos_warped"])
+        return out
+
+    @staticmethod
+    def _weights_from_density(deltas: torch.Tensor, densities: torch.Tensor) -> torch.Tensor:
+        """RaySamples.get_weights (ray_samplers.py:77-101) in differentiable torch ops (training graphs only; the
+        inference path composites inside the render kernel)."""
+        ds = torch.where(deltas > 0, deltas * densities, torch.zeros_like(densities))
+        acc = torch.cumsum(ds[..., :-1, :], dim=-2)
+        acc = torch.cat([torch.zeros_like(acc[..., :1, :]), acc], dim=-2)
+        return (1 - torch.exp(-ds)) * torch.exp(-acc)
 
     def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
         from . import training

@@ -214,8 +214,11 @@ class ProposalNetworkSampler(Sampler):
 
     @torch.no_grad()
     def generate_ray_samples_fused(self, ray_bundle: RayBundle, networks: Sequence, pixel_encoding, z_near, z_far,
-                                   want_lists: bool):
-        """Fused route: one ``njf_proposal_forward`` per level.  ``networks`` are DensityDecoderMlp modules."""
+                                   want_lists: bool, dump_out: Optional[list] = None):
+        """Fused route: one ``njf_proposal_forward`` per level.  ``networks`` are DensityDecoderMlp modules.
+        ``dump_out`` (perception-mode training): receives one dict per level with the proposal net's backward-pass
+        inputs (``act``, ``pe``, ``foot_idx``, ``foot_w``), its ``density`` [B,R,S] and ``updated`` -- whether this
+        step trains the proposal nets (the grad / no-grad schedule of ray_samplers.py:512-549)."""
         assert len(networks) == self.num_proposal_network_iterations
         from .decoder import _cameras
 
@@ -225,7 +228,7 @@ class ProposalNetworkSampler(Sampler):
         counts = self._level_counts()
         self.initial_sampler.train(self.training)
         self.pdf_sampler.train(self.training)
-        self._mark_updated()
+        updated = self._mark_updated()
         cams = _cameras(pixel_encoding, False, z_near, z_far)
         bins = self.initial_sampler.spacing_bins(ray_bundle, counts[0], shared_ok=True)
         weights_list, bins_list = [], []
@@ -236,8 +239,17 @@ class ProposalNetworkSampler(Sampler):
             u = self.pdf_sampler.u_values((b, r), s_out, dev, shared_ok=True)
             bins_out = torch.empty(b, r, s_out + 1, dtype=torch.float32, device=dev)
             w_out = torch.empty(b, r, s_in, dtype=torch.float32, device=dev) if want_lists else None
+            dump = sigma = None
+            if dump_out is not None:
+                pts = b * r * s_in
+                sigma = torch.empty(b, r, s_in, dtype=torch.float32, device=dev)
+                dump = {"act": torch.empty(11, pts, 128, dtype=torch.float32, device=dev),
+                        "pe": torch.empty(pts, 64, dtype=torch.float32, device=dev),
+                        "foot_idx": torch.empty(pts, 4, dtype=torch.int32, device=dev),
+                        "foot_w": torch.empty(pts, 4, dtype=torch.float32, device=dev)}
+                dump_out.append({**dump, "density": sigma, "updated": updated})
             hip.proposal_forward(o, d, cams, fmap, 0, w, bias, bins.contiguous(), s_in, u, s_out, self._anneal, bins_out,
-                                 w_out, precision=net.precision)
+                                 w_out, sigma, precision=net.precision, dump=dump)
             if want_lists:
                 weights_list.append(w_out[..., None])
                 bins_list.append(bins if bins.dim() > 1 else bins.expand(b, r, -1))

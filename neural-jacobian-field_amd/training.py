@@ -14,6 +14,7 @@ chain into a HIP kernel is the next step of SURVEY.md section 8f #2; ``jacobian_
 
 from __future__ import annotations
 
+import math
 from typing import Callable, Dict, List, Sequence
 
 import torch
@@ -27,6 +28,51 @@ JACOBIAN_PARAM_ORDER: List[str] = (
 
 # positional-encoding slot -> reference channel (csrc/njf_kernels.hip::pack_source, kind 1); slot 63 is the bias
 _PE_SLOT_TO_CHANNEL = list(range(30)) + [60, 61] + list(range(30, 60)) + [62]
+
+
+def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
+                      foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
+                      d_feats: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+    """Backward pass of one ResnetFC (resnet_fc.py:130-154) from the activations the HIP forward dumped.
+
+    ``p``: the net's parameters by reference name; ``d_out`` [P, d_out]; ``act`` [11,P,128] (ReLU'd layer inputs),
+    ``pe`` [P,64] (slot order), ``foot_idx``/``foot_w`` [P,4] bilinear footprint on the flattened texel grid,
+    ``feats_flat`` [T,512] encoder features, channels last.  Returns the parameter gradients; when ``d_feats`` [T,512]
+    is given, the gradient w.r.t. the encoder features is accumulated into it (grid_sample's input gradient followed
+    by lin_z's, in hoisted order: scatter the [P,128] latent gradient onto the texels, then one GEMM per lin_z)."""
+    grads: Dict[str, torch.Tensor] = {}
+    r_out = act[10]
+    grads["lin_out.weight"] = d_out.t() @ r_out
+    grads["lin_out.bias"] = d_out.sum(0)
+    delta = (d_out @ p["lin_out.weight"]) * (r_out > 0)
+    idx = None
+    for blk in range(4, -1, -1):
+        r0, r1 = act[2 * blk], act[2 * blk + 1]
+        grads[f"blocks.{blk}.fc_1.weight"] = delta.t() @ r1
+        grads[f"blocks.{blk}.fc_1.bias"] = delta.sum(0)
+        d_net = (delta @ p[f"blocks.{blk}.fc_1.weight"]) * (r1 > 0)
+        grads[f"blocks.{blk}.fc_0.weight"] = d_net.t() @ r0
+        grads[f"blocks.{blk}.fc_0.bias"] = d_net.sum(0)
+        delta = delta + (d_net @ p[f"blocks.{blk}.fc_0.weight"]) * (r0 > 0)
+        if blk < 3:  # lin_z[blk](bilinear(F)) was added here
+            if idx is None:
+                idx = foot_idx.long()
+            d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
+            for c in range(4):
+                d_g.index_add_(0, idx[:, c], delta * foot_w[:, c:c + 1])
+            grads[f"lin_z.{blk}.weight"] = d_g.t() @ feats_flat
+            grads[f"lin_z.{blk}.bias"] = delta.sum(0)
+            if d_feats is not None:
+                d_feats.addmm_(d_g, p[f"lin_z.{blk}.weight"])
+    d_in = delta.t() @ pe  # [128, 64] in slot order
+    grads["lin_in.weight"] = d_in.new_zeros(d_in.shape[0], 63).index_copy_(
+        1, torch.tensor(_PE_SLOT_TO_CHANNEL, device=d_in.device), d_in[:, :63])
+    grads["lin_in.bias"] = d_in[:, 63].clone()
+    return grads
+
+
+def _flat_features(features: torch.Tensor) -> torch.Tensor:
+    return features.permute(0, 2, 3, 1).reshape(-1, features.shape[1])
 
 
 class ActionFlowFunction(torch.autograd.Function):
@@ -59,37 +105,111 @@ class ActionFlowFunction(torch.autograd.Function):
             (g_xw,) = torch.autograd.grad(ctx.project(xw), xw, g_flow.contiguous())
         # flow_s = sum_a J[a,:] act[a]  (action_decoder_jacobian.py:128-145)  =>  dJ[s,a,c] = w_s act[a] g_xw[c]
         d_j = torch.einsum("brs,ba,brc->brsac", weights, action, g_xw).reshape(b * r * s, 3 * a)
-        act = outs["jac_act"]  # [11, P, 128]
-        grads: Dict[str, torch.Tensor] = {}
-        r_out = act[10]
-        grads["lin_out.weight"] = d_j.t() @ r_out
-        grads["lin_out.bias"] = d_j.sum(0)
-        delta = (d_j @ p["lin_out.weight"]) * (r_out > 0)
-        feats_flat = None
-        for blk in range(4, -1, -1):
-            r0, r1 = act[2 * blk], act[2 * blk + 1]
-            grads[f"blocks.{blk}.fc_1.weight"] = delta.t() @ r1
-            grads[f"blocks.{blk}.fc_1.bias"] = delta.sum(0)
-            d_net = (delta @ p[f"blocks.{blk}.fc_1.weight"]) * (r1 > 0)
-            grads[f"blocks.{blk}.fc_0.weight"] = d_net.t() @ r0
-            grads[f"blocks.{blk}.fc_0.bias"] = d_net.sum(0)
-            delta = delta + (d_net @ p[f"blocks.{blk}.fc_0.weight"]) * (r0 > 0)
-            if blk < 3:  # lin_z[blk](bilinear(F)) was added here: scatter the gradient onto the texels, then one GEMM
-                if feats_flat is None:
-                    feats_flat = features.permute(0, 2, 3, 1).reshape(-1, features.shape[1])
-                    idx = outs["foot_idx"].long()
-                    fw = outs["foot_w"]
-                d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
-                for c in range(4):
-                    d_g.index_add_(0, idx[:, c], delta * fw[:, c:c + 1])
-                grads[f"lin_z.{blk}.weight"] = d_g.t() @ feats_flat
-                grads[f"lin_z.{blk}.bias"] = delta.sum(0)
-        d_in = delta.t() @ outs["jac_pe"]  # [128, 64] in slot order
-        grads["lin_in.weight"] = d_in[:, :63].new_zeros(d_in.shape[0], 63).index_copy_(
-            1, torch.tensor(_PE_SLOT_TO_CHANNEL, device=d_in.device), d_in[:, :63])
-        grads["lin_in.bias"] = d_in[:, 63].clone()
+        grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"],
+                                  _flat_features(features))
         ctx.outs = None
         return (None, None, None, None) + tuple(grads[k] for k in JACOBIAN_PARAM_ORDER)
+
+
+COLOR_PARAM_ORDER: List[str] = [f"{i}.{wb}" for i in (0, 2, 4) for wb in ("weight", "bias")]
+
+
+def color_head_backward(p: Dict[str, torch.Tensor], d_rgb: torch.Tensor, rgb: torch.Tensor, col_in: torch.Tensor,
+                        col_act: torch.Tensor):
+    """Backward of sigmoid(L4(relu(L2(relu(L0(cat[geo15, sh16])))))) (action_decoder_jacobian.py:315-322) from the
+    dumped ``col_in`` [P,32] = [geo 15 | 1 | sh 16] and ``col_act`` [2,P,64].  Returns (grads, d_geo [P,15])."""
+    grads: Dict[str, torch.Tensor] = {}
+    d3 = d_rgb * rgb * (1.0 - rgb)
+    grads["4.weight"] = d3.t() @ col_act[1]
+    grads["4.bias"] = d3.sum(0)
+    d2 = (d3 @ p["4.weight"]) * (col_act[1] > 0)
+    grads["2.weight"] = d2.t() @ col_act[0]
+    grads["2.bias"] = d2.sum(0)
+    d1 = (d2 @ p["2.weight"]) * (col_act[0] > 0)
+    d_w0 = d1.t() @ col_in                      # [64, 32]: columns 0..14 geo, 15 the folded bias, 16..31 sh
+    grads["0.weight"] = torch.cat([d_w0[:, :15], d_w0[:, 16:]], dim=1)
+    grads["0.bias"] = d_w0[:, 15].clone()
+    return grads, d1 @ p["0.weight"][:, :15]
+
+
+class FieldFunction(torch.autograd.Function):
+    """Perception-mode training (model_wrapper.py:117-146: every parameter trains, the losses read rgb, depth and the
+    per-level weights).  Outputs the per-sample fields the compositing consumes -- final density [B,R,S,1], colour
+    [B,R,S,3] and each proposal level's density [B,R,S_l,1] -- as functions of (encoder features, density head, colour
+    head, proposal nets).  Sample placement is a constant: the reference detaches the resampled bins
+    (ray_samplers.py:446).  Forward = the fused HIP kernels with activation dumps; backward = library GEMMs on the
+    dumps; the compositing between these fields and the losses is left to autograd (it is O(B R S) elementwise work)."""
+
+    @staticmethod
+    def forward(ctx, run: Callable[[], Dict[str, torch.Tensor]], features: torch.Tensor, n_prop: int, *params):
+        outs = run()
+        ctx.outs = outs
+        ctx.features = features
+        ctx.n_prop = n_prop
+        ctx.save_for_backward(*params)
+        ctx.set_materialize_grads(False)
+        b, r, s = outs["weights"].shape
+        # detached aliases: the returned tensors must not be the objects ``ctx.outs`` holds (reference cycle)
+        fields = [outs["density"].detach().reshape(b, r, s, 1), outs["color"].detach().reshape(b, r, s, 3)]
+        fields += [d["density"].detach()[..., None] for d in outs["proposal_dumps"]]
+        return tuple(fields)
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_color, *g_prop):
+        params = ctx.saved_tensors
+        n = len(JACOBIAN_PARAM_ORDER)
+        outs, features = ctx.outs, ctx.features
+        feats_flat = _flat_features(features).detach()
+        d_feats = torch.zeros_like(feats_flat) if ctx.needs_input_grad[1] else None
+        out_grads = [None] * len(params)
+
+        def clamp_exp(sigma):  # trunc_exp backward, activations.py:31-34: g * exp(clamp(x - 1, -15, 15)), sigma = exp(x - 1)
+            return sigma.clamp(min=math.exp(-15.0), max=math.exp(15.0))
+
+        if g_sigma is not None or g_color is not None:
+            pts = outs["density"].numel()
+            den = dict(zip(JACOBIAN_PARAM_ORDER, params[:n]))
+            col = dict(zip(COLOR_PARAM_ORDER, params[n:n + 6]))
+            d_out = torch.zeros(pts, 16, dtype=torch.float32, device=feats_flat.device)
+            if g_color is not None:
+                cgrads, d_geo = color_head_backward(col, g_color.reshape(pts, 3), outs["color"].reshape(pts, 3),
+                                                    outs["col_in"], outs["col_act"])
+                d_out[:, :15] = d_geo
+                for i, k in enumerate(COLOR_PARAM_ORDER):
+                    out_grads[n + i] = cgrads[k]
+            if g_sigma is not None:
+                d_out[:, 15] = g_sigma.reshape(pts) * clamp_exp(outs["density"].reshape(pts))
+            grads = resnetfc_backward(den, d_out, outs["den_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"],
+                                      feats_flat, d_feats)
+            for i, k in enumerate(JACOBIAN_PARAM_ORDER):
+                out_grads[i] = grads[k]
+        for lvl in range(ctx.n_prop):
+            g = g_prop[lvl]
+            if g is None:
+                continue
+            d = outs["proposal_dumps"][lvl]
+            net = dict(zip(JACOBIAN_PARAM_ORDER, params[n + 6 + lvl * n:n + 6 + (lvl + 1) * n]))
+            d_out = (g.reshape(-1) * clamp_exp(d["density"].reshape(-1)))[:, None]
+            grads = resnetfc_backward(net, d_out, d["act"], d["pe"], d["foot_idx"], d["foot_w"], feats_flat, d_feats)
+            for i, k in enumerate(JACOBIAN_PARAM_ORDER):
+                out_grads[n + 6 + lvl * n + i] = grads[k]
+        ctx.outs = None
+        g_features = None
+        if d_feats is not None:
+            bsz, c, hf, wf = features.shape
+            g_features = d_feats.reshape(bsz, hf, wf, c).permute(0, 3, 1, 2)
+        return (None, g_features, None) + tuple(out_grads)
+
+
+def perception_params(model) -> List[torch.Tensor]:
+    """Parameters FieldFunction differentiates, in its order: density head | colour head | proposal nets."""
+    den = dict(model.decoder.density_head.named_parameters())
+    col = dict(model.decoder.color_head.named_parameters())
+    out = [den[k] for k in JACOBIAN_PARAM_ORDER] + [col[k] for k in COLOR_PARAM_ORDER]
+    for net in model.proposal_networks:
+        head = dict(net.density_head.named_parameters())
+        out += [head[k] for k in JACOBIAN_PARAM_ORDER]
+    return out
 
 
 class RefuseBackward(torch.autograd.Function):
@@ -112,9 +232,9 @@ def is_action_mode(model) -> bool:
             and model.cfg.action_decoder.name == "jacobian_mlp")
 
 
-PERCEPTION_MESSAGE = ("the fused HIP path differentiates only the Jacobian head of a jacobian_mlp decoder (reference action "
-                      "mode, ModelWrapper.freeze_parameters); gradients w.r.t. other parameters (perception mode, "
-                      "jacobian_transformer) are not implemented -- SURVEY.md section 8f #2")
+PERCEPTION_MESSAGE = ("optical_flow is differentiable only in the reference's action mode (ModelWrapper.freeze_parameters: "
+                      "just the jacobian_mlp head trainable); with any other trainable set the fused path differentiates "
+                      "rgb, depth and the per-level weights (perception mode) and optical_flow is a value only")
 
 
 def trainable_names(module: torch.nn.Module) -> List[str]:
