@@ -90,6 +90,49 @@ def depth_loss(output: ModelOutput, target: ModelTarget, sigma: float = 0.001) -
     return 0.08 * total
 
 
+_EPS = 1.0e-7
+
+
+def _sdist(ray_samples) -> torch.Tensor:
+    """Spacing-domain bin edges [..., S+1] of a RaySamples."""
+    return torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
+
+
+def _outer_measure(t: torch.Tensor, t_env: torch.Tensor, w_env: torch.Tensor) -> torch.Tensor:
+    """For every interval [t_i, t_i+1): the summed envelope weight of all envelope intervals that can overlap it
+    (mip-NeRF 360, eq. 13's bound)."""
+    cw = torch.cat([torch.zeros_like(w_env[..., :1]), torch.cumsum(w_env, dim=-1)], dim=-1)
+    last = w_env.shape[-1] - 1
+    lo = (torch.searchsorted(t_env[..., :-1].contiguous(), t[..., :-1].contiguous(), right=True) - 1).clamp(0, last)
+    hi = torch.searchsorted(t_env[..., 1:].contiguous(), t[..., 1:].contiguous(), right=True).clamp(0, last)
+    return torch.take_along_dim(cw[..., 1:], hi, dim=-1) - torch.take_along_dim(cw[..., :-1], lo, dim=-1)
+
+
+def interlevel_loss(weights_list, ray_samples_list) -> torch.Tensor:
+    """nerfstudio.model_components.losses.interlevel_loss (imported at model_wrapper.py:12; nerfstudio is absent
+    and un-pinned, so this restates the published algorithm -- mip-NeRF 360 eq. 13: the proposal histogram must
+    upper-bound the final one): sum over proposal levels of mean(max(0, w - bound)^2 / (w + eps)), with the final
+    level's weights and edges detached."""
+    c = _sdist(ray_samples_list[-1]).detach()
+    w = weights_list[-1][..., 0].detach()
+    total = 0.0
+    for smp, wts in zip(ray_samples_list[:-1], weights_list[:-1]):
+        bound = _outer_measure(c, _sdist(smp), wts[..., 0])
+        total = total + torch.mean(torch.clip(w - bound, min=0) ** 2 / (w + _EPS))
+    return total
+
+
+def distortion_loss(weights_list, ray_samples_list) -> torch.Tensor:
+    """nerfstudio.model_components.losses.distortion_loss (mip-NeRF 360 eq. 15) on the final level, in the spacing
+    domain: sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 (t_i+1 - t_i), averaged over rays."""
+    t = _sdist(ray_samples_list[-1])
+    w = weights_list[-1][..., 0]
+    mid = (t[..., 1:] + t[..., :-1]) / 2
+    inter = torch.sum(w * torch.sum(w[..., None, :] * torch.abs(mid[..., :, None] - mid[..., None, :]), dim=-1), dim=-1)
+    intra = torch.sum(w ** 2 * (t[..., 1:] - t[..., :-1]), dim=-1) / 3
+    return torch.mean(inter + intra)
+
+
 class ModelWrapper(torch.nn.Module):
     """State-dict-compatible shell (``model.*`` prefix, ``depth_sigma`` buffer) around ``Model``:
     ``wrapper.load_state_dict(ckpt["state_dict"])`` works as in the notebooks."""
@@ -107,13 +150,28 @@ class ModelWrapper(torch.nn.Module):
                     p.requires_grad = False
 
     def evaluate_losses(self, batch: Dict) -> Dict[str, torch.Tensor]:
-        """Forward + loss values of model_wrapper.py:107-163 (values only: no autograd graph in round 1)."""
+        """Forward + the individually logged loss terms of model_wrapper.py:107-163 (``loss/*`` names as logged there).
+        With gradients enabled the terms carry autograd graphs (Model.forward's action / perception training paths)."""
         model_input, target = prepare_training_input_output(batch, self.mode, self.rays_per_batch)
         out = self.model.forward(model_input.camera_input, model_input.rendering_input, model_input.robot_input)
         if self.mode == "perception":
             losses = {"loss/rgb": rgb_loss(out, target)}
             if out.training_output is not None:
+                tr = out.training_output
                 losses["loss/depth"] = depth_loss(out, target, float(self.depth_sigma))
+                losses["loss/interlevel"] = 1.0 * interlevel_loss(tr.weights_list, tr.ray_samples_list)
+                losses["loss/distortion"] = 0.01 * distortion_loss(tr.weights_list, tr.ray_samples_list)
         else:
             losses = {"loss/flow_loss": flow_loss(out, target)}
         return losses
+
+    def training_step(self, batch: Dict, batch_idx: int = 0) -> torch.Tensor:
+        """model_wrapper.py:107-146: the scalar that is back-propagated (and, under data parallelism, whose gradient
+        bucket is all-reduced: parallel.allreduce_gradients)."""
+        return sum(self.evaluate_losses(batch).values())
+
+    def configure_optimizers(self, lr: float, warm_up_steps: int):
+        """model_wrapper.py:87-105: Adam(weight_decay=1e-5) + linear warm-up."""
+        optimizer = torch.optim.Adam([p for p in self.parameters() if p.requires_grad], lr=lr, weight_decay=1e-5)
+        warm_up = torch.optim.lr_scheduler.LinearLR(optimizer, 1 / warm_up_steps, 1, total_iters=warm_up_steps)
+        return optimizer, warm_up

@@ -647,6 +647,47 @@ def ds_nerf_depth_loss(weights, termination_depth, steps, lengths, sigma) -> Ten
     return torch.mean(loss.sum(-2) * mask)
 
 
+def interlevel_loss(weights_list: Sequence[Tensor], edges_list: Sequence[Tensor]) -> Tensor:
+    """Proposal supervision used at NJF/models/model_wrapper.py:138 (``nerfstudio.model_components.losses.
+    interlevel_loss``; nerfstudio is not vendored and not pinned -> PARITY UNPINNED, restated from the published
+    definition, mip-NeRF 360 eq. 13).  ``weights_list[l]`` [N,S_l], ``edges_list[l]`` [N,S_l+1] spacing-domain edges.
+    Plain loops over intervals (small cases only): for the final interval [a, b] the bound is the summed weight of
+    the proposal intervals lo..hi, lo = the last one starting at or before a, hi = the first one ending after b
+    (edges compare closed, as searchsorted side="right" makes them)."""
+    w_fin, t_fin = weights_list[-1].detach(), edges_list[-1].detach()
+    total = torch.zeros(())
+    for wts, env in zip(weights_list[:-1], edges_list[:-1]):
+        acc = torch.zeros(())
+        n, s_fin = w_fin.shape
+        s_env = wts.shape[-1]
+        for ray in range(n):
+            for i in range(s_fin):
+                a, b = t_fin[ray, i], t_fin[ray, i + 1]
+                # first envelope interval whose start is <= a (last such), last envelope interval whose end is <= b, +1
+                lo = max(sum(1 for k in range(s_env) if env[ray, k] <= a) - 1, 0)
+                hi = min(sum(1 for k in range(s_env) if env[ray, k + 1] <= b), s_env - 1)
+                bound = wts[ray, lo:hi + 1].sum() if hi >= lo else torch.zeros(())
+                acc = acc + torch.clip(w_fin[ray, i] - bound, min=0) ** 2 / (w_fin[ray, i] + 1.0e-7)
+        total = total + acc / (n * s_fin)
+    return total
+
+
+def distortion_loss(weights: Tensor, edges: Tensor) -> Tensor:
+    """``nerfstudio...losses.distortion_loss`` at NJF/models/model_wrapper.py:139 (PARITY UNPINNED, see above;
+    mip-NeRF 360 eq. 15) on the final level: weights [N,S], edges [N,S+1]."""
+    n, s = weights.shape
+    total = torch.zeros(())
+    for ray in range(n):
+        mid = [(edges[ray, i] + edges[ray, i + 1]) / 2 for i in range(s)]
+        acc = torch.zeros(())
+        for i in range(s):
+            for j in range(s):
+                acc = acc + weights[ray, i] * weights[ray, j] * torch.abs(mid[i] - mid[j])
+            acc = acc + weights[ray, i] ** 2 * (edges[ray, i + 1] - edges[ray, i]) / 3
+        total = total + acc
+    return total / n
+
+
 # --------------------------------------------------------------------------------------
 # BASELINE.json config 0 ("C1", PR1 plumbing reference): the 2D tutorial model's flow composition
 # --------------------------------------------------------------------------------------

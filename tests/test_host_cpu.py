@@ -186,3 +186,35 @@ def test_inverse_dynamics_gauss_newton_recovers_action():
     corrupted[:, ::3] += 50.0
     got = solve_action(lin, corrupted, iterations=6, visible_mask=mask)
     assert torch.allclose(got, truth, atol=2e-3)
+
+
+def test_proposal_losses_match_the_loop_oracle():
+    """interlevel / distortion losses (nerfstudio is absent and un-pinned: parity unpinned) -- the vectorised host
+    expressions against the oracle's interval-by-interval restatement, including gradients."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd.model_wrapper import distortion_loss, interlevel_loss
+    from neural_jacobian_field_amd.ray_samplers import RaySamples
+    gen = torch.Generator().manual_seed(5)
+    n, s_p, s_f = 5, 9, 7
+
+    def level(s):
+        edges = torch.sort(torch.rand(n, s + 1, generator=gen), dim=-1).values
+        edges[:, 0], edges[:, -1] = 0.0, 1.0
+        w = torch.rand(n, s, generator=gen)
+        w = (w / w.sum(-1, keepdim=True) * 0.9).requires_grad_(True)
+        smp = RaySamples(None, None, edges[:, :-1, None], edges[:, 1:, None], None, edges[:, :-1, None], edges[:, 1:, None])
+        return edges, w, smp
+
+    (e_p, w_p, smp_p), (e_f, w_f, smp_f) = level(s_p), level(s_f)
+    got_i = interlevel_loss([w_p[..., None], w_f[..., None]], [smp_p, smp_f])
+    got_d = distortion_loss([w_p[..., None], w_f[..., None]], [smp_p, smp_f])
+    g_i, = torch.autograd.grad(got_i, w_p)
+    g_d, = torch.autograd.grad(got_d, w_f)
+    w_p2, w_f2 = w_p.detach().clone().requires_grad_(True), w_f.detach().clone().requires_grad_(True)
+    ref_i = orc.interlevel_loss([w_p2, w_f2], [e_p, e_f])
+    ref_d = orc.distortion_loss(w_f2, e_f)
+    r_i, = torch.autograd.grad(ref_i, w_p2)
+    r_d, = torch.autograd.grad(ref_d, w_f2)
+    assert got_i.item() > 0 and torch.allclose(got_i, ref_i, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(got_d, ref_d, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(g_i, r_i, rtol=1e-4, atol=1e-8) and torch.allclose(g_d, r_d, rtol=1e-4, atol=1e-8)

@@ -219,3 +219,49 @@ def test_perception_step_trains_all_parts(setup):
         for n, p in model.named_parameters():
             p.requires_grad = req[n]
         model.zero_grad(set_to_none=True)
+
+
+def test_wrapper_training_step_perception_and_action(setup):
+    """ModelWrapper.training_step (model_wrapper.py:107-163) end to end on a dataset-schema batch: the perception loss
+    reaches encoder, density/colour heads and proposal net; the action loss reaches only the Jacobian head."""
+    from neural_jacobian_field_amd.geometry import get_pixel_coordinates
+    from neural_jacobian_field_amd.model_wrapper import ModelWrapper
+    s = setup
+    model, dev, case = s["model"], s["dev"], s["case"]
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    req = {n: p.requires_grad for n, p in model.named_parameters()}
+    B, H, W = 2, 16, 16
+    c = case["cams"]
+    g2 = torch.Generator().manual_seed(31)
+    coords, _ = get_pixel_coordinates(H, W, dev)
+
+    def batch():
+        return {"context": {"rgb": s["image"].to(dev), "extrinsics": c["ctxt_c2w"].to(dev), "intrinsics": c["ctxt_k_norm"].to(dev),
+                            "robot_action": case["action"].to(dev)},
+                "target": {"rgb": torch.rand(B, 3, H, W, generator=g2).to(dev), "depth": (torch.rand(B, 1, H, W, generator=g2) + 0.5).to(dev),
+                           "flow": torch.randn(B, 2, H, W, generator=g2).to(dev), "extrinsics": c["trgt_c2w"].to(dev),
+                           "intrinsics": c["ctxt_k_norm"].to(dev)},
+                "scene": {"near": c["z_near"].to(dev), "far": c["z_far"].to(dev), "coordinates": coords[None].expand(B, -1, -1, -1)}}
+
+    try:
+        for p in model.parameters():
+            p.requires_grad = True
+        wrapper = ModelWrapper("perception", 48, model).train()
+        loss = wrapper.training_step(batch())
+        assert torch.isfinite(loss)
+        loss.backward()
+        got = {n.split(".")[1] + "." + n.split(".")[2] for n, p in wrapper.named_parameters() if p.grad is not None}
+        assert {"encoder.model", "decoder.density_head", "decoder.color_head", "proposal_networks.0"} <= got, got
+        assert all(p.grad is None for n, p in wrapper.named_parameters() if "jacobian_head" in n)
+        wrapper.zero_grad(set_to_none=True)
+
+        wrapper = ModelWrapper("action", 48, model).train()     # freezes everything but the Jacobian head
+        loss = wrapper.training_step(batch())
+        loss.backward()
+        assert all((p.grad is not None) == ("jacobian_head" in n) for n, p in wrapper.named_parameters())
+    finally:
+        model.load_state_dict(state)
+        for n, p in model.named_parameters():
+            p.requires_grad = req[n]
+        model.zero_grad(set_to_none=True)
+        model.eval()
