@@ -218,3 +218,29 @@ def test_proposal_losses_match_the_loop_oracle():
     assert got_i.item() > 0 and torch.allclose(got_i, ref_i, rtol=1e-5, atol=1e-8)
     assert torch.allclose(got_d, ref_d, rtol=1e-5, atol=1e-8)
     assert torch.allclose(g_i, r_i, rtol=1e-4, atol=1e-8) and torch.allclose(g_d, r_d, rtol=1e-4, atol=1e-8)
+
+
+def test_ctypes_structs_match_the_header():
+    """Field names and order of every struct in include/njf_hip.h against the ctypes mirrors (hip.py) and the
+    reference-side stub printed in INTEGRATION.md -- a missing trailing field would make the library read past the
+    caller's struct."""
+    from neural_jacobian_field_amd import hip
+    header = open(os.path.join(ROOT, "include", "njf_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                names += [n.strip().lstrip("*").strip() for n in re.sub(r"^(const\s+)?\w+\s*\*?", "", decl, count=1).split(",")]
+        return names
+
+    pairs = {"NjfRenderOutputs": hip.RenderOutputs, "NjfActivationDump": hip.ActivationDump, "NjfCameras": hip.Cameras,
+             "NjfFeatureMap": hip.FeatureMap}
+    for name, mirror in pairs.items():
+        assert fields(name) == [f[0] for f in mirror._fields_], name
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = re.search(r"class RenderOutputs\(C\.Structure\):.*?_fields_ = \[\(n, vp\) for n in \((.*?)\)\]", doc, flags=re.S).group(1)
+    assert re.findall(r'"(\w+)"', stub) == fields("NjfRenderOutputs")
