@@ -183,9 +183,11 @@ typedef struct NjfRenderOutputs {
   float* color;           /* [B*R,S,3]; NULL to skip */
   float* sample_flow;     /* [B*R,S,3] per-sample 3-D flow; NULL to skip */
   float* jacobian;        /* [B*R,S,3A] per-sample action features (encode_image, model.py:458-495); NULL to skip */
-  /* training forward, all NULL for inference (P = B*R*S; layouts as in NjfActivationDump).  Either jac_act
-   * (action mode: backward of the jacobian_mlp head) or den_act + col_* (perception mode: backward of the density
-   * net and the colour head) may be set, together with jac_pe / foot_idx / foot_w, which both modes share. */
+  /* training forward, all NULL for inference (P = B*R*S; layouts as in NjfActivationDump).  jac_pe / foot_idx /
+   * foot_w select a training forward and are shared by both modes: with den_act + col_* it is the perception mode
+   * (backward of the density net and the colour head), otherwise the action mode (backward of the Jacobian head:
+   * jac_act is required for NJF_JACOBIAN_MLP and must be NULL for NJF_JACOBIAN_TRANSFORMER, whose backward pass
+   * recomputes the head from the encoding and the footprint). */
   float* jac_act;         /* [11, P, 128] activations of the Jacobian ResnetFC */
   float* jac_pe;          /* [P, 64] positional encoding (the density and Jacobian nets see the same one) */
   int* foot_idx;          /* [P, 4] */

@@ -429,7 +429,7 @@ struct ProposalArgs {
 // this lane's share of a point's backward-pass inputs: activations / encoding (both halves), footprint (half 0)
 __device__ __forceinline__ ActDump point_dump(const NjfActivationDump& d, size_t pidx, size_t points, int hh,
                                               const PointGeom& g, int tex0, int texel_stride) {
-  ActDump dump{d.act + pidx * 128 + 64 * hh, d.pe + pidx * 64 + 32 * hh, points * 128};
+  ActDump dump{d.act ? d.act + pidx * 128 + 64 * hh : nullptr, d.pe + pidx * 64 + 32 * hh, points * 128};
   if (hh == 0 && d.foot_idx != nullptr) {
     int* fi = d.foot_idx + pidx * 4;
     fi[0] = tex0 + g.t00 / texel_stride;
@@ -559,7 +559,20 @@ __device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __re
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     if (JKIND == 1)
       resnet_tile<PREC, DUMP == 1>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac, dump);
-    else transformer_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
+    else {
+      if (DUMP == 1 && dump.pe != nullptr) {  // the transformer head's backward pass recomputes it from pe + footprint
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pe[kb][4 * q + e];
+            *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
+          }
+      }
+      transformer_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
+    }
     // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
     // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
     float ph[3] = {0.f, 0.f, 0.f};
@@ -1057,11 +1070,19 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.out = *out;
   hipStream_t s = (hipStream_t)stream;
   const int n = a.rc.total_rays;
-  if (out->jac_act != nullptr) {  // action-mode training forward: dump the Jacobian head for its backward pass
-    if (jacobian_kind != NJF_JACOBIAN_MLP || out->den_act) return NJF_E_MODE;
+  if (out->jac_act != nullptr || (out->jac_pe != nullptr && out->den_act == nullptr)) {
+    // action-mode training forward: dump the Jacobian head's backward-pass inputs (ResnetFC head: activations +
+    // encoding + footprint; transformer head: encoding + footprint, the head is recomputed by the backward pass)
+    if (jacobian_kind == NJF_JACOBIAN_NONE || out->den_act) return NJF_E_MODE;
     if (!out->jac_pe || !out->foot_idx || !out->foot_w) return NJF_E_NULL;
-    if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<1, PREC_F16X2, 1>, a, n, s);
-    return launch_fused(render_kernel<1, PREC_F32, 1>, a, n, s);
+    if (jacobian_kind == NJF_JACOBIAN_MLP) {
+      if (!out->jac_act) return NJF_E_NULL;
+      if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<1, PREC_F16X2, 1>, a, n, s);
+      return launch_fused(render_kernel<1, PREC_F32, 1>, a, n, s);
+    }
+    if (out->jac_act) return NJF_E_MODE;
+    if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<2, PREC_F16X2, 1>, a, n, s);
+    return launch_fused(render_kernel<2, PREC_F32, 1>, a, n, s);
   }
   if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
     if (!out->jac_pe || !out->foot_idx || !out->foot_w || !out->col_in || !out->col_act) return NJF_E_NULL;

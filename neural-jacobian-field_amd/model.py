@@ -238,7 +238,8 @@ class Model(nn.Module):
             pts = b * r * s
             outs["weights"] = outs.get("weights", torch.empty(b, r, s, **f32))
             outs["pos_warped"] = outs.get("pos_warped", torch.empty(b, r, 3, **f32))
-            outs["jac_act"] = torch.empty(11, pts, 128, **f32)
+            if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:  # the transformer head is recomputed from pe + footprint
+                outs["jac_act"] = torch.empty(11, pts, 128, **f32)
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
             outs["foot_w"] = torch.empty(pts, 4, **f32)
@@ -331,7 +332,7 @@ class Model(nn.Module):
 
     def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
         from . import training
-        jparams = training.check_action_mode(self)
+        names, jparams = training.action_params(self)
         with torch.no_grad():
             features = self.encoder.forward(camera_input.input_image)
         box = {}
@@ -345,7 +346,8 @@ class Model(nn.Module):
             return outs
 
         project = lambda x: self._project(x, camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
-        flow = training.ActionFlowFunction.apply(run, project, robot_input.robot_action.detach(), features, *jparams)
+        flow = training.ActionFlowFunction.apply(run, project, robot_input.robot_action.detach(), features, names,
+                                                 self.cfg.action_decoder.name, *jparams)
         outs = box["outs"]
         out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=flow), None, None)
         self._attach_optional_outputs(out, outs, box["bins"], box["weights_list"], box["bins_list"], box["ray_bundle"],

@@ -8,8 +8,9 @@ Forward: the fused HIP kernels, with the final pass additionally dumping the ReL
 Jacobian ``ResnetFC`` (``njf_render_forward`` with ``jac_act``/``jac_pe``/``foot_*`` outputs).
 Backward (round-1 form): the layer-by-layer chain on the dumped ``[P,128]`` matrices as plain library GEMMs
 (rocBLAS through ``torch.matmul``) plus ReLU masks -- exact, tested against autograd of the CPU oracle.  Fusing this
-chain into a HIP kernel is the next step of SURVEY.md section 8f #2; ``jacobian_transformer`` and perception-mode
-(full-model) gradients are not implemented and raise.
+chain into a HIP kernel is the next step of SURVEY.md section 8f #2.  The ``jacobian_transformer`` head is
+differentiated by recomputing it (original parameterisation, library ops) on the dumped encoding + footprint.
+Perception mode (every parameter trains; rgb / depth / per-level weights carry the graph) is ``FieldFunction``.
 """
 
 from __future__ import annotations
@@ -75,26 +76,56 @@ def _flat_features(features: torch.Tensor) -> torch.Tensor:
     return features.permute(0, 2, 3, 1).reshape(-1, features.shape[1])
 
 
+def transformer_head(p: Dict[str, torch.Tensor], xyz_features: torch.Tensor, pixel_features: torch.Tensor,
+                     heads: int = 8) -> torch.Tensor:
+    """ActionDecoderJacobianTransformer.compute_jacobian (action_decoder_jacobian.py:418-446 with
+    model_components/transformer.py:38-135) in its ORIGINAL, un-folded parameterisation, as differentiable torch ops.
+    Used only by the backward pass, which recomputes the head (~0.3 MMAC/point) on the dumped inputs so that autograd
+    yields gradients w.r.t. the reference's parameters directly instead of the folded matrices the kernel evaluates.
+    ``p``: parameters by their name relative to the decoder; xyz_features [P,63], pixel_features [P,512] -> [P,3A]."""
+    x = torch.nn.functional.linear(torch.cat([xyz_features, pixel_features], dim=-1),
+                                   p["jacobian_query_mlp.weight"], p["jacobian_query_mlp.bias"])
+    z = p["jacobian_index_embedding"][0]                               # [A, 64] learned tokens, shared by all points
+    n_pts, n_tok = x.shape[0], z.shape[0]
+    layer = 0
+    while f"jacobian_attn_decoder.layers.{layer}.0.norm.weight" in p:
+        pre = f"jacobian_attn_decoder.layers.{layer}."
+        n = torch.nn.functional.layer_norm(x, x.shape[-1:], p[pre + "0.norm.weight"], p[pre + "0.norm.bias"])
+        q = (n @ p[pre + "0.fn.to_q.weight"].t()).reshape(n_pts, heads, -1)
+        k, v = (z @ p[pre + "0.fn.to_kv.weight"].t()).chunk(2, dim=-1)
+        k, v = k.reshape(n_tok, heads, -1), v.reshape(n_tok, heads, -1)
+        attn = torch.softmax(torch.einsum("phd,ahd->pha", q, k) * q.shape[-1] ** -0.5, dim=-1)
+        o = torch.einsum("pha,ahd->phd", attn, v).reshape(n_pts, -1)
+        x = x + torch.nn.functional.linear(o, p[pre + "0.fn.to_out.0.weight"], p[pre + "0.fn.to_out.0.bias"])
+        n = torch.nn.functional.layer_norm(x, x.shape[-1:], p[pre + "1.norm.weight"], p[pre + "1.norm.bias"])
+        hid = torch.nn.functional.gelu(torch.nn.functional.linear(n, p[pre + "1.fn.net.0.weight"], p[pre + "1.fn.net.0.bias"]))
+        x = x + torch.nn.functional.linear(hid, p[pre + "1.fn.net.3.weight"], p[pre + "1.fn.net.3.bias"])
+        layer += 1
+    return torch.nn.functional.linear(x, p["jacobian_head.weight"], p["jacobian_head.bias"])
+
+
 class ActionFlowFunction(torch.autograd.Function):
-    """optical_flow = f(jacobian_head parameters); every other input is a constant captured by ``run``."""
+    """optical_flow = f(Jacobian-head parameters); every other input is a constant captured by ``run``.
+    ``names``: the parameters' names relative to the decoder, ``kind``: ``jacobian_mlp`` | ``jacobian_transformer``."""
 
     @staticmethod
     def forward(ctx, run: Callable[[], Dict[str, torch.Tensor]], project: Callable, action: torch.Tensor,
-                features: torch.Tensor, *jparams: torch.Tensor):
+                features: torch.Tensor, names: Sequence[str], kind: str, *jparams: torch.Tensor):
         outs = run()
         ctx.outs = outs
         ctx.project = project
         ctx.action = action
         ctx.features = features
+        ctx.names, ctx.kind = list(names), kind
         ctx.save_for_backward(*jparams)
         ctx.set_materialize_grads(False)
         return outs["flow"]
 
     @staticmethod
     def backward(ctx, g_flow):
+        lead = (None,) * 6
         if g_flow is None:
-            return (None,) * (4 + len(ctx.saved_tensors))
-        p = dict(zip(JACOBIAN_PARAM_ORDER, ctx.saved_tensors))
+            return lead + (None,) * len(ctx.saved_tensors)
         outs, action, features = ctx.outs, ctx.action, ctx.features
         weights = outs["weights"]  # [B,R,S]
         b, r, s = weights.shape
@@ -105,10 +136,23 @@ class ActionFlowFunction(torch.autograd.Function):
             (g_xw,) = torch.autograd.grad(ctx.project(xw), xw, g_flow.contiguous())
         # flow_s = sum_a J[a,:] act[a]  (action_decoder_jacobian.py:128-145)  =>  dJ[s,a,c] = w_s act[a] g_xw[c]
         d_j = torch.einsum("brs,ba,brc->brsac", weights, action, g_xw).reshape(b * r * s, 3 * a)
-        grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"],
-                                  _flat_features(features))
+        feats_flat = _flat_features(features)
+        if ctx.kind == "jacobian_mlp":
+            p = {n[len("jacobian_head."):]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
+            grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat)
+            result = tuple(grads[n[len("jacobian_head."):]] for n in ctx.names)
+        else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
+            pe = outs["jac_pe"]
+            xyz_features = pe.new_empty(pe.shape[0], 63)
+            xyz_features[:, torch.tensor(_PE_SLOT_TO_CHANNEL, device=pe.device)] = pe[:, :63]
+            idx, fw = outs["foot_idx"].long(), outs["foot_w"]
+            pixel_features = sum(feats_flat[idx[:, c]] * fw[:, c:c + 1] for c in range(4))   # bilinear, border-clamped
+            leaves = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
+            with torch.enable_grad():
+                jac = transformer_head(dict(zip(ctx.names, leaves)), xyz_features, pixel_features)
+                result = torch.autograd.grad(jac, leaves, d_j)
         ctx.outs = None
-        return (None, None, None, None) + tuple(grads[k] for k in JACOBIAN_PARAM_ORDER)
+        return lead + tuple(result)
 
 
 COLOR_PARAM_ORDER: List[str] = [f"{i}.{wb}" for i in (0, 2, 4) for wb in ("weight", "bias")]
@@ -227,9 +271,10 @@ class RefuseBackward(torch.autograd.Function):
 
 
 def is_action_mode(model) -> bool:
+    """The reference's action-mode trainable set (ModelWrapper.freeze_parameters, model_wrapper.py:75-85 with
+    ActionDecoderJacobian.freeze_non_action_parameters): only decoder parameters whose name contains "jacobian"."""
     names = trainable_names(model)
-    return (bool(names) and all(n.startswith("decoder.jacobian_head.") for n in names)
-            and model.cfg.action_decoder.name == "jacobian_mlp")
+    return bool(names) and all(n.startswith("decoder.jacobian") for n in names)
 
 
 PERCEPTION_MESSAGE = ("optical_flow is differentiable only in the reference's action mode (ModelWrapper.freeze_parameters: "
@@ -241,17 +286,13 @@ def trainable_names(module: torch.nn.Module) -> List[str]:
     return [n for n, q in module.named_parameters() if q.requires_grad]
 
 
-def check_action_mode(model) -> Sequence[torch.Tensor]:
-    """Returns the Jacobian-head parameters in JACOBIAN_PARAM_ORDER, or raises if the trainable set is not the
-    reference's action mode (models/model_wrapper.py:75-85) on a ``jacobian_mlp`` decoder."""
-    names = trainable_names(model)
-    if any(not n.startswith("decoder.jacobian_head.") for n in names):
-        other = [n for n in names if not n.startswith("decoder.jacobian_head.")][:3]
-        raise NotImplementedError(
-            "the fused path differentiates only the Jacobian head (reference action mode: "
-            f"ModelWrapper.freeze_parameters); also trainable here: {other} ... (perception-mode backward is "
-            "SURVEY.md section 8f #2)")
-    if model.cfg.action_decoder.name != "jacobian_mlp":
-        raise NotImplementedError("backward is implemented for the jacobian_mlp decoder only")
-    head = dict(model.decoder.jacobian_head.named_parameters())
-    return [head[k] for k in JACOBIAN_PARAM_ORDER]
+def action_params(model):
+    """(names relative to the decoder, tensors) of the Jacobian head in the order ActionFlowFunction uses: the
+    ResnetFC layer order for ``jacobian_mlp``, registration order for ``jacobian_transformer`` (index embedding, query
+    MLP, attention decoder, output Linear).  Frozen members are included (they simply receive unused gradients)."""
+    dec = dict(model.decoder.named_parameters())
+    if model.cfg.action_decoder.name == "jacobian_mlp":
+        names = ["jacobian_head." + k for k in JACOBIAN_PARAM_ORDER]
+    else:
+        names = [n for n in dec if n.startswith("jacobian")]
+    return names, [dec[n] for n in names]

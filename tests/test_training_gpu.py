@@ -265,3 +265,48 @@ def test_wrapper_training_step_perception_and_action(setup):
             p.requires_grad = req[n]
         model.zero_grad(set_to_none=True)
         model.eval()
+
+
+def test_transformer_action_mode_gradients_match_oracle_autograd(setup):
+    """jacobian_transformer (the shipped Allegro decoder, model_allegro.yaml:26) in action mode: the kernel evaluates
+    the folded head, the backward pass recomputes the un-folded head on the dumped encoding + footprint; gradients of
+    every "jacobian*" parameter against autograd through the CPU oracle."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model, RobotInput
+    s = setup
+    case, dev, A = s["case"], s["dev"], 6
+    full = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_transformer", A), seed=6)
+    model = Model(model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [s["S"]], "num_nerf_samples": s["S"]},
+                                       "action_decoder": {"name": "jacobian_transformer"}}))
+    model.load_state_dict(full, strict=True)
+    model.to(dev).eval()
+    frozen = model.decoder.freeze_non_action_parameters()
+    assert frozen > 0
+    for n, p in model.named_parameters():
+        if "decoder" not in n:
+            p.requires_grad = False
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert trainable and all(n.startswith("decoder.jacobian") for n in trainable)
+    action = torch.randn(case["action"].shape[0], A, generator=torch.Generator().manual_seed(8)) * 0.3
+    out = model.forward(s["cam"], s["rin"], RobotInput(action.to(dev)))
+    loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))
+    loss.backward()
+
+    params = {k: v.clone() for k, v in full.items()}
+    for k in trainable:
+        params[k].requires_grad_(True)
+    c = case["cams"]
+    ref = orc.model_forward(params, input_image=s["image"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
+                            trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
+                            directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=action,
+                            num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_transformer")
+    ref_loss = orc.flow_loss(ref.optical_flow, s["target"])
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3
+    named = dict(model.named_parameters())
+    worst = max(rel(named[k].grad, params[k].grad) for k in trainable)
+    print("worst relative gradient error (transformer head)", worst)
+    assert worst < 5e-3, worst
+    assert all(p.grad is None for n, p in named.items() if n not in trainable)
