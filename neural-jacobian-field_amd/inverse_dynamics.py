@@ -51,6 +51,20 @@ def linearize_flow(model: Model, camera_input: CameraInput, rendering_input: Ren
     return FlowLinearization(out.vis_output.ray_positions, jac, camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
 
 
+def _solve_spd(h: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """x = h^-1 g for small damped normal matrices h [B,A,A] (symmetric positive definite), g [B,A]: un-pivoted
+    Gauss-Jordan in batched tensor ops.  torch.linalg.solve would do, but its LAPACK-style back ends synchronise
+    with the host (error check / MAGMA), which rules out HIP-graph capture of the control step."""
+    a = h.shape[-1]
+    m = torch.cat([h, g[..., None]], dim=-1)                                   # [B, A, A+1]
+    rows = torch.arange(a, device=h.device)
+    for k in range(a):
+        pivot_row = m[:, k:k + 1, :] / m[:, k:k + 1, k:k + 1]
+        factor = torch.where((rows == k)[None, :, None], torch.zeros_like(m[:, :, k:k + 1]), m[:, :, k:k + 1])
+        m = torch.where((rows == k)[None, :, None], pivot_row, m - factor * pivot_row)
+    return m[..., -1]
+
+
 def _projection_matrix(lin: FlowLinearization) -> torch.Tensor:
     """[B,3,4] world -> homogeneous pixel matrix K . inv(E)[:3]."""
     from . import hip
@@ -90,7 +104,7 @@ def solve_action(lin: FlowLinearization, target_flow: torch.Tensor, init_action:
         jac = ((duv_dx @ lin.jacobian) * w[..., None]).reshape(b, 2 * r, a_dim)
         h = jac.transpose(1, 2) @ jac
         diag = torch.diag_embed(torch.diagonal(h, dim1=1, dim2=2).clamp_min(1e-12))
-        step = torch.linalg.solve(h + lam * diag, jac.transpose(1, 2) @ res.reshape(b, 2 * r, 1))[..., 0]
+        step = _solve_spd(h + lam * diag, (jac.transpose(1, 2) @ res.reshape(b, 2 * r, 1))[..., 0])
         cand = action - step
         uv_c, depth_c, res_c, cost_c = evaluate(cand)
         better = cost_c < cost                                                # NaN (point behind the camera) -> rejected
@@ -100,3 +114,79 @@ def solve_action(lin: FlowLinearization, target_flow: torch.Tensor, init_action:
         cost = torch.where(better, cost_c, cost)
         lam = torch.where(better[:, None, None], lam / 3.0, lam * 4.0).clamp(1e-9, 1e9)
     return action
+
+
+class GraphedLinearizer:
+    """``linearize_flow`` for a fixed camera rig and ray set, captured once into a HIP graph and replayed per frame:
+    at control-loop sizes (a few hundred tracked rays) the fused render is launch-bound, so replaying one graph
+    (encoder + lin_z hoist + proposal pass + final pass) removes the per-launch host cost.  ``__call__(image)`` copies
+    the new context image into the captured input buffer and replays; the returned tensors are the graph's static
+    outputs (overwritten by the next call)."""
+
+    def __init__(self, model: Model, camera_input: CameraInput, rendering_input: RenderingInput,
+                 action_dim: Optional[int] = None, warmup: int = 2):
+        self._image = camera_input.input_image.clone()
+        cam = CameraInput(self._image, camera_input.ctxt_extrinsics, camera_input.ctxt_intrinsics,
+                          camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # warm-up off the default stream: packs weights, loads MIOpen kernels
+            for _ in range(warmup):
+                linearize_flow(model, cam, rendering_input, action_dim)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = linearize_flow(model, cam, rendering_input, action_dim)
+
+    def __call__(self, image: torch.Tensor) -> FlowLinearization:
+        self._image.copy_(image)
+        self._graph.replay()
+        return self._out
+
+
+class GraphedInverseDynamics:
+    """The whole control step -- encoder, lin_z hoist, proposal pass, final pass, ``iterations`` Levenberg-Marquardt
+    steps -- as ONE replayed HIP graph: ``action = controller(image, target_flow[, init_action, visible_mask])``.
+    Camera rig, tracked rays and iteration count are fixed at capture time; nothing in the step synchronises with the
+    host, so the per-frame host cost is three small copies and one graph launch."""
+
+    def __init__(self, model: Model, camera_input: CameraInput, rendering_input: RenderingInput, iterations: int = 8,
+                 damping: float = 1e-3, action_dim: Optional[int] = None, warmup: int = 2):
+        a = action_dim or model.cfg.action_dim
+        b, r = rendering_input.origins.shape[:2]
+        dev = rendering_input.origins.device
+        self._image = camera_input.input_image.clone()
+        self._target = torch.zeros(b, r, 2, device=dev)
+        self._init = torch.zeros(b, a, device=dev)
+        self._mask = torch.ones(b, r, device=dev)
+        cam = CameraInput(self._image, camera_input.ctxt_extrinsics, camera_input.ctxt_intrinsics,
+                          camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
+
+        def step():
+            lin = linearize_flow(model, cam, rendering_input, a)
+            return solve_action(lin, self._target, self._init, iterations, damping, self._mask)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._action = step()
+
+    def __call__(self, image: torch.Tensor, target_flow: torch.Tensor, init_action: Optional[torch.Tensor] = None,
+                 visible_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._image.copy_(image)
+        self._target.copy_(target_flow)
+        if init_action is None:
+            self._init.zero_()
+        else:
+            self._init.copy_(init_action)
+        if visible_mask is None:
+            self._mask.fill_(1.0)
+        else:
+            self._mask.copy_(visible_mask)
+        self._graph.replay()
+        return self._action

@@ -273,3 +273,23 @@ def test_inverse_dynamics_least_squares(model_and_golden):
     target = model.forward(cam, rin, RobotInput(truth)).standard_output.optical_flow
     got = solve_action(lin, target, iterations=20)
     assert rel(lin.optical_flow(got), target) < 1e-2
+
+
+def test_graphed_control_step_matches_eager(model_and_golden):
+    """The control step captured as one HIP graph (encoder + fused render + LM iterations) replays to the eager
+    result, also after the inputs change (new image, new target)."""
+    from neural_jacobian_field_amd.inverse_dynamics import GraphedInverseDynamics, linearize_flow, solve_action
+    from neural_jacobian_field_amd.model import CameraInput
+    model, g = model_and_golden
+    cam, rin, rob = _inputs(g)
+    ctrl = GraphedInverseDynamics(model, cam, rin, iterations=6)
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    for trial in range(2):
+        image = torch.rand(cam.input_image.shape, generator=gen).to(cam.input_image.device)
+        cam_t = CameraInput(image, cam.ctxt_extrinsics, cam.ctxt_intrinsics, cam.trgt_extrinsics, cam.trgt_intrinsics)
+        lin = linearize_flow(model, cam_t, rin)
+        target = lin.optical_flow(torch.randn_like(rob.robot_action) * 0.002)
+        eager = solve_action(lin, target, iterations=6)
+        got = ctrl(image, target).clone()
+        assert rel(lin.optical_flow(got), target) < 1e-2
+        assert rel(lin.optical_flow(got), lin.optical_flow(eager)) < 1e-2   # two encoder runs: MIOpen ulps
