@@ -29,6 +29,14 @@ JACOBIAN_PARAM_ORDER: List[str] = (
 
 # positional-encoding slot -> reference channel (csrc/njf_kernels.hip::pack_source, kind 1); slot 63 is the bias
 _PE_SLOT_TO_CHANNEL = list(range(30)) + [60, 61] + list(range(30, 60)) + [62]
+_slot_index_cache: Dict[torch.device, torch.Tensor] = {}
+
+
+def _slot_to_channel(device: torch.device) -> torch.Tensor:
+    """Device copy of _PE_SLOT_TO_CHANNEL (made once per device: a host->device copy per backward pass would stall)."""
+    if device not in _slot_index_cache:
+        _slot_index_cache[device] = torch.tensor(_PE_SLOT_TO_CHANNEL, device=device)
+    return _slot_index_cache[device]
 
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
@@ -67,7 +75,7 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
                 d_feats.addmm_(d_g, p[f"lin_z.{blk}.weight"])
     d_in = delta.t() @ pe  # [128, 64] in slot order
     grads["lin_in.weight"] = d_in.new_zeros(d_in.shape[0], 63).index_copy_(
-        1, torch.tensor(_PE_SLOT_TO_CHANNEL, device=d_in.device), d_in[:, :63])
+        1, _slot_to_channel(d_in.device), d_in[:, :63])
     grads["lin_in.bias"] = d_in[:, 63].clone()
     return grads
 
@@ -144,7 +152,7 @@ class ActionFlowFunction(torch.autograd.Function):
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
             xyz_features = pe.new_empty(pe.shape[0], 63)
-            xyz_features[:, torch.tensor(_PE_SLOT_TO_CHANNEL, device=pe.device)] = pe[:, :63]
+            xyz_features[:, _slot_to_channel(pe.device)] = pe[:, :63]
             idx, fw = outs["foot_idx"].long(), outs["foot_w"]
             pixel_features = sum(feats_flat[idx[:, c]] * fw[:, c:c + 1] for c in range(4))   # bilinear, border-clamped
             leaves = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
