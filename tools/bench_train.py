@@ -13,6 +13,8 @@ from neural_jacobian_field_amd.config import model_cfg_from_dict
 from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
 
 dev = torch.device("cuda:0")
+if os.environ.get("NJF_MIOPEN_FIND"):
+    torch.backends.cudnn.benchmark = True
 B, H, W, R, S = 7, 256, 256, 256, 64
 case = ph.make_case(B, H, W, R, 8, seed=0)
 model = Model(model_cfg_from_dict({"action_dim": 8, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
