@@ -41,9 +41,9 @@ def _slot_to_channel(device: torch.device) -> torch.Tensor:
 
 def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T b for tall-skinny operands (a [K,M], b [K,N], K = points or texels >> M, N <= 512): the weight-gradient
-    GEMMs.  The output has only a handful of macro-tiles, so a plain GEMM call serialises the whole K loop on one or
-    two workgroups (measured: 3.5 ms for lin_z's [128 x 114,688] x [114,688 x 512] on an MI355X, 15 GFLOP); splitting
-    K into batches fills the chip, and the partial products are summed afterwards."""
+    GEMMs.  The output has only a handful of macro-tiles, so a plain GEMM call serialises the whole K loop on a few
+    workgroups; splitting K into batches fills the chip, and the partial products are summed afterwards (measured on
+    an MI355X at the reference batch shape: action-mode step 15.5 -> 10.0 ms, perception-mode step 30.3 -> 21.2 ms)."""
     k = a.shape[0]
     groups = 128
     while groups > 1 and (k % groups or k // groups < 256):
