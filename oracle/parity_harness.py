@@ -113,9 +113,13 @@ def hip_forward(case, s_prop, s_final, device, anneal: float = 1.0, request: Opt
 
 def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32, action_dim=8, device=None,
                     tol: float = 1e-4, seed: int = 0, identity_context: bool = True, anneal: float = 1.0,
-                    precision: Optional[str] = None) -> Dict:
+                    precision: Optional[str] = None, param_hook=None) -> Dict:
+    """``param_hook(params)``: optional in-place edit of the seeded state dict (e.g. the reference's own initialisation
+    of the Jacobian head) before both sides see it."""
     device = device or torch.device("cuda:0")
     case = make_case(batch, height, width, rays, action_dim, seed, identity_context)
+    if param_hook is not None:
+        param_hook(case["params"])
     ref = oracle_forward(case, s_prop, s_final, anneal)
     req = RenderRequest(vis=True, sample_weights=True, per_sample=True)
     res, _, _ = hip_forward(case, s_prop, s_final, device, anneal, req, precision=precision)

@@ -35,6 +35,26 @@ def test_fused_forward_matches_oracle(device, cfg, precision):
     assert rep["ok"], rep
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_reference_initialisation_of_the_jacobian_head(device, precision):
+    """The reference initialises every Linear of the Jacobian head with N(0, 1e-4) weights AND biases
+    (action_decoder_jacobian.py:78-83), so at the start of action-mode training the head's activations are ~1e-3 and
+    its output ~1e-6: operands near the bottom of fp16's normal range.  The split-precision path must still meet the
+    bound there (dominant terms keep hi and lo exact enough; measured 5e-6 on the per-sample Jacobian)."""
+    import parity_harness as ph
+
+    def reference_init(params):
+        gen = torch.Generator().manual_seed(11)
+        for k, v in params.items():
+            if k.startswith("decoder.jacobian_head."):
+                params[k] = torch.randn(v.shape, generator=gen) * 1e-4
+
+    rep = ph.run_parity_case(device=device, tol=TOL, precision=precision, batch=2, height=16, width=16, rays=64,
+                             s_prop=32, s_final=32, param_hook=reference_init)
+    assert rep["ok"], rep
+    assert rep["errors"]["s_jacobian"] < 2e-5, rep["errors"]
+
+
 def test_fused_kernels_are_bit_reproducible(device):
     """Same inputs, two launches: every output must be bitwise identical (no atomics, no races)."""
     import parity_harness as ph
