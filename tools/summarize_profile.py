@@ -20,11 +20,12 @@ tag = f"{tag}_{prec}"
 MFMA_FLOP = 4096 if prec == "f32" else 32768      # v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16
 MFMA_CYCLES = 64 if prec == "f32" else 32
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+# the traced command may fork helpers, each leaving its own stats file: take the one that holds the fused kernels
+stats = max(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=lambda f: open(f).read().count("render_kernel"))
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
 PCODE = 1 if prec == "f16x2" else 0  # bench.py runs both precisions in one process: pick this one's instantiations
-KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PCODE}>": "proposal", "project_kernel": "project"}
+KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PCODE},": "proposal", "project_kernel": "project"}
 agg = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"{src}/pmc*/*/*_counter_collection.csv"):
