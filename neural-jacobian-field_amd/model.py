@@ -426,8 +426,8 @@ class Model(nn.Module):
                      verbose: bool = False) -> RenderingOutput:
         """model.py:527-628.  The fused path never materialises per-point feature tensors, so the whole frame
         is rendered in ONE pass (``patch_size`` is accepted for signature compatibility and ignored); the encoder
-        runs once instead of once per patch.  Colour-mapped depth/flow images (nerfstudio / torchvision helpers in the
-        reference) are left to the caller: ``depth_rgb``/``flow_rgb`` are None."""
+        runs once instead of once per patch.  ``depth_rgb`` / ``flow_rgb`` come from visualization.py (restated
+        nerfstudio / torchvision helpers, evaluated on the device)."""
         was_training = self.training
         self.eval()
         try:
@@ -436,10 +436,13 @@ class Model(nn.Module):
                                                              want_lists=False, want_vis=True, want_samples=False)
         finally:
             self.train(was_training)
+        from .visualization import apply_depth_colormap, flow_to_image
         smp = ray_bundle.samples_from_bins(bins)
         img = lambda t: t.reshape(t.shape[0], render_height, render_width, -1)
+        depth_raw, flow_raw = img(outs["depth"]), img(outs["flow"])
         return RenderingOutput(
-            rgb=img(outs["rgb"]), depth_raw=img(outs["depth"]), depth_rgb=None, flow_raw=img(outs["flow"]), flow_rgb=None,
+            rgb=img(outs["rgb"]), depth_raw=depth_raw, depth_rgb=apply_depth_colormap(depth_raw), flow_raw=flow_raw,
+            flow_rgb=flow_to_image(flow_raw.permute(0, 3, 1, 2)).permute(0, 2, 3, 1),
             ray_positions=img(outs["pos"]), ray_positions_warped=img(outs["pos_warped"]),
             action_features=img(outs["action_features"]), steps=img(((smp.starts + smp.ends) / 2).squeeze(-1)),
             weights=img(outs["weights"]))

@@ -152,6 +152,15 @@ def test_patch_render_equals_forward(model_and_golden):
     # (the MIOpen encoder is not bit-reproducible call to call, so compare to 1e-5 rather than bitwise)
     assert rel(ro.rgb.reshape(2, -1, 3), out.standard_output.rgb) < 1e-5
     assert rel(ro.action_features.reshape(2, h * w, -1), out.vis_output.action_features) < 1e-4
+    # colour-mapped outputs (model.py:598-626) are produced on the device
+    assert ro.depth_rgb.shape == (2, h, w, 3) and ro.depth_rgb.is_cuda and 0 <= ro.depth_rgb.min() and ro.depth_rgb.max() <= 1
+    assert ro.flow_rgb.shape == (2, h, w, 3) and ro.flow_rgb.dtype == torch.uint8 and ro.flow_rgb.is_cuda
+    # and the rendered Jacobian field feeds the reference's sensitivity colouring without leaving the device
+    from neural_jacobian_field_amd.inference import jacobian_color_map as cm
+    sens = cm.compute_joint_sensitivity(ro.action_features, cam.trgt_extrinsics[:, None, None, None])
+    assert sens.shape == (2, 8, h, w) and sens.is_cuda and sens.min() >= 0 and sens.max() <= 1
+    image = cm.visualize_joint_sensitivity(sens, torch.tensor(cm.JACOBIAN_COLORMAP["model_allegro"]).t())
+    assert image.shape == (2, h, w, 3) and image.dtype.name == "uint8"
 
 
 def test_geometry_and_samplers_vs_reference(dev, golden):
