@@ -95,3 +95,21 @@ def allreduce_gradients(parameters, average: bool = True) -> None:
         n = p.grad.numel()
         p.grad.copy_(flat[off:off + n].view_as(p.grad))
         off += n
+
+
+def data_parallel_step(loss_fn, parameters: Sequence[torch.nn.Parameter], optimizer: torch.optim.Optimizer) -> torch.Tensor:
+    """One optimiser step under data parallelism (BASELINE config 4; reference: Lightning DDP, train.py:67-79): every
+    rank evaluates ``loss_fn()`` on ITS scenes / ray shard (e.g. ``lambda: wrapper.training_step(batch)``), gradients
+    are averaged in one flattened RCCL all-reduce, every rank applies the identical update.  Returns the loss
+    averaged over ranks (what rank 0 would log)."""
+    optimizer.zero_grad(set_to_none=True)
+    loss = loss_fn()
+    loss.backward()
+    parameters = list(parameters)
+    allreduce_gradients(parameters, average=True)
+    optimizer.step()
+    mean = loss.detach().clone().reshape(1)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(mean, op=dist.ReduceOp.SUM)
+        mean /= dist.get_world_size()
+    return mean[0]

@@ -149,14 +149,29 @@ def _gloo_worker(rank, world, port, tmp):
         q.grad = torch.full_like(q, float(rank + 1))
     par.allreduce_gradients(lin.parameters())
     grads_ok = all(torch.allclose(q.grad, torch.full_like(q, (1 + world) / 2)) for q in lin.parameters())
+    # data_parallel_step: two ranks on different halves of a batch == one process on the whole batch
+    torch.manual_seed(7)
+    net, full = torch.nn.Linear(6, 2), torch.nn.Linear(6, 2)
+    full.load_state_dict(net.state_dict())
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+    half = slice(rank * 4, rank * 4 + 4)
+    opt, opt_full = torch.optim.SGD(net.parameters(), lr=0.1), torch.optim.SGD(full.parameters(), lr=0.1)
+    mean_loss = par.data_parallel_step(lambda: torch.nn.functional.mse_loss(net(x[half]), y[half]), net.parameters(), opt)
+    opt_full.zero_grad()
+    loss_full = torch.nn.functional.mse_loss(full(x), y)
+    loss_full.backward()
+    opt_full.step()
+    step_ok = (all(torch.allclose(a, b, atol=1e-6) for a, b in zip(net.parameters(), full.parameters()))
+               and abs(mean_loss - loss_full) < 1e-6)
     ok = (abs(losses["loss/rgb"] - ref_rgb) < 1e-6 and abs(losses["loss/flow_loss"] - ref_flow) < 1e-6
-          and torch.equal(frame, ref_depth) and grads_ok)
+          and torch.equal(frame, ref_depth) and grads_ok and step_ok)
     open(os.path.join(tmp, f"ok{rank}"), "w").write(str(bool(ok)))
     dist.destroy_process_group()
 
 
 def test_ray_sharding_world_size_2_gloo(tmp_path):
-    """Ray-sharded loss / depth-clip / frame gather over 2 gloo ranks equals the unsharded computation."""
+    """Ray-sharded loss / depth-clip / frame gather / gradient bucket / optimiser step over 2 gloo ranks equal the
+    unsharded computation."""
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -12,11 +12,19 @@ from neural_jacobian_field_amd import synthetic
 from neural_jacobian_field_amd.config import model_cfg_from_dict
 from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
 
-dev = torch.device("cuda:0")
+# BASELINE config 4: `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py <mode>`
+# runs one rank per GPU, each on its own scenes, gradients averaged in one RCCL all-reduce per step
+WORLD, RANK, LOCAL = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+torch.cuda.set_device(LOCAL)
+dev = torch.device("cuda", LOCAL)
+if WORLD > 1:
+    import torch.distributed as dist
+    os.environ["NCCL_DEBUG"] = "WARN"
+    dist.init_process_group("nccl", device_id=dev)
 if os.environ.get("NJF_MIOPEN_FIND"):
     torch.backends.cudnn.benchmark = True
 B, H, W, R, S = 7, 256, 256, 256, 64
-case = ph.make_case(B, H, W, R, 8, seed=0)
+case = ph.make_case(B, H, W, R, 8, seed=RANK)
 model = Model(model_cfg_from_dict({"action_dim": 8, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
                                    "action_decoder": {"name": "jacobian_mlp"}}))
 sd = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", 8), seed=0)
@@ -39,9 +47,11 @@ from neural_jacobian_field_amd import model_wrapper as mw
 from neural_jacobian_field_amd.model import ModelTarget
 ptarget = ModelTarget(rgb=d(torch.rand(B, R, 3)), depth=d(torch.rand(B, R, 1) + 0.5), optical_flow=None, visible_mask=None)
 
-def step(i):
-    model.step_before_iter(i)
-    opt.zero_grad(set_to_none=True)
+from neural_jacobian_field_amd.parallel import data_parallel_step
+trainable = [p for p in model.parameters() if p.requires_grad]
+
+
+def compute_loss():
     out = model.forward(cam, rin, rob)
     if MODE == "action":
         loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, target)
@@ -49,8 +59,12 @@ def step(i):
         tr = out.training_output
         loss = (mw.rgb_loss(out, ptarget) + mw.depth_loss(out, ptarget) + mw.interlevel_loss(tr.weights_list, tr.ray_samples_list)
                 + 0.01 * mw.distortion_loss(tr.weights_list, tr.ray_samples_list))
-    loss.backward()
-    opt.step()
+    return loss
+
+
+def step(i):
+    model.step_before_iter(i)
+    loss = data_parallel_step(compute_loss, trainable, opt)
     model.step_after_iter(i)
     return loss
 
@@ -61,6 +75,11 @@ N = 10
 for i in range(N):
     step(3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
-print(json.dumps({"training_step_ms": round(1e3 * dt, 2), "rays_per_step": B * R, "samples": f"{S}+{S}",
-                  "train_rays_per_s": round(B * R / dt, 1), "mode": {"action": "action (Jacobian head only), encoder fwd included",
+if WORLD > 1:
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+if RANK == 0:
+  print(json.dumps({"training_step_ms": round(1e3 * dt, 2), "n_gpus": WORLD, "rays_per_step": WORLD * B * R, "samples": f"{S}+{S}",
+                  "train_rays_per_s": round(WORLD * B * R / dt, 1), "mode": {"action": "action (Jacobian head only), encoder fwd included",
                            "perception": "perception (all parameters), encoder fwd+bwd included"}[MODE]}))
