@@ -9,7 +9,7 @@ Reference: ``model_components/resnet_fc.py:11-18`` (MlpCfg), ``models/decoder/ac
 from __future__ import annotations
 
 from dataclasses import dataclass, field, fields, is_dataclass
-from typing import Any, Dict, Literal, Optional, Tuple, Union, get_args, get_origin, get_type_hints
+from typing import Any, Dict, Literal, Optional, Tuple, Union, get_origin, get_type_hints
 
 
 @dataclass

@@ -7,7 +7,7 @@ torch ops on the same device (plumbing, launched once per frame).
 
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

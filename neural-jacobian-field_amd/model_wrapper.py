@@ -8,7 +8,7 @@ Everything here is host-side indexing / scalar reductions on the device the batc
 
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.nn.functional as F

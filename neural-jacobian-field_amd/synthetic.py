@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 import zlib
-from typing import Dict, Sequence, Tuple
+from typing import Dict, Tuple
 
 import torch
 

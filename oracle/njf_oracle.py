@@ -27,7 +27,6 @@ the reference's state-dict names (``decoder.density_head.lin_in.weight`` ...).
 
 from __future__ import annotations
 
-import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
