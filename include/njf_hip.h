@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 2
+#define NJF_ABI_VERSION 3
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -132,11 +132,12 @@ int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kin
 /* G[b,p,n] = sum_k F[b,k,p] * wz[k,n] + bz[n];  F is the encoder output [B,512,Hf,Wf] (NCHW),
  * wz [512,N] (k-major, as written by njf_pack_resnetfc*), bz [N], out [B, Hf*Wf, N].  Because bilinear interpolation is linear with weights
  * summing to 1, lin_z(grid_sample(F)) == grid_sample(G): this moves resnet_fc.py:138-141's
- * 3 x (512->128) GEMMs from per-point to per-texel. */
+ * 3 x (512->128) GEMMs from per-point to per-texel.  `precision` selects the MFMA path as in the fused kernels
+ * (operands stay fp32 in memory; NJF_PRECISION_F16X2 splits them on the fly). */
 int njf_project_features(const float* feats, const float* wz, const float* bz, int batch, int hw, int n,
-                         float* out, void* stream);
+                         float* out, int precision, void* stream);
 int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, const float* bz, int batch, int hw, int n,
-                            float* out, void* stream);
+                            float* out, int precision, void* stream);
 
 /* ---- ray generation: rendering/geometry.py:117-134 + :170-203 ------------------------------ */
 /* coords [B,R,2] normalised pixel centres (NULL -> full H x W grid of get_pixel_coordinates),

@@ -253,18 +253,108 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
   }
 }
 
+// Split-precision variant (PREC_F16X2): one wave = 64 texels (two A tiles) x 32*NJF_PROJ_NT channels, K swept 16
+// at a time with v_mfma_f32_32x32x16_f16.  Both operands are fp32 in memory and split x = hi + lo on the fly
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate: same accuracy class as the fp32 kernel at 3/16 of its matrix time).
+// Lane (j, kh) supplies k = 16*t + 8*kh .. +7 of texel row j (A) / output channel column j (B).
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(x[i] - (float)h);
+  }
+}
+
+// channel tiles per wave: 2 keeps accumulators + the double-buffered raw operands inside 256 VGPRs at two waves per
+// SIMD (measured on C2: NT=2 0.119 ms, NT=3 0.30 ms, NT=4 0.79 ms with spills; the fp32-MFMA kernel 0.29 ms)
+#ifndef NJF_PROJ_NT
+#define NJF_PROJ_NT 2
+#endif
+__global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __restrict__ feats, const float* __restrict__ wz,
+                                                            const float* __restrict__ bz, int hw, int n, int ld,
+                                                            float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.z;
+  const int p0 = (blockIdx.x * 4 + wave) * 64;
+  const int n0 = blockIdx.y * (32 * NJF_PROJ_NT);
+  if (p0 >= hw) return;
+  const float* fa[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) fa[a] = feats + (size_t)b * 512 * hw + min(p0 + 32 * a + j, hw - 1);
+  int nn[NJF_PROJ_NT];
+#pragma unroll
+  for (int t = 0; t < NJF_PROJ_NT; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
+  f32x16 acc[2][NJF_PROJ_NT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < NJF_PROJ_NT; ++t) acc[a][t] = (f32x16)(0.f);
+  // raw fp32 operands of K-step t+1 are requested before the split + MFMAs of step t (register double buffer): the
+  // operands come straight from global memory / L2, so one K-step of latency must be in flight at all times
+  float xa[2][8], xb[NJF_PROJ_NT][8];
+  auto fetch = [&](int k0) {
+    const int kb = k0 + 8 * kh;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xa[a][i] = fa[a][(size_t)(kb + i) * hw];
+#pragma unroll
+    for (int t = 0; t < NJF_PROJ_NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xb[t][i] = wz[(size_t)(kb + i) * ld + nn[t]];
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < 512; k0 += 16) {
+    f16x8 ah[2], al[2], bh[NJF_PROJ_NT], bl[NJF_PROJ_NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) split8(xa[a], ah[a], al[a]);
+#pragma unroll
+    for (int t = 0; t < NJF_PROJ_NT; ++t) split8(xb[t], bh[t], bl[t]);
+    if (k0 + 16 < 512) fetch(k0 + 16);
+#pragma unroll
+    for (int t = 0; t < NJF_PROJ_NT; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[t], acc[a][t], 0, 0, 0);
+        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[t], acc[a][t], 0, 0, 0);
+        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[t], acc[a][t], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < NJF_PROJ_NT; ++t) {
+    const int c = n0 + 32 * t + j;
+    if (c >= n) continue;
+    const float bias = bz[c];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = p0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < hw) out[((size_t)b * hw + row) * n + c] = acc[a][t][r] + bias;
+      }
+  }
+}
+
 extern "C" int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, const float* bz, int batch, int hw,
-                                       int n, float* out, void* stream) {
+                                       int n, float* out, int precision, void* stream) {
   if (!feats || !wz || !bz || !out) return NJF_E_NULL;
   if (batch < 1 || hw < 1 || n < 1 || wz_ld < n) return NJF_E_SHAPE;
-  dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
-  project_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(feats, wz, bz, hw, n, wz_ld, out);
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (precision == NJF_PRECISION_F16X2) {
+    dim3 grid((hw + 255) / 256, (n + 32 * NJF_PROJ_NT - 1) / (32 * NJF_PROJ_NT), batch);
+    project_kernel_f16x2<<<grid, 256, 0, (hipStream_t)stream>>>(feats, wz, bz, hw, n, wz_ld, out);
+  } else {
+    dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
+    project_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(feats, wz, bz, hw, n, wz_ld, out);
+  }
   return launch_status();
 }
 
 extern "C" int njf_project_features(const float* feats, const float* wz, const float* bz, int batch, int hw, int n,
-                                    float* out, void* stream) {
-  return njf_project_features_ld(feats, wz, n, bz, batch, hw, n, out, stream);
+                                    float* out, int precision, void* stream) {
+  return njf_project_features_ld(feats, wz, n, bz, batch, hw, n, out, precision, stream);
 }
 
 // =============================================================================================

@@ -116,12 +116,12 @@ class _HoistCache:
         self.features = None
         self.gmap = None
 
-    def get(self, features: torch.Tensor, wversion, wz: torch.Tensor, bz: torch.Tensor) -> torch.Tensor:
-        key = (features._version, tuple(features.shape), wversion)
+    def get(self, features: torch.Tensor, wversion, wz: torch.Tensor, bz: torch.Tensor, precision: str) -> torch.Tensor:
+        key = (features._version, tuple(features.shape), wversion, precision)
         if features is not self.features or key != self.key:
             b, _, hf, wf = features.shape
             gmap = torch.empty(b, hf, wf, wz.shape[1], dtype=torch.float32, device=features.device)
-            hip.project_features(features.contiguous(), wz, bz, gmap)
+            hip.project_features(features.contiguous(), wz, bz, gmap, precision=precision)
             self.key, self.features, self.gmap = key, features, gmap
         return self.gmap
 
@@ -167,7 +167,7 @@ class DensityDecoderMlp(nn.Module):
 
     def hoisted_map(self, features: torch.Tensor) -> torch.Tensor:
         self.packed()
-        return self._hoist.get(features, self._packed_version, self._wz, self._bz)
+        return self._hoist.get(features, self._packed_version, self._wz, self._bz, self.precision)
 
     # ---- reference API -----------------------------------------------------------------
     @torch.no_grad()
@@ -259,7 +259,7 @@ class ActionDecoderJacobian(ActionDecoder):
 
     def hoisted_map(self, features: torch.Tensor) -> torch.Tensor:
         self.packed()
-        return self._hoist.get(features, self._packed_version, self._wz, self._bz)
+        return self._hoist.get(features, self._packed_version, self._wz, self._bz, self.precision)
 
     def _points(self, xyz_flat, dirs_flat, enc: PixelEncoding, with_jacobian: bool, want: Dict[str, bool]):
         b, n = xyz_flat.shape[:2]

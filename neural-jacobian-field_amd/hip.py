@@ -85,8 +85,8 @@ _SIGNATURES = {
     "njf_pack_resnetfc_ld": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_color_head": ([C.POINTER(ColorHeadWeights), _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_linear": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp], C.c_int),
-    "njf_project_features": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
-    "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_project_features": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
+    "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
                               _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.POINTER(ActivationDump), C.c_int, _vp],
@@ -219,13 +219,15 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], kind: int, w
                                           _stream()))
 
 
-def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor) -> None:
+def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor,
+                     precision: Optional[str] = None) -> None:
     """feats [B,512,Hf,Wf]; wz [512,N]; bz [N]; out [B,Hf,Wf,N]."""
     b, k, hf, wf = feats.shape
     n = wz.shape[1]
     if k != 512 or wz.shape[0] != 512 or tuple(out.shape) != (b, hf, wf, n):
         raise ValueError("njf_hip: project_features shape mismatch")
-    _check(load_library().njf_project_features_ld(_ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out), _stream()))
+    _check(load_library().njf_project_features_ld(_ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out),
+                                                  precision_code(precision), _stream()))
 
 
 # --------------------------------------------------------------------------------------

@@ -111,7 +111,7 @@ class FusedRenderer:
         """Encoder output [B,512,Hf,Wf] -> hoisted channels-last map [B,Hf,Wf,384*(n_prop+2)]."""
         b, _, hf, wf = features.shape
         gmap = torch.empty(b, hf, wf, self.gstride, dtype=torch.float32, device=self.device)
-        hip.project_features(features.contiguous(), self.wz, self.bz, gmap)
+        hip.project_features(features.contiguous(), self.wz, self.bz, gmap, precision=self.precision)
         return gmap
 
     # ------------------------------------------------------------------ per ray batch

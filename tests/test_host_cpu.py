@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 2
+    assert lib.njf_abi_version() == 3
 
 
 def test_argument_validation_happens_before_any_launch(built):

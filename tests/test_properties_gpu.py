@@ -125,6 +125,26 @@ def test_sampler_ops_randomised_vs_oracle(dev):
         assert (out_bins[:, 1:] >= out_bins[:, :-1]).all()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("shape", [(1, 16, 16, 384), (2, 9, 13, 832), (1, 5, 7, 40)])   # ragged texel counts / channel counts
+def test_feature_projection_vs_float64(dev, precision, shape):
+    """The lin_z hoist G = F . Wz + bz (resnet_fc.py:138-141 moved to texels) against a float64 contraction; both MFMA
+    paths must sit at fp32 rounding level (the split path splits BOTH operands on the fly)."""
+    from neural_jacobian_field_amd import hip
+    b, hf, wf, n = shape
+    g = torch.Generator().manual_seed(hf * 100 + n)
+    feats = (torch.randn(b, 512, hf, wf, generator=g) * 3).to(dev)
+    wz = (torch.randn(512, n, generator=g) * 0.05).to(dev)
+    bz = torch.randn(n, generator=g).to(dev)
+    out = torch.empty(b, hf, wf, n, device=dev)
+    hip.project_features(feats, wz, bz, out, precision=precision)
+    ref = torch.einsum("bkhw,kn->bhwn", feats.double(), wz.double()) + bz.double()
+    err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+    f32 = torch.einsum("bkhw,kn->bhwn", feats, wz) + bz
+    floor = ((f32.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < max(2e-6, 4 * floor), (err, floor)
+
+
 def test_binding_error_behaviour(dev):
     from neural_jacobian_field_amd import hip
     z = torch.zeros(2, 300, device=dev)
