@@ -302,3 +302,23 @@ def test_flow_and_depth_colour_maps_are_well_formed():
     out = apply_depth_colormap(d)
     assert out.shape == (2, 5, 6, 3)
     assert torch.allclose(apply_depth_colormap(d, accumulation=torch.zeros_like(d)), torch.ones_like(out))
+
+
+def test_header_is_plain_c(tmp_path, built):
+    """include/njf_hip.h is the drop-in boundary: it must compile as C99 and as C++ with no other headers, and a C
+    translation unit that takes the address of every declared entry point must link against the library."""
+    import subprocess
+    header = os.path.join(ROOT, "include", "njf_hip.h")
+    for lang, std in (("c", "c99"), ("c++", "c++17")):
+        subprocess.run(["gcc", "-x", lang, f"-std={std}", "-fsyntax-only", "-Wall", "-Werror", header], check=True)
+    names = sorted(set(re.findall(r"\b(njf_[a-z0-9_]+)\s*\(", open(header).read())))
+    src = tmp_path / "link_check.c"
+    src.write_text('#include "njf_hip.h"\n#include <stdio.h>\nint main(void) {\n  const void* fns[] = {'
+                   + ", ".join(f"(const void*)&{n}" for n in names)
+                   + '};\n  printf("%d %d\\n", (int)(sizeof(fns) / sizeof(fns[0])), njf_abi_version());\n  return 0;\n}\n')
+    lib_dir = os.path.join(ROOT, "neural-jacobian-field_amd")
+    exe = tmp_path / "link_check"
+    subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
+                    "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == len(names) and int(out[1]) == 3
