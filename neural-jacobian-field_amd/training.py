@@ -198,6 +198,12 @@ def color_head_backward(p: Dict[str, torch.Tensor], d_rgb: torch.Tensor, rgb: to
     return grads, d1 @ p["0.weight"][:, :15]
 
 
+def trunc_exp_backward_factor(sigma: torch.Tensor) -> torch.Tensor:
+    """d density / d pre-activation of ``trunc_exp(x - 1)`` from the density itself (activations.py:24-29): the reference
+    back-propagates g * exp(clamp(x - 1, -15, 15)); with sigma = exp(x - 1) that is sigma clamped to [e^-15, e^15]."""
+    return sigma.clamp(min=math.exp(-15.0), max=math.exp(15.0))
+
+
 class FieldFunction(torch.autograd.Function):
     """Perception-mode training (model_wrapper.py:117-146: every parameter trains, the losses read rgb, depth and the
     per-level weights).  Outputs the per-sample fields the compositing consumes -- final density [B,R,S,1], colour
@@ -229,8 +235,7 @@ class FieldFunction(torch.autograd.Function):
         d_feats = torch.zeros_like(feats_flat) if ctx.needs_input_grad[1] else None
         out_grads = [None] * len(params)
 
-        def clamp_exp(sigma):  # trunc_exp backward, activations.py:31-34: g * exp(clamp(x - 1, -15, 15)), sigma = exp(x - 1)
-            return sigma.clamp(min=math.exp(-15.0), max=math.exp(15.0))
+        clamp_exp = trunc_exp_backward_factor
 
         if g_sigma is not None or g_color is not None:
             pts = outs["density"].numel()

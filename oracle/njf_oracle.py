@@ -354,10 +354,25 @@ def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_l
     return _affine(params, "lin_out", torch.relu(h))
 
 
+class _TruncExp(torch.autograd.Function):
+    """NJF/model_components/activations.py:13-29 (TruncatedExponential): exp forward, and a backward whose exponent is
+    clamped to [-15, 15] -- the gradient differs from exp's own wherever |x| > 15."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, min=-15, max=15))
+
+
 def trunc_exp_density(pre: Tensor) -> Tensor:
-    """NJF/model_components/activations.py:13-38: forward of trunc_exp(x - 1) is exp(x - 1) (fp32 cast only
-    under autocast, which the reference path never enables)."""
-    return torch.exp(pre - 1)
+    """NJF/model_components/activations.py:32-38: init_density_activation("trunc_exp") = trunc_exp(x - 1) (fp32 cast
+    only under autocast, which the reference path never enables)."""
+    return _TruncExp.apply(pre - 1)
 
 
 # --------------------------------------------------------------------------------------
