@@ -362,7 +362,21 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h[m][4 * q + e] = fmaf(v[t][m][q][e], w[t0 + t], h[m][4 * q + e]);
+          for (int e = 0; e < 4; ++e) {
+            // Texels 1..3: one v_fmac per value, written as asm so that the SLP vectoriser cannot pair them into
+            // v_pk_fma_f32 -- the packed form needs every bilinear weight as a {w, w} register pair, which the
+            // allocator materialises per use site and spills (252 -> 70 spilled VGPRs in the render kernel, 156 -> 11
+            // in the proposal kernel; 10 % of the frame time).  Texel 0 stays a compiler-visible fmaf: h was just
+            // written by MFMAs, and the MFMA-write -> VALU-read wait states are only inserted for instructions the
+            // hazard recogniser can see, never for inline asm (the asm then reads registers last written by VALU).
+            if (t0 + t == 0) {
+              h[m][4 * q + e] = fmaf(v[t][m][q][e], w[0], h[m][4 * q + e]);
+            } else {
+              float acc = h[m][4 * q + e];
+              asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v[t][m][q][e]), "v"(w[t0 + t]));
+              h[m][4 * q + e] = acc;
+            }
+          }
 #pragma unroll
     for (int m = 0; m < MB; ++m) asm volatile("" : "+v"(h[m]) : : "memory");
   }

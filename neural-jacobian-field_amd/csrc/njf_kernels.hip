@@ -701,7 +701,9 @@ struct RenderArgs {
   NjfRenderOutputs out;
 };
 
-template <int JKIND, int PREC, int DUMP = 0>
+// AF: composite the per-sample action features (sum_s w J, 16 more accumulators per lane) -- a compile-time switch
+// because the extra live registers cost ~80 spilled VGPRs in the frames that do not ask for them
+template <int JKIND, int PREC, int DUMP = 0, bool AF = true>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   constexpr bool WITH_J = JKIND != 0;
   constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
@@ -742,7 +744,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   float acc_p[3] = {0.f, 0.f, 0.f}, acc_pw[3] = {0.f, 0.f, 0.f};
   float tmin = 3.0e38f, tmax = -3.0e38f;
   f32x16 acc_j = (f32x16)(0.f);
-  const bool want_af = WITH_J && a.out.action_features != nullptr;
+  const bool want_af = AF && WITH_J && a.out.action_features != nullptr;
 
   for (int t = 0; t < tiles; ++t) {
     const int s = t * 32 + j;
@@ -1185,14 +1187,19 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
     if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F32, 2>, a, n, s);
     return launch_fused(render_kernel<0, PREC_F32, 2>, a, n, s);
   }
+  const bool af = with_j && out->action_features != nullptr;
   if (precision == NJF_PRECISION_F16X2) {
-    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F16X2>, a, n, s);
-    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F16X2>, a, n, s);
-    return launch_fused(render_kernel<0, PREC_F16X2>, a, n, s);
+    if (jacobian_kind == NJF_JACOBIAN_MLP)
+      return af ? launch_fused(render_kernel<1, PREC_F16X2, 0, true>, a, n, s) : launch_fused(render_kernel<1, PREC_F16X2, 0, false>, a, n, s);
+    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER)
+      return af ? launch_fused(render_kernel<2, PREC_F16X2, 0, true>, a, n, s) : launch_fused(render_kernel<2, PREC_F16X2, 0, false>, a, n, s);
+    return launch_fused(render_kernel<0, PREC_F16X2, 0, false>, a, n, s);
   }
-  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F32>, a, n, s);
-  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F32>, a, n, s);
-  return launch_fused(render_kernel<0, PREC_F32>, a, n, s);
+  if (jacobian_kind == NJF_JACOBIAN_MLP)
+    return af ? launch_fused(render_kernel<1, PREC_F32, 0, true>, a, n, s) : launch_fused(render_kernel<1, PREC_F32, 0, false>, a, n, s);
+  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER)
+    return af ? launch_fused(render_kernel<2, PREC_F32, 0, true>, a, n, s) : launch_fused(render_kernel<2, PREC_F32, 0, false>, a, n, s);
+  return launch_fused(render_kernel<0, PREC_F32, 0, false>, a, n, s);
 }
 
 extern "C" int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
