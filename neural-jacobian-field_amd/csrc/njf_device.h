@@ -368,7 +368,10 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
             // allocator materialises per use site and spills (252 -> 70 spilled VGPRs in the render kernel, 156 -> 11
             // in the proposal kernel; 10 % of the frame time).  Texel 0 stays a compiler-visible fmaf: h was just
             // written by MFMAs, and the MFMA-write -> VALU-read wait states are only inserted for instructions the
-            // hazard recogniser can see, never for inline asm (the asm then reads registers last written by VALU).
+            // hazard recogniser can see, never for inline asm.  Every register is therefore first read by a visible
+            // instruction, and its asm updates depend on that result.  (A cheaper "touch one register per
+            // accumulator block" was tried and is WRONG: the scheduler moves the other registers' asm above the
+            // touch -- caught by the transformer-head golden tests.)
             if (t0 + t == 0) {
               h[m][4 * q + e] = fmaf(v[t][m][q][e], w[0], h[m][4 * q + e]);
             } else {
