@@ -210,11 +210,11 @@ extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out,
 }
 
 // =============================================================================================
-// feature projection  G[b,p,n] = sum_k F[b,k,p] * wz[k*ld+n] + bz[n]       (fp32 MFMA)
+// feature projection  G[b,p,n] = sum_k F[b,k,p] * wz[k*ld+n] + bz[n]   (exact-fp32 MFMA kernel; split variant below)
 // =============================================================================================
 // One wave: 32 texels x 128 channels, K = 512 swept two at a time straight from global memory
 // (A: 32 consecutive texels of one channel plane = one 128-B line; B: 32 consecutive output
-// channels of one k row).  Per-image cost (19 GFLOP at 256^2) is ~1% of a frame.
+// channels of one k row).  Per-image cost: 19 GFLOP at 256^2.
 __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ feats, const float* __restrict__ wz,
                                                       const float* __restrict__ bz, int hw, int n, int ld,
                                                       float* __restrict__ out) {
