@@ -67,18 +67,36 @@ struct WeightStream {
   int total;       // chunks over the whole workgroup lifetime
   int idx;         // next chunk to consume
   int in_pass;     // idx % per_pass of the chunk being prefetched
+  // DMA job of the chunk being prefetched: NJF_DMA_ROUNDS rounds of 4 KiB, issued one at a time between the MFMA
+  // groups of the chunk being consumed (dma_round) instead of as one burst behind the barrier: the burst -- 8 waves x
+  // 8 x 1 KiB through the CU's 64 B/clk vector-memory path, all at the same moment -- stalled every wave ~1,150
+  // cycles per chunk at the issue of its own loads (17 % of the render kernel, measured with s_memtime stamps).
+  const float* dma_src;  // this lane's source of round 0
+  float* dma_dst;        // this wave's LDS destination of round 0
+  int dma_next;          // 0 = job pending, NJF_DMA_ROUNDS = issued (or nothing to prefetch)
 };
+#define NJF_DMA_ROUNDS (NJF_CHUNK / (NJF_THREADS * 4))
 
-__device__ __forceinline__ void dma_chunk(const float* __restrict__ src, int buf, int wave, int lane) {
-  // 256 threads x 16 B = 4 KiB per round, 8 rounds per 32 KiB chunk.  LDS destination is
-  // wave-uniform base + lane*16 (hardware), global source is per lane.
-  float* dst = njf_lds + buf * NJF_CHUNK + wave * 256;
-  const float* s = src + wave * 256 + lane * 4;
+__device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
+  // 256 threads x 16 B = 4 KiB per round.  LDS destination is wave-uniform base + lane*16 (hardware), global source
+  // is per lane.
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st.dma_src + r * NJF_THREADS * 4),
+                                   (__attribute__((address_space(3))) void*)(st.dma_dst + r * NJF_THREADS * 4), 16, 0, 0);
+}
+
+// Issue the whole pending job at once (chunk shapes that do not interleave; start of the kernel).
+__device__ __forceinline__ void stream_flush(WeightStream& st) {
+  if (st.dma_next == 0) {
 #pragma unroll
-  for (int r = 0; r < NJF_CHUNK / (NJF_THREADS * 4); ++r) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + r * NJF_THREADS * 4),
-                                     (__attribute__((address_space(3))) void*)(dst + r * NJF_THREADS * 4), 16, 0, 0);
+    for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
+    st.dma_next = NJF_DMA_ROUNDS;
   }
+}
+
+__device__ __forceinline__ void dma_job(WeightStream& st, const float* __restrict__ src, int buf, int wave, int lane) {
+  st.dma_src = src + wave * 256 + lane * 4;
+  st.dma_dst = njf_lds + buf * NJF_CHUNK + wave * 256;
+  st.dma_next = 0;
 }
 
 __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
@@ -88,19 +106,26 @@ __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, i
   st.total = per_pass * passes;
   st.idx = 0;
   st.in_pass = 0;
-  dma_chunk(g, 0, wave, lane);
+  dma_job(st, g, 0, wave, lane);
+  stream_flush(st);
 }
 
+// One barrier: after it the current chunk is resident and the other buffer is free (all of its readers passed the
+// barrier); the job that refills it is set up here and issued by the consumer of the current chunk, round by round.
 __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, int lane) {
 #ifdef NJF_ABLATE_BARRIER  // experiment builds only: weights stay whatever is in LDS (results are garbage)
   return njf_lds + (st.idx++ & 1) * NJF_CHUNK;
 #endif
+  stream_flush(st);  // rounds the previous consumer did not issue (chunk shapes without interleaving)
   __syncthreads();
   const float* cur = njf_lds + (st.idx & 1) * NJF_CHUNK;
   st.idx += 1;
   st.in_pass += 1;
   if (st.in_pass == st.per_pass) st.in_pass = 0;
-  if (st.idx < st.total) dma_chunk(st.g + (size_t)st.in_pass * NJF_CHUNK, st.idx & 1, wave, lane);
+  // The last chunk of a workgroup has nothing to prefetch.  Its consumer is always a lin_out-shaped chunk (MBO = 1),
+  // which only ever calls stream_flush; the interleaving consumers (mma_chunk with MBO = 4) issue their 8 rounds
+  // unconditionally and are never last.
+  if (st.idx < st.total) dma_job(st, st.g + (size_t)st.in_pass * NJF_CHUNK, st.idx & 1, wave, lane);
   return cur;
 }
 
@@ -109,8 +134,12 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
 // [kb][q][mb][lane][e]).  RELU applies max(.,0) to the B operand on the fly.
 // ------------------------------------------------------------------------------------------
 template <int PREC, int MBO, int NKB, int KB0, bool RELU, int KBI>
-__device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane, const f32x16 (&in)[KBI],
-                                          f32x16 (&out)[MBO]) {
+__device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restrict__ wl, int lane,
+                                          const f32x16 (&in)[KBI], f32x16 (&out)[MBO]) {
+  // DMA rounds of the next chunk ride between the MFMA groups of this one when there are exactly NJF_DMA_ROUNDS
+  // groups (the 128-wide layers: MBO = 4, NKB = 2); every other shape issues the job up front.
+  constexpr bool SPREAD = MBO == 4 && NKB == 2 && NJF_DMA_ROUNDS == 8;
+  if constexpr (!SPREAD) stream_flush(st);
   if constexpr (PREC == PREC_F32) {
     // hipcc schedules this fully unrolled body as groups of 4*MBO MFMAs and re-issues each group's ds_read_b128s
     // two MFMAs (128 cycles) before the registers are needed, which covers the LDS latency; a hand-pipelined
@@ -123,6 +152,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
         f32x4 a[MBO];
 #pragma unroll
         for (int m = 0; m < MBO; ++m) a[m] = *(const f32x4*)(base + ((kb * 4 + q) * MBO + m) * 256);
+        if constexpr (SPREAD) dma_issue(st, kb * 4 + q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float b = in[KB0 + kb][q * 4 + e];
@@ -167,6 +197,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
 #pragma unroll
             for (int i = 0; i < 4; ++i) n[i] = base[((u + 1) * 4 + i) * 64];
           }
+          if constexpr (SPREAD) dma_issue(st, u);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mm = 0; mm < 2; ++mm) {
@@ -234,6 +265,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ wl, int lane
       }
     }
   }
+  if constexpr (SPREAD) st.dma_next = NJF_DMA_ROUNDS;
 }
 
 // acc[m][r] (+)= bias[16*MB*hh + 16*m + r]   (bias in LDS, logical order)
@@ -501,7 +533,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
   }
   {
     const float* wl = stream_step(st, wave, lane);
-    mma_chunk<PREC, 4, 2, 0, false, 2>(wl, lane, pe, h);  // lin_in (bias folded into slot 63)
+    mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
   for (int blk = 0; blk < 5; ++blk) {
     if (blk < 3) add_hoisted_latent<4>(gz + blk * 128, g, hh, h);
@@ -510,28 +542,28 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     bias_init<4, true>(bl, hh, net);
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 0, true, 4>(wl, lane, h, net);
+      mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, h, net);
     }
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 2, true, 4>(wl, lane, h, net);
+      mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, h, net);
     }
     if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
     bias_init<4, false>(bl + 128, hh, h);
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 0, true, 4>(wl, lane, net, h);
+      mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, net, h);
     }
     {
       const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 2, true, 4>(wl, lane, net, h);
+      mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, net, h);
     }
   }
   if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h);
   bias_init<1, true>(bias + 1280, hh, out);
   {
     const float* wl = stream_step(st, wave, lane);
-    mma_chunk<PREC, 1, 4, 0, true, 4>(wl, lane, h, out);
+    mma_chunk<PREC, 1, 4, 0, true, 4>(st, wl, lane, h, out);
   }
 }
 
@@ -567,11 +599,11 @@ __device__ __forceinline__ void color_tile(WeightStream& st, const float* __rest
   f32x16 a[2], b[2];
   a[0] = (f32x16)(0.f);
   a[1] = (f32x16)(0.f);
-  mma_chunk<PREC, 2, 1, 0, false, 1>(wl, lane, cin, a);
+  mma_chunk<PREC, 2, 1, 0, false, 1>(st, wl, lane, cin, a);
   bias_init<2, true>(bias, hh, b);
-  mma_chunk<PREC, 2, 2, 0, true, 2>(wl + 2048, lane, a, b);
+  mma_chunk<PREC, 2, 2, 0, true, 2>(st, wl + 2048, lane, a, b);
   bias_init<1, true>(bias + 64, hh, rgb);
-  mma_chunk<PREC, 1, 2, 0, true, 2>(wl + 6144, lane, b, rgb);
+  mma_chunk<PREC, 1, 2, 0, true, 2>(st, wl + 6144, lane, b, rgb);
   if (DUMP && dump.in != nullptr) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -630,13 +662,13 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
   x[0] = (f32x16)(0.f);
   x[1] = (f32x16)(0.f);
   const float* wl = stream_step(st, wave, lane);
-  mma_chunk<PREC, 2, 2, 0, false, 2>(wl, lane, pe, x);  // query MLP, PE part (bias in slot 63)
+  mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, pe, x);  // query MLP, PE part (bias in slot 63)
   add_hoisted_latent<2>(gq, g, hh, x);            // query MLP, feature part (hoisted)
   for (int l = 0; l < 3; ++l) {
     const float* bl = bias + 256 * l;
     norm64(x, n);
     bias_init<2, true>(bl, hh, t);
-    mma_chunk<PREC, 2, 2, 0, false, 2>(wl + 4096, lane, n, t);  // dots[head*8 + key]
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, n, t);  // dots[head*8 + key]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -657,10 +689,10 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
     }
     wl = stream_step(st, wave, lane);
     bias_init<2, false>(bl + 64, hh, x);
-    mma_chunk<PREC, 2, 2, 0, false, 2>(wl, lane, t, x);  // x += to_out(attn @ V)
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, t, x);  // x += to_out(attn @ V)
     norm64(x, n);
     bias_init<2, true>(bl + 128, hh, t);
-    mma_chunk<PREC, 2, 2, 0, false, 2>(wl + 4096, lane, n, t);
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, n, t);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -670,10 +702,10 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
       }
     wl = stream_step(st, wave, lane);
     bias_init<2, false>(bl + 192, hh, x);
-    mma_chunk<PREC, 2, 2, 0, false, 2>(wl, lane, t, x);  // x += FF
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, t, x);  // x += FF
   }
   bias_init<1, true>(bias + 768, hh, out);
-  mma_chunk<PREC, 1, 2, 0, false, 2>(wl + 4096, lane, x, out);
+  mma_chunk<PREC, 1, 2, 0, false, 2>(st, wl + 4096, lane, x, out);
 }
 
 // ------------------------------------------------------------------------------------------
