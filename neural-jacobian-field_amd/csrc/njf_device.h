@@ -136,8 +136,9 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
 template <int PREC, int MBO, int NKB, int KB0, bool RELU, int KBI>
 __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restrict__ wl, int lane,
                                           const f32x16 (&in)[KBI], f32x16 (&out)[MBO]) {
-  // DMA rounds of the next chunk ride between the MFMA groups of this one when there are exactly NJF_DMA_ROUNDS
-  // groups (the 128-wide layers: MBO = 4, NKB = 2); every other shape issues the job up front.
+  // DMA rounds of the next chunk ride between the MFMA groups of this one (the 128-wide layers: MBO = 4, NKB = 2, eight
+  // groups): two rounds behind each of the first four groups, so the last round still has half a chunk to land before
+  // the next barrier's vmcnt(0).  Every other shape issues the job up front.
   constexpr bool SPREAD = MBO == 4 && NKB == 2 && NJF_DMA_ROUNDS == 8;
   if constexpr (!SPREAD) stream_flush(st);
   if constexpr (PREC == PREC_F32) {
@@ -152,7 +153,12 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
         f32x4 a[MBO];
 #pragma unroll
         for (int m = 0; m < MBO; ++m) a[m] = *(const f32x4*)(base + ((kb * 4 + q) * MBO + m) * 256);
-        if constexpr (SPREAD) dma_issue(st, kb * 4 + q);
+        if constexpr (SPREAD) {
+          if (kb * 4 + q < 4) {
+            dma_issue(st, 2 * (kb * 4 + q));
+            dma_issue(st, 2 * (kb * 4 + q) + 1);
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float b = in[KB0 + kb][q * 4 + e];
@@ -197,7 +203,12 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 #pragma unroll
             for (int i = 0; i < 4; ++i) n[i] = base[((u + 1) * 4 + i) * 64];
           }
-          if constexpr (SPREAD) dma_issue(st, u);
+          if constexpr (SPREAD) {
+            if (u < 4) {
+              dma_issue(st, 2 * u);
+              dma_issue(st, 2 * u + 1);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mm = 0; mm < 2; ++mm) {
