@@ -209,8 +209,8 @@ def main():
             "metric": "rendered rays/s (64 samples/ray, 256^2 image)",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if precision == "f32" else "f32 in/out + fp32 accumulate; MFMA operands split hi+lo into 2 x f16 "
-                     "(3 f16 MFMAs per product block, fp32-class accuracy: same parity bound as the f32-MFMA path)",
+            "dtype": "f32" if precision == "f32" else "f32 (matrix products as an error-compensated 2 x f16 split of the fp32 "
+                     "operands, 3 f16 MFMAs per block, fp32 accumulate; same parity bound as the f32-MFMA path)",
             "data": "synthetic",
             "config": {"workload": ("C2: " if (BB, HH, WW, SS) == (1, 256, 256, 64) else "") +
                                    f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final "
