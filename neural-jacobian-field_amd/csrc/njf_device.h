@@ -429,14 +429,20 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 }
 
 // ------------------------------------------------------------------------------------------
-// sin(arg) with exact range reduction in fp64 (arguments reach ~3e4 rad at the top octave of the
-// positional encoding; hardware v_sin_f32 and __sinf are not accurate enough there).
+// sin(arg) with exact range reduction (arguments reach ~3e4 rad at the top octave of the positional
+// encoding; hardware v_sin_f32 and __sinf are not accurate enough there).  The reduction works in revolutions,
+// arg / 2pi evaluated as a two-float product: 1/2pi = C_HI + C_LO (24 + 24 bits), u = fl(arg * C_HI), the exact
+// rounding error of that product from one fma, plus arg * C_LO.  u - rint(u) is exact, so the phase is good to
+// half an ulp of 0.5 (2.8e-8 revolutions, sin error 1.8e-7) -- the same as rounding an fp64 reduction to float, at
+// a third of the cost (fp64 VALU runs at half rate and needs conversions both ways).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sin_accurate(float arg) {
-  const double u = (double)arg * 0.15915494309189533576888;  // revolutions
-  double ph = u - rint(u);                                   // [-0.5, 0.5], exact
-  if (fabs(ph) > 0.25) ph = copysign(0.5, ph) - ph;          // sin(pi - x) = sin(x)
-  const float y = (float)ph;                                 // |y| <= 0.25
+  const float C_HI = 0.15915493667125702f, C_LO = 6.4206382432985265e-09f;
+  const float u = arg * C_HI;
+  float e = fmaf(arg, C_HI, -u);
+  e = fmaf(arg, C_LO, e);
+  float y = (u - rintf(u)) + e;                          // [-0.5, 0.5] (+ rounding)
+  if (fabsf(y) > 0.25f) y = copysignf(0.5f, y) - y;      // sin(pi - x) = sin(x); |y| <= 0.25 afterwards
   const float y2 = y * y;
   // sin(2*pi*y) = y * P(y^2), Taylor to x^13 (truncation < 6e-10 at |x| = pi/2)
   float p = 3.8199525848482803f;            // +(2pi)^13/13!
