@@ -117,6 +117,11 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
   return njf_lds + (st.idx++ & 1) * NJF_CHUNK;
 #endif
   stream_flush(st);  // rounds the previous consumer did not issue (chunk shapes without interleaving)
+  // Every wave must have ITS share of the chunk in LDS before anyone passes the barrier.  LDS-DMA completion is
+  // counted by vmcnt, and the workgroup fence of __syncthreads() does not cover it (the compiler only waits vmcnt
+  // in front of this wave's own reads of the buffer): without the explicit wait another wave can read a round that
+  // is still in flight -- a race the full-frame ray-sharding test caught once the rounds were issued later.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float* cur = njf_lds + (st.idx & 1) * NJF_CHUNK;
   st.idx += 1;
