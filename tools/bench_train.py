@@ -31,6 +31,8 @@ sd = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", 8), seed
 model.load_state_dict(sd)
 MODE = sys.argv[1] if len(sys.argv) > 1 else "action"
 model.to(dev).train()
+if os.environ.get("NJF_CHANNELS_LAST"):
+    model.encoder.to(memory_format=torch.channels_last)
 if MODE == "action":
     model.encoder.eval()
     model.decoder.freeze_non_action_parameters()
