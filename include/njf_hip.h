@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 3
+#define NJF_ABI_VERSION 4
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -138,6 +138,20 @@ int njf_project_features(const float* feats, const float* wz, const float* bz, i
                          float* out, int precision, void* stream);
 int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, const float* bz, int batch, int hw, int n,
                             float* out, int precision, void* stream);
+
+/* ---- feature-pyramid producer: encoder_resnet.py:78-86 fused with the lin_z hoist ----------- */
+/* The encoder output is cat_l(bilinear_upsample(latent_l)) (align_corners=False) of its conv1 / layer1..3 latents.
+ * Given the latents themselves (NCHW, level 0 at the output resolution, channel counts summing to 512 in
+ * concatenation order) this computes the same hoisted map G = F . wz + bz without ever forming F: every level is
+ * projected at its own resolution, the coarser ones are bilinearly up-sampled and added.  `workspace` (caller-owned)
+ * holds the projected coarser levels: sum over l >= 1 of batch * height_l * width_l * n floats. */
+typedef struct NjfPyramidLevel {
+  const float* feats; /* [B, channels, height, width] */
+  int channels;       /* multiple of 16 */
+  int height, width;
+} NjfPyramidLevel;
+int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels, const float* wz, int wz_ld, const float* bz,
+                        int batch, int n, float* out, float* workspace, int precision, void* stream);
 
 /* ---- ray generation: rendering/geometry.py:117-134 + :170-203 ------------------------------ */
 /* coords [B,R,2] normalised pixel centres (NULL -> full H x W grid of get_pixel_coordinates),

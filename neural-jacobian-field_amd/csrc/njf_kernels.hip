@@ -216,7 +216,7 @@ extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out,
 // (A: 32 consecutive texels of one channel plane = one 128-B line; B: 32 consecutive output
 // channels of one k row).  Per-image cost: 19 GFLOP at 256^2.
 __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ feats, const float* __restrict__ wz,
-                                                      const float* __restrict__ bz, int hw, int n, int ld,
+                                                      const float* __restrict__ bz, int hw, int n, int ld, int K,
                                                       float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, kh = lane >> 5;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
   const int n0 = blockIdx.y * 128;
   if (p0 >= hw) return;
   const int p = min(p0 + j, hw - 1);
-  const float* fa = feats + (size_t)b * 512 * hw + p;
+  const float* fa = feats + (size_t)b * K * hw + p;
   f32x16 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x16)(0.f);
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
 #pragma unroll
   for (int t = 0; t < 4; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
 #pragma unroll 4
-  for (int k = 0; k < 512; k += 2) {
+  for (int k = 0; k < K; k += 2) {
     const float a = fa[(size_t)(k + kh) * hw];
     const float* wr = wz + (size_t)(k + kh) * ld;
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
   for (int t = 0; t < 4; ++t) {
     const int c = n0 + 32 * t + j;
     if (c >= n) continue;
-    const float bias = bz[c];
+    const float bias = bz ? bz[c] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo
 #define NJF_PROJ_NT 2
 #endif
 __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __restrict__ feats, const float* __restrict__ wz,
-                                                            const float* __restrict__ bz, int hw, int n, int ld,
+                                                            const float* __restrict__ bz, int hw, int n, int ld, int K,
                                                             float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, kh = lane >> 5;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
   if (p0 >= hw) return;
   const float* fa[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) fa[a] = feats + (size_t)b * 512 * hw + min(p0 + 32 * a + j, hw - 1);
+  for (int a = 0; a < 2; ++a) fa[a] = feats + (size_t)b * K * hw + min(p0 + 32 * a + j, hw - 1);
   int nn[NJF_PROJ_NT];
 #pragma unroll
   for (int t = 0; t < NJF_PROJ_NT; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
@@ -306,13 +306,13 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
       for (int i = 0; i < 8; ++i) xb[t][i] = wz[(size_t)(kb + i) * ld + nn[t]];
   };
   fetch(0);
-  for (int k0 = 0; k0 < 512; k0 += 16) {
+  for (int k0 = 0; k0 < K; k0 += 16) {
     f16x8 ah[2], al[2], bh[NJF_PROJ_NT], bl[NJF_PROJ_NT];
 #pragma unroll
     for (int a = 0; a < 2; ++a) split8(xa[a], ah[a], al[a]);
 #pragma unroll
     for (int t = 0; t < NJF_PROJ_NT; ++t) split8(xb[t], bh[t], bl[t]);
-    if (k0 + 16 < 512) fetch(k0 + 16);
+    if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
     for (int t = 0; t < NJF_PROJ_NT; ++t)
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
   for (int t = 0; t < NJF_PROJ_NT; ++t) {
     const int c = n0 + 32 * t + j;
     if (c >= n) continue;
-    const float bias = bz[c];
+    const float bias = bz ? bz[c] : 0.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -337,24 +337,116 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
   }
 }
 
+static void launch_project(const float* feats, int K, const float* wz, int ld, const float* bz, int batch, int hw, int n,
+                           float* out, int precision, hipStream_t s) {
+  if (precision == NJF_PRECISION_F16X2) {
+    dim3 grid((hw + 255) / 256, (n + 32 * NJF_PROJ_NT - 1) / (32 * NJF_PROJ_NT), batch);
+    project_kernel_f16x2<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+  } else {
+    dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
+    project_kernel<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+  }
+}
+
 extern "C" int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, const float* bz, int batch, int hw,
                                        int n, float* out, int precision, void* stream) {
   if (!feats || !wz || !bz || !out) return NJF_E_NULL;
   if (batch < 1 || hw < 1 || n < 1 || wz_ld < n) return NJF_E_SHAPE;
   if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
-  if (precision == NJF_PRECISION_F16X2) {
-    dim3 grid((hw + 255) / 256, (n + 32 * NJF_PROJ_NT - 1) / (32 * NJF_PROJ_NT), batch);
-    project_kernel_f16x2<<<grid, 256, 0, (hipStream_t)stream>>>(feats, wz, bz, hw, n, wz_ld, out);
-  } else {
-    dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
-    project_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(feats, wz, bz, hw, n, wz_ld, out);
-  }
+  launch_project(feats, 512, wz, wz_ld, bz, batch, hw, n, out, precision, (hipStream_t)stream);
   return launch_status();
 }
 
 extern "C" int njf_project_features(const float* feats, const float* wz, const float* bz, int batch, int hw, int n,
                                     float* out, int precision, void* stream) {
   return njf_project_features_ld(feats, wz, n, bz, batch, hw, n, out, precision, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Feature-pyramid producer (encoder_resnet.py:78-86 + the lin_z hoist): the encoder's output is
+// cat_l(upsample_l(latent_l)); projection and bilinear up-sampling are both linear and act on different axes, so
+// G = bz + sum_l upsample_l(latent_l . Wz[rows of level l]).  Each level is projected at its OWN resolution
+// (5.6x fewer FLOPs than projecting the concatenated map, which is never formed), level 0 straight into `out`;
+// this kernel then adds the up-sampled coarser levels in place.  One thread = 4 channels of one texel.
+// ---------------------------------------------------------------------------------------------
+struct UpsampleArgs {
+  const float* src[3];
+  int h[3], w[3];
+  int levels;
+  int batch, height, width, n;
+  float* out;
+};
+
+__global__ void __launch_bounds__(256) upsample_add_kernel(UpsampleArgs a) {
+  const int n4 = a.n >> 2;
+  const long long total = (long long)a.batch * a.height * a.width * n4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % n4) * 4;
+  const long long t = i / n4;
+  const int x = (int)(t % a.width), y = (int)((t / a.width) % a.height), b = (int)(t / ((long long)a.width * a.height));
+  f32x4 acc = *(const f32x4*)(a.out + ((size_t)t * a.n + c));
+  for (int l = 0; l < a.levels; ++l) {
+    // F.interpolate(mode="bilinear", align_corners=False): src = (dst + 0.5) * in / out - 0.5, clamped at 0
+    const int h = a.h[l], w = a.w[l];
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)h / (float)a.height) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)w / (float)a.width) - 0.5f, 0.f);
+    const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float wy = sy - (float)y0, wx = sx - (float)x0;
+    const float* base = a.src[l] + (size_t)b * h * w * a.n + c;
+    const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * w + x0) * a.n), v01 = *(const f32x4*)(base + ((size_t)y0 * w + x1) * a.n);
+    const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * w + x0) * a.n), v11 = *(const f32x4*)(base + ((size_t)y1 * w + x1) * a.n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float top = v00[e] * (1.0f - wx) + v01[e] * wx, bot = v10[e] * (1.0f - wx) + v11[e] * wx;
+      acc[e] += top * (1.0f - wy) + bot * wy;
+    }
+  }
+  *(f32x4*)(a.out + ((size_t)t * a.n + c)) = acc;
+}
+
+extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels, const float* wz, int wz_ld, const float* bz,
+                                   int batch, int n, float* out, float* workspace, int precision, void* stream) {
+  if (!levels || !wz || !bz || !out) return NJF_E_NULL;
+  if (num_levels < 1 || num_levels > 4 || batch < 1 || n < 4 || (n & 3) || wz_ld < n) return NJF_E_SHAPE;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (num_levels > 1 && !workspace) return NJF_E_NULL;
+  int rows = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!levels[l].feats) return NJF_E_NULL;
+    if (levels[l].channels < 16 || (levels[l].channels & 15) || levels[l].height < 1 || levels[l].width < 1) return NJF_E_SHAPE;
+    rows += levels[l].channels;
+  }
+  if (rows != 512) return NJF_E_SHAPE;  // rows of wz = channels of the concatenated encoder output
+  hipStream_t s = (hipStream_t)stream;
+  UpsampleArgs u;
+  u.levels = num_levels - 1;
+  u.batch = batch;
+  u.height = levels[0].height;
+  u.width = levels[0].width;
+  u.n = n;
+  u.out = out;
+  int row0 = 0;
+  float* ws = workspace;
+  for (int l = 0; l < num_levels; ++l) {
+    const int hw = levels[l].height * levels[l].width;
+    float* dst = l == 0 ? out : ws;
+    launch_project(levels[l].feats, levels[l].channels, wz + (size_t)row0 * wz_ld, wz_ld, l == 0 ? bz : nullptr, batch, hw, n,
+                   dst, precision, s);
+    if (l > 0) {
+      u.src[l - 1] = ws;
+      u.h[l - 1] = levels[l].height;
+      u.w[l - 1] = levels[l].width;
+      ws += (size_t)batch * hw * n;
+    }
+    row0 += levels[l].channels;
+  }
+  if (u.levels > 0) {
+    const long long total = (long long)batch * u.height * u.width * (n >> 2);
+    upsample_add_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(u);
+  }
+  return launch_status();
 }
 
 // =============================================================================================

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from .encoder import FeaturePyramid
 from .config import (ActionDecoderCfg, ActionDecoderJacobianMlpCfg, ActionDecoderJacobianTransformerCfg,
                      DensityDecoderCfg, DensityDecoderMlpCfg, MlpCfg)
 
@@ -121,7 +122,10 @@ class _HoistCache:
         if features is not self.features or key != self.key:
             b, _, hf, wf = features.shape
             gmap = torch.empty(b, hf, wf, wz.shape[1], dtype=torch.float32, device=features.device)
-            hip.project_features(features.contiguous(), wz, bz, gmap, precision=precision)
+            if isinstance(features, FeaturePyramid):
+                hip.project_pyramid(features.levels, wz, bz, gmap, precision=precision)
+            else:
+                hip.project_features(features.contiguous(), wz, bz, gmap, precision=precision)
             self.key, self.features, self.gmap = key, features, gmap
         return self.gmap
 

@@ -82,6 +82,28 @@ class Encoder(nn.Module, ABC):
     def get_output_dim(self) -> int: ...
 
 
+class FeaturePyramid:
+    """The encoder's latents BEFORE up-sampling and concatenation (conv1, layer1..3 outputs).  Stands in for the
+    [B,512,Hf,Wf] feature tensor on the inference path: the hoisted map is produced from the levels directly
+    (njf_project_pyramid), so the concatenated map and its three up-sampled copies are never written."""
+
+    def __init__(self, levels):
+        self.levels = list(levels)
+
+    @property
+    def shape(self):
+        b, _, h, w = self.levels[0].shape
+        return torch.Size((b, sum(lv.shape[1] for lv in self.levels), h, w))
+
+    @property
+    def device(self):
+        return self.levels[0].device
+
+    @property
+    def _version(self):
+        return sum(lv._version for lv in self.levels)
+
+
 class EncoderResnet(Encoder):
     def __init__(self, cfg: EncoderResnetCfg):
         super().__init__(cfg)
@@ -97,9 +119,7 @@ class EncoderResnet(Encoder):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, rgb: torch.Tensor) -> torch.Tensor:
-        """[B,3,H,W] -> [B,512,H/2,W/2]: conv1..layer3 outputs, bilinearly upsampled (align_corners=False)
-        to the conv1 resolution and concatenated (encoder_resnet.py:53-86)."""
+    def _latents(self, rgb: torch.Tensor):
         m = self.model
         x = m.relu(m.bn1(m.conv1(rgb)))
         pyramid = [x]
@@ -109,6 +129,21 @@ class EncoderResnet(Encoder):
             for i in range(1, min(self.num_layers, 5)):
                 x = getattr(m, f"layer{i}")(x)
                 pyramid.append(x)
+        return pyramid
+
+    def forward_pyramid(self, rgb: torch.Tensor):
+        """Inference path of the fused renderer: the latents without the up-sampling + concatenation of
+        encoder_resnet.py:78-86 (a FeaturePyramid), or the plain feature tensor when the configuration is not the
+        bilinear 512-channel one the pyramid producer implements."""
+        pyramid = self._latents(rgb)
+        if self.upsample_interp != "bilinear" or sum(p.shape[1] for p in pyramid) != 512:
+            return self.forward(rgb)
+        return FeaturePyramid(pyramid)
+
+    def forward(self, rgb: torch.Tensor) -> torch.Tensor:
+        """[B,3,H,W] -> [B,512,H/2,W/2]: conv1..layer3 outputs, bilinearly upsampled (align_corners=False)
+        to the conv1 resolution and concatenated (encoder_resnet.py:53-86)."""
+        pyramid = self._latents(rgb)
         size = pyramid[0].shape[-2:]
         pyramid = [F.interpolate(p, size, mode=self.upsample_interp, align_corners=False) for p in pyramid]
         return torch.cat(pyramid, dim=1)

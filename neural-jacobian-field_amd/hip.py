@@ -72,6 +72,10 @@ class RenderOutputs(C.Structure):
         "den_act", "col_in", "col_act")]
 
 
+class PyramidLevel(C.Structure):
+    _fields_ = [("feats", _vp), ("channels", C.c_int), ("height", C.c_int), ("width", C.c_int)]
+
+
 class ActivationDump(C.Structure):
     _fields_ = [("act", _vp), ("pe", _vp), ("foot_idx", _vp), ("foot_w", _vp)]
 
@@ -87,6 +91,8 @@ _SIGNATURES = {
     "njf_pack_linear": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_project_features": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
+    "njf_project_pyramid": ([C.POINTER(PyramidLevel), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp],
+                            C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
                               _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.POINTER(ActivationDump), C.c_int, _vp],
@@ -228,6 +234,28 @@ def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, ou
         raise ValueError("njf_hip: project_features shape mismatch")
     _check(load_library().njf_project_features_ld(_ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out),
                                                   precision_code(precision), _stream()))
+
+
+def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor, precision: Optional[str] = None) -> None:
+    """levels: the encoder's latents [B,C_l,H_l,W_l] in concatenation order (level 0 at the output resolution, channel
+    counts summing to 512); wz [512,N]; bz [N]; out [B,H_0,W_0,N] -- the hoisted map of the concatenated, up-sampled
+    feature map, without forming it (njf_project_pyramid)."""
+    b = levels[0].shape[0]
+    n = wz.shape[1]
+    if tuple(out.shape) != (b, levels[0].shape[2], levels[0].shape[3], n) or wz.shape[0] != 512:
+        raise ValueError("njf_hip: project_pyramid shape mismatch")
+    arr = (PyramidLevel * len(levels))()
+    keep = []
+    ws_floats = 0
+    for i, lv in enumerate(levels):
+        lv = lv.contiguous()
+        keep.append(lv)
+        arr[i] = PyramidLevel(_ptr(lv), lv.shape[1], lv.shape[2], lv.shape[3])
+        if i > 0:
+            ws_floats += b * lv.shape[2] * lv.shape[3] * n
+    workspace = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=out.device)
+    _check(load_library().njf_project_pyramid(arr, len(levels), _ptr(wz), n, _ptr(bz), b, n, _ptr(out), _ptr(workspace),
+                                              precision_code(precision), _stream()))
 
 
 # --------------------------------------------------------------------------------------

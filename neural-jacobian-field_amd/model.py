@@ -367,9 +367,15 @@ class Model(nn.Module):
                 weights=outs["weights"], ray_positions=outs["pos"], ray_positions_warped=outs["pos_warped"])
 
     @torch.no_grad()
+    def _encode_for_render(self, image: torch.Tensor):
+        """Encoder output for the fused inference path: the un-concatenated latents when the encoder offers them
+        (the hoisted map is then produced without materialising the 512-channel feature map)."""
+        fp = getattr(self.encoder, "forward_pyramid", None)
+        return fp(image) if fp is not None else self.encoder.forward(image)
+
     def _forward_inference(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
                            compute_vis_features: bool = False) -> ModelOutput:
-        features = self.encoder.forward(camera_input.input_image)
+        features = self._encode_for_render(camera_input.input_image)
         outs, bins, weights_list, bins_list, ray_bundle = self._fused_render(
             camera_input, rendering_input, robot_input, features, want_lists=self.training, want_vis=compute_vis_features,
             want_samples=False)
@@ -399,7 +405,7 @@ class Model(nn.Module):
     def encode_image(self, camera_input: CameraInput, rendering_input: RenderingInput,
                      robot_input: RobotInput) -> ModelInferenceEncoding:
         """model.py:458-495: proposal sampling + per-sample density/Jacobian/weights, cached for inverse dynamics."""
-        features = self.encoder.forward(camera_input.input_image)
+        features = self._encode_for_render(camera_input.input_image)
         outs, bins, _, _, ray_bundle = self._fused_render(camera_input, rendering_input, robot_input, features,
                                                          want_lists=False, want_vis=False, want_samples=True)
         positions = ray_bundle.samples_from_bins(bins).get_positions()
@@ -431,7 +437,7 @@ class Model(nn.Module):
         was_training = self.training
         self.eval()
         try:
-            features = self.encoder.forward(camera_input.input_image)
+            features = self._encode_for_render(camera_input.input_image)
             outs, bins, _, _, ray_bundle = self._fused_render(camera_input, rendering_input, robot_input, features,
                                                              want_lists=False, want_vis=True, want_samples=False)
         finally:

@@ -13,6 +13,7 @@ from neural_jacobian_field_amd.config import model_cfg_from_dict
 from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
 
 dev = torch.device("cuda:0")
+torch.manual_seed(0)  # the flow residual of the solve depends on the drawn image / command
 B, H, W, R, S, A = 1, 256, 256, int(os.environ.get("RAYS", 256)), 64, 8
 case = ph.make_case(B, H, W, R, A, seed=0)
 model = Model(model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
