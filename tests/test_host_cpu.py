@@ -253,7 +253,7 @@ def test_ctypes_structs_match_the_header():
         return names
 
     pairs = {"NjfRenderOutputs": hip.RenderOutputs, "NjfActivationDump": hip.ActivationDump, "NjfCameras": hip.Cameras,
-             "NjfFeatureMap": hip.FeatureMap}
+             "NjfFeatureMap": hip.FeatureMap, "NjfPyramidLevel": hip.PyramidLevel}
     for name, mirror in pairs.items():
         assert fields(name) == [f[0] for f in mirror._fields_], name
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
