@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 4
+#define NJF_ABI_VERSION 5
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -239,6 +239,18 @@ int njf_alpha_weights(const float* deltas, const float* densities, int rays, int
 /* PDFSampler.generate_ray_samples (ray_samplers.py:351-451) on spacing bins. */
 int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ray, int s_in, const float* u,
                      int u_per_ray, int s_out, float anneal, int rays, float* bins_out, void* stream);
+
+/* ---- inverse dynamics on the composited Jacobian field ---------------------------------------- */
+/* The control loop of notebooks/real_world/2_inverse_dynamics.ipynb (cells 26-29: 100 Adam steps through
+ * Model.infer_optical_flow, model.py:497-525) as a least-squares problem: optical_flow(a) = proj(x + M a) - proj(x),
+ * x = mean_position [B,R,3] and M = jacobian [B,R,3,A] being the composited outputs of njf_render_forward (pos,
+ * action_features re-ordered spatial-major), projection [B,3,4] = K . inv(E)[:3] of the target camera.  Runs
+ * `iterations` Levenberg-Marquardt steps on sum_r mask_r |flow_r(a) - target_flow_r|^2 inside one launch (one
+ * workgroup per batch element, deterministic reductions) and writes the command to action [B,A].
+ * visible_mask [B,R] and init_action [B,A] may be NULL (all rays, start from zero).  A <= 16. */
+int njf_solve_action(const float* mean_position, const float* jacobian, const float* projection, const float* target_flow,
+                     const float* visible_mask, const float* init_action, int batch, int rays, int action_dim,
+                     int iterations, float damping, float* action, void* stream);
 
 #ifdef __cplusplus
 }

@@ -232,12 +232,14 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
   int nn[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
-#pragma unroll 4
-  for (int k = 0; k < K; k += 2) {
-    const float a = fa[(size_t)(k + kh) * hw];
-    const float* wr = wz + (size_t)(k + kh) * ld;
+  for (int k0 = 0; k0 < K; k0 += 8) {  // K is a multiple of 16 (checked by the launchers)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[nn[t]], acc[t], 0, 0, 0);
+    for (int k = k0; k < k0 + 8; k += 2) {
+      const float a = fa[(size_t)(k + kh) * hw];
+      const float* wr = wz + (size_t)(k + kh) * ld;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[nn[t]], acc[t], 0, 0, 0);
+    }
   }
   // D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (texel)
 #pragma unroll
@@ -1067,6 +1069,172 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
       }
     }
   }
+}
+
+// =============================================================================================
+// inverse dynamics: Levenberg-Marquardt on the linearised flow, one workgroup per batch element
+// =============================================================================================
+// optical_flow(a) = proj(x + M a) - proj(x) with x = sum_s w x_s and M = sum_s w J_s (the composited outputs of the
+// final pass; render_optical_flow, model.py:288-314).  Minimises sum_r mask_r |flow_r(a) - target_r|^2 over the command
+// a -- the control loop of notebooks/real_world/2_inverse_dynamics.ipynb, which runs 100 Adam steps through
+// Model.infer_optical_flow instead.  All iterations run inside ONE launch: per iteration every thread linearises its
+// rays (2 x A Jacobian rows into LDS), A*A threads contract them into the normal matrix in a fixed order (no
+// atomics: deterministic), thread 0 solves the damped A x A system, and the step is kept if it lowers the cost.
+#define NJF_SOLVE_MAX_A 16
+struct SolveArgs {
+  const float* pos;     // [B,R,3]
+  const float* jac;     // [B,R,3,A]
+  const float* proj;    // [B,3,4]  K . inv(E)[:3]
+  const float* target;  // [B,R,2]
+  const float* mask;    // [B,R] or null
+  const float* init;    // [B,A] or null
+  int R, A, iters;
+  float damping;
+  float* action;        // [B,A]
+};
+
+__global__ void __launch_bounds__(256) solve_action_kernel(SolveArgs a) {
+  __shared__ float rows[256][2 * NJF_SOLVE_MAX_A + 2];  // per ray: 2 Jacobian rows (A each) + 2 residuals
+  __shared__ float hmat[NJF_SOLVE_MAX_A][NJF_SOLVE_MAX_A + 1];
+  __shared__ float act[NJF_SOLVE_MAX_A], cand[NJF_SOLVE_MAX_A], red[256];
+  __shared__ float lam, cost, cost_c;
+  const int b = blockIdx.x, tid = threadIdx.x, A = a.A, R = a.R;
+  const float* P = a.proj + b * 12;
+  if (tid < A) act[tid] = a.init ? a.init[b * A + tid] : 0.f;
+  if (tid == 0) lam = a.damping;
+  __syncthreads();
+
+  // residual (and optionally Jacobian rows) of ray r at command `cmd`; returns the squared residual
+  auto eval_ray = [&](int r, const float* cmd, bool want_rows, int slot) -> float {
+    const size_t ri = (size_t)b * R + r;
+    const float w = a.mask ? a.mask[ri] : 1.f;
+    float x[3], x0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      x0[c] = a.pos[ri * 3 + c];
+      float v = x0[c];
+      for (int k = 0; k < A; ++k) v = fmaf(a.jac[(ri * 3 + c) * A + k], cmd[k], v);
+      x[c] = v;
+    }
+    auto project = [&](const float* p, float& u, float& v, float& d) {
+      const float hx = fmaf(P[2], p[2], fmaf(P[1], p[1], P[0] * p[0])) + P[3];
+      const float hy = fmaf(P[6], p[2], fmaf(P[5], p[1], P[4] * p[0])) + P[7];
+      d = fmaf(P[10], p[2], fmaf(P[9], p[1], P[8] * p[0])) + P[11] + 1e-9f;
+      u = hx / d;
+      v = hy / d;
+    };
+    float u0, v0, d0, u, v, d;
+    project(x0, u0, v0, d0);
+    project(x, u, v, d);
+    const float r0 = ((u - u0) - a.target[ri * 2]) * w, r1 = ((v - v0) - a.target[ri * 2 + 1]) * w;
+    if (want_rows) {
+      // d uv / d x = (P[:2,:3] - uv (x) P[2,:3]) / depth, times M
+      float gu[3], gv[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gu[c] = (P[c] - u * P[8 + c]) / d;
+        gv[c] = (P[4 + c] - v * P[8 + c]) / d;
+      }
+      for (int k = 0; k < A; ++k) {
+        float ju = 0.f, jv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float m = a.jac[(ri * 3 + c) * A + k];
+          ju = fmaf(gu[c], m, ju);
+          jv = fmaf(gv[c], m, jv);
+        }
+        rows[slot][k] = ju * w;
+        rows[slot][A + k] = jv * w;
+      }
+      rows[slot][2 * A] = r0;
+      rows[slot][2 * A + 1] = r1;
+    }
+    return r0 * r0 + r1 * r1;
+  };
+  auto block_sum = [&](float v) -> float {
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const float out = red[0];
+    __syncthreads();
+    return out;
+  };
+
+  for (int it = 0; it < a.iters; ++it) {
+    // normal equations H = J^T J, g = J^T res, accumulated over chunks of 256 rays in a fixed order
+    // entry e = hi * (A + 1) + hj of [H | g] (hj == A: the right-hand side); A * (A + 1) <= 272 entries, so a thread
+    // owns entry tid and, for A = 16, entry tid + 256 as well
+    const int entries = A * (A + 1);
+    float hacc[2] = {0.f, 0.f}, csum = 0.f;
+    for (int r0 = 0; r0 < R; r0 += 256) {
+      const int r = r0 + tid;
+      if (r < R) csum += eval_ray(r, act, true, tid);
+      __syncthreads();
+      const int n = min(256, R - r0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k;
+        if (e < entries) {
+          const int hi = e / (A + 1), hj = e % (A + 1);
+          float acc = hacc[k];
+          for (int q = 0; q < n; ++q) {
+            const float bu = hj < A ? rows[q][hj] : rows[q][2 * A], bv = hj < A ? rows[q][A + hj] : rows[q][2 * A + 1];
+            acc = fmaf(rows[q][hi], bu, acc);
+            acc = fmaf(rows[q][A + hi], bv, acc);
+          }
+          hacc[k] = acc;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      if (e < entries) hmat[e / (A + 1)][e % (A + 1)] = hacc[k];
+    }
+    const float c_now = block_sum(csum);
+    if (tid == 0) {
+      cost = c_now;
+      // (H + lam diag(H)) step = g, un-pivoted Gauss-Jordan (symmetric positive definite after damping)
+      for (int i = 0; i < A; ++i) hmat[i][i] += lam * fmaxf(hmat[i][i], 1e-12f);
+      for (int k = 0; k < A; ++k) {
+        const float inv = 1.0f / hmat[k][k];
+        for (int j = 0; j <= A; ++j) hmat[k][j] *= inv;
+        for (int i = 0; i < A; ++i) {
+          if (i == k) continue;
+          const float f = hmat[i][k];
+          for (int j = 0; j <= A; ++j) hmat[i][j] = fmaf(-f, hmat[k][j], hmat[i][j]);
+        }
+      }
+      for (int i = 0; i < A; ++i) cand[i] = act[i] - hmat[i][A];
+    }
+    __syncthreads();
+    float cs = 0.f;
+    for (int r = tid; r < R; r += 256) cs += eval_ray(r, cand, false, 0);
+    const float c_new = block_sum(cs);
+    if (tid == 0) {
+      const bool better = c_new < cost;  // NaN (a point behind the camera) compares false: step rejected
+      if (better)
+        for (int i = 0; i < A; ++i) act[i] = cand[i];
+      lam = fminf(fmaxf(better ? lam / 3.0f : lam * 4.0f, 1e-9f), 1e9f);
+    }
+    __syncthreads();
+  }
+  if (tid < A) a.action[b * A + tid] = act[tid];
+}
+
+extern "C" int njf_solve_action(const float* mean_position, const float* jacobian, const float* projection,
+                                const float* target_flow, const float* visible_mask, const float* init_action, int batch,
+                                int rays, int action_dim, int iterations, float damping, float* action, void* stream) {
+  if (!mean_position || !jacobian || !projection || !target_flow || !action) return NJF_E_NULL;
+  if (batch < 1 || rays < 1 || iterations < 0) return NJF_E_SHAPE;
+  if (action_dim < 1 || action_dim > NJF_SOLVE_MAX_A) return NJF_E_ACTION_DIM;
+  SolveArgs a{mean_position, jacobian, projection, target_flow, visible_mask, init_action, rays, action_dim, iterations, damping, action};
+  solve_action_kernel<<<batch, 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
 }
 
 // =============================================================================================

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_project_pyramid": ([C.POINTER(PyramidLevel), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp],
                             C.c_int),
+    "njf_solve_action": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
                               _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.POINTER(ActivationDump), C.c_int, _vp],
@@ -324,6 +325,15 @@ def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int
         jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,
         _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo),
         precision_code(precision), _stream()))
+
+
+def solve_action(mean_position, jacobian, projection, target_flow, visible_mask, init_action, iterations: int,
+                 damping: float, action) -> None:
+    """mean_position [B,R,3], jacobian [B,R,3,A], projection [B,3,4], target_flow [B,R,2] -> action [B,A]."""
+    b, r = target_flow.shape[:2]
+    _check(load_library().njf_solve_action(_ptr(mean_position), _ptr(jacobian), _ptr(projection), _ptr(target_flow),
+                                           _ptr(visible_mask), _ptr(init_action), b, r, jacobian.shape[-1], int(iterations),
+                                           float(damping), _ptr(action), _stream()))
 
 
 def alpha_weights(deltas, densities, weights) -> None:

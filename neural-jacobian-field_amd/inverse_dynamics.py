@@ -51,20 +51,6 @@ def linearize_flow(model: Model, camera_input: CameraInput, rendering_input: Ren
     return FlowLinearization(out.vis_output.ray_positions, jac, camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
 
 
-def _solve_spd(h: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
-    """x = h^-1 g for small damped normal matrices h [B,A,A] (symmetric positive definite), g [B,A]: un-pivoted
-    Gauss-Jordan in batched tensor ops.  torch.linalg.solve would do, but its LAPACK-style back ends synchronise
-    with the host (error check / MAGMA), which rules out HIP-graph capture of the control step."""
-    a = h.shape[-1]
-    m = torch.cat([h, g[..., None]], dim=-1)                                   # [B, A, A+1]
-    rows = torch.arange(a, device=h.device)
-    for k in range(a):
-        pivot_row = m[:, k:k + 1, :] / m[:, k:k + 1, k:k + 1]
-        factor = torch.where((rows == k)[None, :, None], torch.zeros_like(m[:, :, k:k + 1]), m[:, :, k:k + 1])
-        m = torch.where((rows == k)[None, :, None], pivot_row, m - factor * pivot_row)
-    return m[..., -1]
-
-
 def _projection_matrix(lin: FlowLinearization) -> torch.Tensor:
     """[B,3,4] world -> homogeneous pixel matrix K . inv(E)[:3]."""
     from . import hip
@@ -74,46 +60,20 @@ def _projection_matrix(lin: FlowLinearization) -> torch.Tensor:
 @torch.no_grad()
 def solve_action(lin: FlowLinearization, target_flow: torch.Tensor, init_action: Optional[torch.Tensor] = None,
                  iterations: int = 20, damping: float = 1e-3, visible_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Levenberg-Marquardt on ``|| optical_flow(a) - target_flow ||^2`` (pixels).
+    """Levenberg-Marquardt on ``|| optical_flow(a) - target_flow ||^2`` (pixels): all iterations in ONE HIP launch
+    (``njf_solve_action``: one workgroup per batch element, deterministic reductions, no host synchronisation).
 
     target_flow [B,R,2], visible_mask [B,R] (the notebook masks the loss with the tracker's visibility) -> [B,A].
     The only non-linearity is the perspective divide, so for the few-pixel flows of a control step a handful of
-    iterations reach the minimum; each is a [2R x A] normal-equation solve per batch element.  A step is kept only
-    where it lowers the cost (per batch element, no host synchronisation), which keeps large-flow problems stable."""
-    b, r = target_flow.shape[:2]
-    a_dim = lin.jacobian.shape[-1]
-    dev = target_flow.device
-    action = torch.zeros(b, a_dim, dtype=torch.float32, device=dev) if init_action is None else init_action.clone().float()
-    w = torch.ones(b, r, 1, device=dev) if visible_mask is None else visible_mask[..., None].float()
-    proj = _projection_matrix(lin)[:, None]                                   # [B,1,3,4]
-    p_lin, p_off = proj[..., :3].expand(b, r, 3, 3), proj[..., 3]
-    uv0 = Model._project(lin.mean_position, lin.trgt_extrinsics, lin.trgt_intrinsics)
-
-    def evaluate(act):
-        x = lin.mean_position + torch.einsum("brca,ba->brc", lin.jacobian, act)
-        xyw = torch.einsum("brij,brj->bri", p_lin, x) + p_off
-        depth = xyw[..., 2:] + 1e-9
-        uv = xyw[..., :2] / depth
-        res = ((uv - uv0) - target_flow) * w                                   # [B,R,2]
-        return uv, depth, res, res.square().sum((1, 2))
-
-    lam = torch.full((b, 1, 1), damping, device=dev)
-    uv, depth, res, cost = evaluate(action)
-    for _ in range(iterations):
-        duv_dx = (proj[..., :2, :3] - uv[..., None] * proj[..., 2:3, :3]) / depth[..., None]     # [B,R,2,3]
-        jac = ((duv_dx @ lin.jacobian) * w[..., None]).reshape(b, 2 * r, a_dim)
-        h = jac.transpose(1, 2) @ jac
-        diag = torch.diag_embed(torch.diagonal(h, dim1=1, dim2=2).clamp_min(1e-12))
-        step = _solve_spd(h + lam * diag, (jac.transpose(1, 2) @ res.reshape(b, 2 * r, 1))[..., 0])
-        cand = action - step
-        uv_c, depth_c, res_c, cost_c = evaluate(cand)
-        better = cost_c < cost                                                # NaN (point behind the camera) -> rejected
-        sel = better[:, None]
-        action = torch.where(sel, cand, action)
-        uv, depth, res = (torch.where(sel[..., None], n, o) for n, o in ((uv_c, uv), (depth_c, depth), (res_c, res)))
-        cost = torch.where(better, cost_c, cost)
-        lam = torch.where(better[:, None, None], lam / 3.0, lam * 4.0).clamp(1e-9, 1e9)
-    return action
+    iterations reach the minimum; a step is kept only where it lowers the cost, which keeps large-flow problems
+    stable.  GPU tensors only (no CPU path); the tensor-op restatement used by the tests lives in oracle/."""
+    from . import hip
+    b = target_flow.shape[0]
+    out = torch.empty(b, lin.jacobian.shape[-1], dtype=torch.float32, device=target_flow.device)
+    f = lambda t: None if t is None else t.float().contiguous()
+    hip.solve_action(f(lin.mean_position), f(lin.jacobian), f(_projection_matrix(lin)), f(target_flow), f(visible_mask),
+                     f(init_action), iterations, damping, out)
+    return out
 
 
 class GraphedLinearizer:

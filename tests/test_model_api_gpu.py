@@ -302,3 +302,29 @@ def test_graphed_control_step_matches_eager(model_and_golden):
         got = ctrl(image, target).clone()
         assert rel(lin.optical_flow(got), target) < 1e-2
         assert rel(lin.optical_flow(got), lin.optical_flow(eager)) < 1e-2   # two encoder runs: MIOpen ulps
+
+
+def test_solve_action_kernel_matches_the_tensor_restatement(dev):
+    """njf_solve_action (all LM iterations in one launch) against oracle/lm_reference.py on synthetic linearisations:
+    ragged ray counts beyond one 256-ray chunk, A up to 16, masks, non-zero starts; and bit-reproducible."""
+    import lm_reference
+    from neural_jacobian_field_amd.inverse_dynamics import FlowLinearization, solve_action
+    gen = torch.Generator().manual_seed(12)
+    for b, r, a in ((2, 40, 6), (1, 700, 8), (3, 256, 16), (1, 5, 2)):
+        pos = (torch.rand(b, r, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.5]) + torch.tensor([-0.5, -0.5, 1.5])).to(dev)
+        jac = (torch.randn(b, r, 3, a, generator=gen) * 0.05).to(dev)
+        ext = torch.eye(4).repeat(b, 1, 1)
+        ext[:, :3, 3] = torch.randn(b, 3, generator=gen) * 0.05
+        k = torch.tensor([[200.0, 0, 128], [0, 210.0, 120], [0, 0, 1]]).repeat(b, 1, 1)
+        lin = FlowLinearization(pos, jac, ext.to(dev), k.to(dev))
+        truth = (torch.randn(b, a, generator=gen) * 0.5).to(dev)
+        target = lin.optical_flow(truth)
+        mask = (torch.rand(b, r, generator=gen) > 0.2).float().to(dev)
+        init = (torch.randn(b, a, generator=gen) * 0.1).to(dev)
+        for kwargs in (dict(), dict(visible_mask=mask), dict(init_action=init, iterations=5)):
+            got = solve_action(lin, target, **kwargs)
+            ref = lm_reference.lm_solve_action(lin, target, **kwargs)
+            assert torch.allclose(got, ref, atol=2e-4, rtol=1e-3), (b, r, a, kwargs.keys(), (got - ref).abs().max().item())
+            assert torch.equal(got, solve_action(lin, target, **kwargs))
+        if 2 * r >= a:
+            assert rel(lin.optical_flow(solve_action(lin, target)), target) < 1e-3
