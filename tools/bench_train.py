@@ -77,6 +77,17 @@ N = 10
 for i in range(N):
     step(3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+if os.environ.get("NJF_PROFILE"):  # steady-state kernel breakdown of 5 steps (after warm-up)
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for i in range(5):
+            step(20 + i)
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:18]
+    tot = sum(e.device_time_total for e in prof.key_averages())
+    print(f"steady-state device time per step: {tot / 5e3:.2f} ms")
+    for e in rows:
+        print(f"  {e.device_time_total / 5e3:7.3f} ms/step  x{e.count / 5:6.1f}  {e.key[:90]}")
 if WORLD > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
