@@ -62,7 +62,7 @@ __device__ __forceinline__ float mfma_step(float a, float b, f32x16& c) {
 // for the next one has been issued into the other buffer (whose readers all passed the barrier).
 // ------------------------------------------------------------------------------------------
 struct WeightStream {
-  const float* g;  // blob base (global)
+  __amdgpu_buffer_rsrc_t rsrc;  // the packed blob as a raw buffer (stride 0)
   int per_pass;    // chunks per tile pass
   int total;       // chunks over the whole workgroup lifetime
   int idx;         // next chunk to consume
@@ -71,17 +71,22 @@ struct WeightStream {
   // groups of the chunk being consumed (dma_round) instead of as one burst behind the barrier: the burst -- 8 waves x
   // 8 x 1 KiB through the CU's 64 B/clk vector-memory path, all at the same moment -- stalled every wave ~1,150
   // cycles per chunk at the issue of its own loads (17 % of the render kernel, measured with s_memtime stamps).
-  const float* dma_src;  // this lane's source of round 0
-  float* dma_dst;        // this wave's LDS destination of round 0
-  int dma_next;          // 0 = job pending, NJF_DMA_ROUNDS = issued (or nothing to prefetch)
+  int dma_voff;    // this lane's byte offset inside a wave's 1 KiB share of a round (lane * 16)
+  int dma_soff;    // byte offset (wave-uniform) of this wave's share of round 0 of the chunk being prefetched
+  float* dma_dst;  // this wave's LDS destination of round 0
+  int dma_next;    // 0 = job pending, NJF_DMA_ROUNDS = issued (or nothing to prefetch)
 };
 #define NJF_DMA_ROUNDS (NJF_CHUNK / (NJF_THREADS * 4))
 
 __device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
-  // 256 threads x 16 B = 4 KiB per round.  LDS destination is wave-uniform base + lane*16 (hardware), global source
-  // is per lane.
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st.dma_src + r * NJF_THREADS * 4),
-                                   (__attribute__((address_space(3))) void*)(st.dma_dst + r * NJF_THREADS * 4), 16, 0, 0);
+  // 256 threads x 16 B = 4 KiB per round.  LDS destination is wave-uniform base + lane*16 (hardware), the source is
+  // buffer base + wave-uniform byte offset (SGPR) + lane*16 (VGPR).  The MUBUF form (buffer_load_dwordx4 ... lds) is
+  // used instead of global_load_lds_dwordx4 on purpose: the latter is FLAT-encoded, and while a FLAT instruction that
+  // may touch LDS is outstanding hipcc's wait-count pass turns EVERY s_waitcnt into lgkmcnt(0)/vmcnt(0) -- the
+  // A-fragment prefetch of mma_chunk (ds_reads of unit u+1 issued before the MFMAs of unit u) then waits for the
+  // loads it has just issued.  With the buffer form the waits are exact (lgkmcnt(4)).
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (__attribute__((address_space(3))) void*)(st.dma_dst + r * NJF_THREADS * 4),
+                                           16, st.dma_voff, st.dma_soff + r * NJF_THREADS * 16, 0, 0);
 }
 
 // Issue the whole pending job at once (chunk shapes that do not interleave; start of the kernel).
@@ -93,20 +98,22 @@ __device__ __forceinline__ void stream_flush(WeightStream& st) {
   }
 }
 
-__device__ __forceinline__ void dma_job(WeightStream& st, const float* __restrict__ src, int buf, int wave, int lane) {
-  st.dma_src = src + wave * 256 + lane * 4;
+__device__ __forceinline__ void dma_job(WeightStream& st, int chunk, int buf, int wave) {
+  st.dma_soff = chunk * (NJF_CHUNK * 4) + wave * 1024;
   st.dma_dst = njf_lds + buf * NJF_CHUNK + wave * 256;
   st.dma_next = 0;
 }
 
 __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
                                              int lane) {
-  st.g = g;
+  // raw buffer descriptor: stride 0, num_records in bytes (range check far above any blob), dword 3 = 32-bit data format
+  st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7ffffff0, 0x00020000);
   st.per_pass = per_pass;
   st.total = per_pass * passes;
   st.idx = 0;
   st.in_pass = 0;
-  dma_job(st, g, 0, wave, lane);
+  st.dma_voff = lane * 16;
+  dma_job(st, 0, 0, wave);
   stream_flush(st);
 }
 
@@ -130,8 +137,36 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
   // The last chunk of a workgroup has nothing to prefetch.  Its consumer is always a lin_out-shaped chunk (MBO = 1),
   // which only ever calls stream_flush; the interleaving consumers (mma_chunk with MBO = 4) issue their 8 rounds
   // unconditionally and are never last.
-  if (st.idx < st.total) dma_job(st, st.g + (size_t)st.in_pass * NJF_CHUNK, st.idx & 1, wave, lane);
+  if (st.idx < st.total) dma_job(st, st.in_pass, st.idx & 1, wave);
   return cur;
+}
+
+// hi/lo split of two fp32 values (ReLU'd on request) into elements 2p, 2p+1 of the packed B operands:
+// hi = fp16(x), lo = fp16(x - hi) (the residual is exact in fp32, so lo carries the next 11 bits of x).
+// The residual and its conversion are ONE v_fma_mix{lo,hi}_f16 per value -- fma(-hi, 1.0, x) evaluated in fp32 and
+// rounded once to fp16, the same value because x - hi is exact -- instead of v_cvt_f32_f16 + v_sub_f32 + half a
+// v_cvt_pk_f16_f32: 2.5 instead of 3.5 VALU instructions per activation value (bit-identical outputs, -1.6 % frame
+// time).  hipcc does not select the mix form by itself (it folds fma(h, -1, x) back into a subtraction), hence asm;
+// the asm reads only results of compiler-visible VALU instructions (v_max / v_cvt_pk), never an MFMA result directly.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool RELU>
+__device__ __forceinline__ void split_pair(float x0, float x1, int p, f16x8& hi, f16x8& lo) {
+  if (RELU) {
+    x0 = relu_bits(x0);
+    x1 = relu_bits(x1);
+  }
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  hi[2 * p] = h0;
+  hi[2 * p + 1] = h1;
+  const f16x2 hp = {h0, h1};
+  const unsigned hu = __builtin_bit_cast(unsigned, hp);
+  unsigned lu;
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "v"(x1));
+  u32x4 lv = __builtin_bit_cast(u32x4, lo);
+  lv[p] = lu;
+  lo = __builtin_bit_cast(f16x8, lv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -183,13 +218,7 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
     constexpr int T = NKB * 2;
     f16x8 bh, bl;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float x = in[KB0][i];
-      if (RELU) x = relu_bits(x);
-      const _Float16 h = (_Float16)x;
-      bh[i] = h;
-      bl[i] = (_Float16)(x - (float)h);
-    }
+    for (int p = 0; p < 4; ++p) split_pair<RELU>(in[KB0][2 * p], in[KB0][2 * p + 1], p, bh, bl);
     if constexpr (MBO == 4) {
       // units u = (K-step t, pair of output blocks): the 4 A fragments of unit u+1 are requested (and pinned there
       // with sched_barrier) before the 6 MFMAs of unit u, which cover the LDS latency; 2 x 16 VGPRs of A live.
@@ -227,20 +256,7 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 #endif
             if (t + 1 < T) {
               const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
-#pragma unroll
-              for (int i = 2 * m; i < 2 * m + 2; ++i) {
-                float x = in[KB0 + kb2][8 * tt2 + i];
-                if (RELU) x = relu_bits(x);
-#ifdef NJF_ABLATE_SPLIT  // experiment builds only: no hi/lo conversion work
-                nh[i] = (_Float16)1.0f;
-                nl[i] = (_Float16)0.0f;
-                asm volatile("" :: "v"(x));
-#else
-                const _Float16 h = (_Float16)x;
-                nh[i] = h;
-                nl[i] = (_Float16)(x - (float)h);
-#endif
-              }
+              split_pair<RELU>(in[KB0 + kb2][8 * tt2 + 2 * m], in[KB0 + kb2][8 * tt2 + 2 * m + 1], m, nh, nl);
             }
           }
 #pragma unroll
@@ -262,13 +278,8 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
         if (t + 1 < T) {
           const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float x = in[KB0 + kb2][8 * tt2 + i];
-            if (RELU) x = relu_bits(x);
-            const _Float16 h = (_Float16)x;
-            nh[i] = h;
-            nl[i] = (_Float16)(x - (float)h);
-          }
+          for (int p = 0; p < 4; ++p)
+            split_pair<RELU>(in[KB0 + kb2][8 * tt2 + 2 * p], in[KB0 + kb2][8 * tt2 + 2 * p + 1], p, nh, nl);
         }
 #pragma unroll
         for (int m = 0; m < MBO; ++m) {
