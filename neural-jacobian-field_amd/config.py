@@ -1,7 +1,7 @@
 """Typed configuration mirroring the reference dataclasses (field names and defaults identical),
 without hydra/omegaconf/dacite.
 
-Reference: ``model_components/resnet_fc.py:11-18`` (MlpCfg), ``models/decoder/action_decoder_jacobian.py:33-61``,
+Reference: ``model_components/resnet_fc.py:11-18`` (MlpCfg), ``models/decoder/action_decoder_jacobian.py:33-61``, ``action_decoder_flow.py:32-39``,
 ``models/decoder/density_decoder.py:16-20``, ``models/encoder/encoder_resnet.py:15-21``,
 ``models/model.py:35-54`` (RenderingCfg, ModelCfg); YAML defaults in ``configurations/model/*.yaml``.
 """
@@ -67,9 +67,20 @@ class ActionDecoderJacobianTransformerCfg:
     arm_action_dim: Optional[int] = None
 
 
+@dataclass
+class ActionDecoderFlowMlpCfg:
+    """models/decoder/action_decoder_flow.py:32-39 (the field really is spelled ``num_frequncies`` there)."""
+    name: Literal["flow_mlp"] = "flow_mlp"
+    mlp: MlpCfg = field(default_factory=MlpCfg)
+    num_frequncies: int = 10
+    geometry_feature_dim: int = 15
+    use_arm_model: bool = False
+    arm_action_dim: Optional[int] = None
+
+
 EncoderCfg = EncoderResnetCfg
 DensityDecoderCfg = DensityDecoderMlpCfg
-ActionDecoderCfg = Union[ActionDecoderJacobianMlpCfg, ActionDecoderJacobianTransformerCfg]
+ActionDecoderCfg = Union[ActionDecoderJacobianMlpCfg, ActionDecoderFlowMlpCfg, ActionDecoderJacobianTransformerCfg]
 
 
 @dataclass
@@ -96,6 +107,7 @@ class ModelCfg:
 _ACTION_DECODER_CFGS = {
     "jacobian_mlp": ActionDecoderJacobianMlpCfg,
     "jacobian_transformer": ActionDecoderJacobianTransformerCfg,
+    "flow_mlp": ActionDecoderFlowMlpCfg,
 }
 
 

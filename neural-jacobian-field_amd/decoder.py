@@ -2,7 +2,7 @@
 state-dict-compatible parameter trees) whose forward passes run in the fused HIP kernels.
 
 Reference: ``models/decoder/__init__.py:11-44`` (registries), ``action_decoder.py:11-64``,
-``action_decoder_jacobian.py:86-337``, ``density_decoder.py:23-71``,
+``action_decoder_jacobian.py:86-337``, ``action_decoder_flow.py:64-290``, ``density_decoder.py:23-71``,
 ``model_components/resnet_fc.py:82-154``.
 """
 
@@ -17,8 +17,8 @@ import torch.nn as nn
 
 from . import hip
 from .encoder import FeaturePyramid
-from .config import (ActionDecoderCfg, ActionDecoderJacobianMlpCfg, ActionDecoderJacobianTransformerCfg,
-                     DensityDecoderCfg, DensityDecoderMlpCfg, MlpCfg)
+from .config import (ActionDecoderCfg, ActionDecoderFlowMlpCfg, ActionDecoderJacobianMlpCfg,
+                     ActionDecoderJacobianTransformerCfg, DensityDecoderCfg, DensityDecoderMlpCfg, MlpCfg)
 
 
 # --------------------------------------------------------------------------------------
@@ -73,18 +73,21 @@ class ResnetFC(nn.Module):
     the fused kernels, reached through the owning decoder; the geometry it supports is the shipped one
     (``MlpCfg(n_blocks=5, d_hidden=128, combine_layer=3, beta=0)``, d_in=63, d_latent=512)."""
 
-    def __init__(self, resnet_cfg: MlpCfg, d_in: int, d_latent: int, d_out: int):
+    def __init__(self, resnet_cfg: MlpCfg, d_in: int, d_latent: int, d_out: int, extra_latent: int = 0):
+        """``extra_latent``: latent columns beyond the 512 encoder channels that are CONSTANT per batch element (the
+        robot action of ``flow_mlp``, action_decoder_flow.py:100-106); the owning decoder folds their ``lin_z``
+        contribution into the hoisted map's bias, the kernels only ever see 512 feature channels."""
         super().__init__()
         if (resnet_cfg.n_blocks, resnet_cfg.d_hidden, resnet_cfg.combine_layer) != (5, 128, 3) or resnet_cfg.beta > 0:
             raise ValueError("fused ResnetFC supports MlpCfg(n_blocks=5, d_hidden=128, combine_layer=3, beta=0) only")
-        if d_in != 63 or d_latent != 512 or not (1 <= d_out <= 32):
-            raise ValueError("fused ResnetFC supports d_in=63, d_latent=512, 1 <= d_out <= 32")
-        self.resnet_cfg, self.d_latent, self.d_out = resnet_cfg, d_latent, d_out
+        if d_in != 63 or d_latent != 512 or not (1 <= d_out <= 32) or extra_latent < 0:
+            raise ValueError("fused ResnetFC supports d_in=63, d_latent=512 (+ per-batch constants), 1 <= d_out <= 32")
+        self.resnet_cfg, self.d_latent, self.d_out = resnet_cfg, d_latent + extra_latent, d_out
         h = resnet_cfg.d_hidden
         self.lin_in = nn.Linear(d_in, h)
         self.lin_out = nn.Linear(h, d_out)
         self.blocks = nn.ModuleList([ResnetBlockFC(h) for _ in range(resnet_cfg.n_blocks)])
-        self.lin_z = nn.ModuleList([nn.Linear(d_latent, h) for _ in range(resnet_cfg.combine_layer)])
+        self.lin_z = nn.ModuleList([nn.Linear(d_latent + extra_latent, h) for _ in range(resnet_cfg.combine_layer)])
         for lin in [self.lin_in, self.lin_out, *self.lin_z]:
             nn.init.constant_(lin.bias, 0.0)
             nn.init.kaiming_normal_(lin.weight, a=0, mode="fan_in")
@@ -130,14 +133,18 @@ class _HoistCache:
         return self.gmap
 
 
-def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trgt_w2c=None, trgt_k=None, action_dim=None):
+def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trgt_w2c=None, trgt_k=None, action_dim=None,
+             action=None):
+    """``action``: what the kernel contracts the head's output with (default: the robot action itself)."""
     b = enc.extrinsics.shape[0]
     dev = enc.extrinsics.device
     zeros = torch.zeros(b, dtype=torch.float32, device=dev)
+    if action is None:
+        action = enc.action
     return hip.make_cameras(hip.inverse(enc.extrinsics).contiguous(), enc.intrinsics.contiguous(),
                             zeros if z_near is None else z_near.contiguous(),
                             zeros if z_far is None else z_far.contiguous(), trgt_w2c, trgt_k,
-                            enc.action.contiguous() if with_action else None, action_dim)
+                            action.contiguous() if with_action else None, action_dim)
 
 
 # --------------------------------------------------------------------------------------
@@ -218,7 +225,8 @@ class ActionDecoderJacobian(ActionDecoder):
     GOFF_DENSITY, GOFF_JACOBIAN = 0, hip.ZDIM
 
     def _init_common(self, cfg, action_dim: int, encoder_dim: int, max_action: int):
-        if cfg.num_frequencies != 10 or cfg.geometry_feature_dim != 15:
+        n_freq = cfg.num_frequncies if hasattr(cfg, "num_frequncies") else cfg.num_frequencies
+        if n_freq != 10 or cfg.geometry_feature_dim != 15:
             raise ValueError("fused path supports num_frequencies=10 and geometry_feature_dim=15")
         if cfg.use_arm_model:
             raise NotImplementedError("use_arm_model (second Jacobian head) is not part of the fused path")
@@ -261,15 +269,25 @@ class ActionDecoderJacobian(ActionDecoder):
             self._packed_version = v
         return self._w, self._bd, self._bc, self._bj
 
-    def hoisted_map(self, features: torch.Tensor) -> torch.Tensor:
+    def hoisted_map(self, features: torch.Tensor, action: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Per-image hoisted map.  ``action`` ([B,A]) only matters to decoders whose head takes the action as a latent
+        input (``flow_mlp``); the Jacobian decoders ignore it."""
         self.packed()
         return self._hoist.get(features, self._packed_version, self._wz, self._bz, self.precision)
+
+    # what the kernel contracts the head's 3*A' outputs with: the robot action for the Jacobian heads
+    @property
+    def kernel_action_dim(self) -> int:
+        return self.action_dim
+
+    def kernel_action(self, action: torch.Tensor) -> torch.Tensor:
+        return action
 
     def _points(self, xyz_flat, dirs_flat, enc: PixelEncoding, with_jacobian: bool, want: Dict[str, bool]):
         b, n = xyz_flat.shape[:2]
         dev = xyz_flat.device
         w, bd, bc, bj = self.packed()
-        fmap = hip.make_feature_map(self.hoisted_map(enc.features))
+        fmap = hip.make_feature_map(self.hoisted_map(enc.features, enc.action))
         f32 = dict(dtype=torch.float32, device=dev)
         out = {"density": torch.empty(b, n, 1, **f32)}
         if want.get("color"):
@@ -277,11 +295,12 @@ class ActionDecoderJacobian(ActionDecoder):
         if want.get("geo"):
             out["geo"] = torch.empty(b, n, 15, **f32)
         if with_jacobian:
-            out["jacobian"] = torch.empty(b, n, 3 * self.action_dim, **f32)
+            out["jacobian"] = torch.empty(b, n, 3 * self.kernel_action_dim, **f32)
             if want.get("flow"):
                 out["flow"] = torch.empty(b, n, 3, **f32)
         hip.points_forward(xyz_flat.contiguous(), None if dirs_flat is None else dirs_flat.contiguous(),
-                           _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.action_dim), fmap,
+                           _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.kernel_action_dim,
+                                    action=self.kernel_action(enc.action)), fmap,
                            self.GOFF_DENSITY, self.GOFF_JACOBIAN, 1, w, bd, bc, bj,
                            jacobian_kind=self.JACOBIAN_KIND if with_jacobian else hip.JACOBIAN_NONE,
                            precision=self.precision, **out)
@@ -341,6 +360,86 @@ class ActionDecoderJacobianMLP(ActionDecoderJacobian):
 
     def _pack_jacobian(self, params, w_j, b_j, wz, bz):
         hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.precision)
+
+
+def initialize_flow_weights(m: nn.Module) -> None:
+    """action_decoder_flow.py:56-61 (same rule as the Jacobian heads)."""
+    initialize_jacobian_weights(m)
+
+
+class ActionDecoderFlowMlp(ActionDecoderJacobian):
+    """action_decoder_flow.py:64-290 (``flow_mlp``, the reference's direct-flow ablation): density + colour heads as in
+    the Jacobian decoders, and ``flow_head = ResnetFC(d_latent = encoder_dim + action_dim, d_out = 3)`` evaluated on
+    ``cat[pixel_aligned_features, action]`` -- the scene flow itself, not a Jacobian.
+
+    On the fused path the action never reaches the per-point kernel as an input: it is constant per batch element and
+    enters only through ``lin_z``, so ``lin_z(cat[f, a]) = W_f f + (W_a a + b)`` and the bracket is a per-image bias of
+    the hoisted map (``hoisted_map`` adds it to the flow head's 384 channels).  The kernel then runs the flow head as a
+    "Jacobian head" with ONE action channel contracted with the constant 1.0, which returns its three outputs unchanged.
+
+    Not offered (and why): ``encode_image`` (the reference's own version returns a ``map`` object that
+    ``Model.encode_image`` cannot consume, action_decoder_flow.py:246-279), ``use_arm_model``, training of the flow
+    head, and the 640-channel hidden ``action_features`` of ``DecoderOutput`` (nothing in the reference reads them for
+    this decoder; ``DecoderOutput.action_features`` is None and the composited visualisation slot holds the scene flow).
+    """
+
+    action_param_glob_pattern = "flow_head"
+    JACOBIAN_KIND = hip.JACOBIAN_MLP
+    J_W_FLOATS, J_B_FLOATS, J_HOIST = hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM
+
+    def __init__(self, cfg: ActionDecoderFlowMlpCfg, action_dim: int, encoder_dim: int):
+        super().__init__(cfg)
+        self._init_common(cfg, action_dim, encoder_dim, 1 << 16)  # the kernel sees one channel, any A works
+        self.flow_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim, extra_latent=action_dim)
+        self.flow_head.apply(initialize_flow_weights)
+        self.color_head = self._make_color_head(cfg)
+        self._ones = None
+
+    @property
+    def kernel_action_dim(self) -> int:
+        return 1
+
+    def kernel_action(self, action: torch.Tensor) -> torch.Tensor:
+        if self._ones is None or self._ones.shape[0] != action.shape[0] or self._ones.device != action.device:
+            self._ones = torch.ones(action.shape[0], 1, dtype=torch.float32, device=action.device)
+        return self._ones
+
+    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+        enc_dim = self.flow_head.d_latent - self.action_dim
+        sliced = dict(params)
+        for i in range(3):  # the kernels hoist the 512 feature columns; the action columns become a bias (hoisted_map)
+            sliced[f"flow_head.lin_z.{i}.weight"] = params[f"flow_head.lin_z.{i}.weight"][:, :enc_dim].contiguous()
+        hip.pack_resnetfc(sliced, "flow_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.precision)
+
+    @torch.no_grad()
+    def hoisted_map(self, features: torch.Tensor, action: Optional[torch.Tensor] = None) -> torch.Tensor:
+        base = super().hoisted_map(features)
+        if action is None:
+            raise ValueError("flow_mlp: the hoisted map depends on the robot action (PixelEncoding.action)")
+        enc_dim = self.flow_head.d_latent - self.action_dim
+        w_a = torch.stack([lin.weight[:, enc_dim:] for lin in self.flow_head.lin_z])       # [3,128,A]
+        delta = torch.einsum("lfa,ba->blf", w_a, action.to(w_a.dtype))                       # [B,3,128] logical order
+        f = torch.arange(128, device=delta.device)                                           # csrc: njf_hoist_position(f, 4)
+        pos = 32 * ((f % 64) // 16) + 8 * ((f % 16) // 4) + 4 * (f // 64) + (f % 4)
+        permuted = torch.empty_like(delta)
+        permuted[:, :, pos] = delta
+        gmap = base.clone()
+        gmap[..., self.GOFF_JACOBIAN:self.GOFF_JACOBIAN + hip.ZDIM] += permuted.reshape(-1, 1, 1, hip.ZDIM)
+        return gmap
+
+    @torch.no_grad()
+    def forward(self, world_space_xyz, world_space_dir, pixel_encoding: PixelEncoding) -> DecoderOutput:
+        """action_decoder_flow.py:185-244."""
+        out = super().forward(world_space_xyz, world_space_dir, pixel_encoding)
+        return DecoderOutput(out.density, out.color, out.flow, None)
+
+    def encode_image(self, world_space_xyz, pixel_encoding: PixelEncoding):
+        raise NotImplementedError("flow_mlp has no usable encode_image in the reference either "
+                                  "(action_decoder_flow.py:246-279 returns a map object); use a Jacobian decoder for "
+                                  "inverse dynamics")
+
+    def compute_jacobian_at(self, world_space_xyz, pixel_encoding: PixelEncoding):
+        raise NotImplementedError("flow_mlp predicts the scene flow directly; it has no Jacobian")
 
 
 # ---- parameter tree of model_components/transformer.py (names only; arithmetic is folded + fused) ----
@@ -448,7 +547,8 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
 # registries (models/decoder/__init__.py:11-44)
 # --------------------------------------------------------------------------------------
 DENSITY_DECODERS = {"density_mlp": DensityDecoderMlp}
-ACTION_DECODERS = {"jacobian_mlp": ActionDecoderJacobianMLP, "jacobian_transformer": ActionDecoderJacobianTransformer}
+ACTION_DECODERS = {"jacobian_mlp": ActionDecoderJacobianMLP, "jacobian_transformer": ActionDecoderJacobianTransformer,
+                   "flow_mlp": ActionDecoderFlowMlp}
 
 
 def get_density_decoder(cfg: DensityDecoderCfg, encoder_dim: int) -> DensityDecoderMlp:

@@ -220,7 +220,7 @@ class Model(nn.Module):
         o, d = rendering_input.origins.contiguous(), rendering_input.directions.contiguous()
         b, r = o.shape[:2]
         s = self.cfg.rendering.num_nerf_samples
-        a3 = 3 * self.cfg.action_dim
+        a3 = 3 * self.decoder.kernel_action_dim  # 3A for the Jacobian decoders, 3 for flow_mlp (the flow itself)
         dev = o.device
         f32 = dict(dtype=torch.float32, device=dev)
         outs: Dict[str, torch.Tensor] = {"rgb": torch.empty(b, r, 3, **f32), "depth": torch.empty(b, r, 1, **f32),
@@ -256,10 +256,10 @@ class Model(nn.Module):
             outs["col_in"] = torch.empty(pts, 32, **f32)
             outs["col_act"] = torch.empty(2, pts, 64, **f32)
         w, bd, bc, bj = self.decoder.packed()
-        fmap = hip.make_feature_map(self.decoder.hoisted_map(features))
+        fmap = hip.make_feature_map(self.decoder.hoisted_map(features, enc.action))
         cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
                         hip.inverse(camera_input.trgt_extrinsics).contiguous(),
-                        camera_input.trgt_intrinsics.contiguous())
+                        camera_input.trgt_intrinsics.contiguous(), action=self.decoder.kernel_action(enc.action))
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
                            {k: v for k, v in outs.items() if torch.is_tensor(v)},
                            jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
@@ -275,6 +275,10 @@ class Model(nn.Module):
         output, and every call under ``torch.no_grad()`` / with frozen parameters, is a plain inference pass."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training
+            if self.cfg.action_decoder.name == "flow_mlp" and any(
+                    n.startswith("decoder.flow_head") for n in training.trainable_names(self)):
+                raise NotImplementedError("flow_mlp is an inference-only decoder on the fused path: its flow head has no "
+                                          "backward pass here (freeze decoder.flow_head or call under torch.no_grad())")
             if training.is_action_mode(self):
                 return self._forward_action_grad(camera_input, rendering_input, robot_input, compute_vis_features)
             return self._forward_perception_grad(camera_input, rendering_input, robot_input, compute_vis_features)
@@ -405,6 +409,9 @@ class Model(nn.Module):
     def encode_image(self, camera_input: CameraInput, rendering_input: RenderingInput,
                      robot_input: RobotInput) -> ModelInferenceEncoding:
         """model.py:458-495: proposal sampling + per-sample density/Jacobian/weights, cached for inverse dynamics."""
+        if "jacobian" not in self.cfg.action_decoder.name:
+            raise NotImplementedError("encode_image caches per-sample Jacobians (model.py:458-495); flow_mlp has none -- "
+                                      "the reference's own flow_mlp.encode_image is unusable as well")
         features = self._encode_for_render(camera_input.input_image)
         outs, bins, _, _, ray_bundle = self._fused_render(camera_input, rendering_input, robot_input, features,
                                                          want_lists=False, want_vis=False, want_samples=True)

@@ -77,6 +77,8 @@ def decoder_shapes(kind: str, action_dim: int, encoder_dim: int = 512, pe_dim: i
             _linear(out, base + "1.fn.net.0", mlp_dim, attn_feat_dim)
             _linear(out, base + "1.fn.net.3", attn_feat_dim, mlp_dim)
         _linear(out, prefix + "jacobian_head", 3 * action_dim, attn_feat_dim)
+    elif kind == "flow_mlp":  # models/decoder/action_decoder_flow.py:100-106: the action joins the latent
+        out.update(resnet_fc_shapes(prefix + "flow_head.", pe_dim, encoder_dim + action_dim, 3))
     else:
         raise ValueError(f"unknown action decoder {kind!r}")
     out.update(color_head_shapes(prefix, geo_dim))
@@ -166,6 +168,10 @@ def seeded_tensor(name: str, shape: Shape, seed: int = 0, linear_std: float = 0.
         t[-1] *= 3.0
     if name.endswith("density_head.lin_out.bias"):
         t[-1] += 2.0
+    # flow_mlp predicts the scene flow itself: keep it at the ~0.1 m scale J.a has for the Jacobian decoders, so the
+    # warped points stay in front of the target camera and the projected flow is well conditioned
+    if name.endswith("flow_head.lin_out.weight") or name.endswith("flow_head.lin_out.bias"):
+        t *= 0.1
     return t
 
 

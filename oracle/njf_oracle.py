@@ -434,6 +434,12 @@ def jacobian_mlp(params: Params, feats: Tensor, pe: Tensor) -> Tensor:
     return resnet_fc(_sub(params, "jacobian_head."), feats, pe)
 
 
+def flow_mlp(params: Params, feats: Tensor, pe: Tensor, action: Tensor) -> Tensor:
+    """NJF/models/decoder/action_decoder_flow.py:165-183 (ActionDecoderFlowMlp.compute_flow): ResnetFC with
+    d_latent = encoder_dim + action_dim on cat[pixel_aligned_features, action]; d_out = 3."""
+    return resnet_fc(_sub(params, "flow_head."), torch.cat([feats, action], dim=-1), pe)
+
+
 def jacobian_transformer(params: Params, feats: Tensor, pe: Tensor, heads: int = 8, depth: int = 3) -> Tensor:
     """NJF/models/decoder/action_decoder_jacobian.py:418-446 + transformer.py:85-135."""
     x = _affine(params, "jacobian_query_mlp", torch.cat([pe, feats], dim=-1))
@@ -461,10 +467,15 @@ def decoder_forward(params: Params, xyz: Tensor, dirs: Tensor, enc: PixelEncodin
     """
     b, r, s = xyz.shape[:3]
     dens, geo, pe, feats = decoder_density(params, xyz.reshape(b, r * s, 3), enc)
-    jac = jacobian_mlp(params, feats, pe) if kind == "jacobian_mlp" else jacobian_transformer(params, feats, pe)
     action = enc.action[:, None, :].expand(b, r * s, action_dim)
-    # :128-145 -- J viewed (action_dim, spatial_dim), contracted with the action
-    flow = torch.einsum("bnas,bna->bns", jac.reshape(b, r * s, action_dim, -1), action)
+    if kind == "flow_mlp":
+        # NJF/models/decoder/action_decoder_flow.py:165-183 (compute_flow): the action is concatenated to the pixel-aligned
+        # features and the head outputs the scene flow directly; there is no Jacobian ("jac" = the head's raw output)
+        flow = jac = flow_mlp(params, feats, pe, action)
+    else:
+        jac = jacobian_mlp(params, feats, pe) if kind == "jacobian_mlp" else jacobian_transformer(params, feats, pe)
+        # :128-145 -- J viewed (action_dim, spatial_dim), contracted with the action
+        flow = torch.einsum("bnas,bna->bns", jac.reshape(b, r * s, action_dim, -1), action)
     dir01 = ((dirs + 1.0) / 2.0).reshape(b * r * s, 3)  # :24-30, :194-198
     sh = sh4_encoding(dir01.contiguous()).reshape(b, r, s, -1)
     geo = geo.reshape(b, r, s, -1)

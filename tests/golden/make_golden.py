@@ -184,7 +184,7 @@ def main():
     from neural_jacobian_field.model_components import activations, pixel_aligned_features
     from neural_jacobian_field.model_components.resnet_fc import MlpCfg, ResnetFC
     from neural_jacobian_field.models import model as ref_model
-    from neural_jacobian_field.models.decoder import (ActionDecoderJacobianMlpCfg,
+    from neural_jacobian_field.models.decoder import (ActionDecoderFlowMlpCfg, ActionDecoderJacobianMlpCfg,
                                                        ActionDecoderJacobianTransformerCfg, DensityDecoderMlpCfg)
     from neural_jacobian_field.models.decoder.action_decoder import PixelEncoding
     from neural_jacobian_field.models.decoder.action_decoder_jacobian import TransformerCfg
@@ -275,6 +275,8 @@ def main():
         name="jacobian_transformer", mlp=mlp_cfg,
         transformer=TransformerCfg(attn_feat_dim=64, attn_head_dim=64, num_attn_heads=8, attn_depth=3, attn_mlp_dim=64))
 
+    flow_dec = ActionDecoderFlowMlpCfg(name="flow_mlp", mlp=mlp_cfg)  # the reference's direct-flow ablation decoder
+
     def build(dec_cfg, action_dim, n_prop, n_nerf):
         rcfg = ref_model.RenderingCfg(num_proposal_samples=tuple(n_prop), num_nerf_samples=n_nerf, single_jitter=False,
                                       proposal_warmup=5000, proposal_update_every=5, use_proposal_weight_anneal=True,
@@ -300,7 +302,7 @@ def main():
     kpix = convention.denormalize_intrinsics(Kn, width=W, height=H)
     z_near, z_far = torch.tensor([0.5, 0.4]), torch.tensor([10.0, 6.0])
 
-    for tag, dec_cfg, A in (("mlp", mlp_dec, 8), ("transformer", tr_dec, 6)):
+    for tag, dec_cfg, A in (("mlp", mlp_dec, 8), ("transformer", tr_dec, 6), ("flow", flow_dec, 5)):
         model, shapes = build(dec_cfg, A, [16], 12)
         manifest[tag] = {k: list(v) for k, v in shapes.items()}
         action = 0.1 * randn(25, B, A)
@@ -309,6 +311,28 @@ def main():
         rin = ref_model.RenderingInput(origins=ro, directions=rd, z_near=z_near, z_far=z_far)
         rob = ref_model.RobotInput(robot_action=action)
         model.eval()
+        if tag == "flow":
+            # flow_mlp: Model.forward + the decoder on the final samples.  No visualisation features (640 hidden
+            # channels nothing reads), no encode_image / infer_optical_flow (the reference's flow_mlp.encode_image
+            # returns a map object, action_decoder_flow.py:246-279).  The action is scaled up so that its path through
+            # lin_z is well above the comparison tolerance.
+            action = 5.0 * action
+            rob = ref_model.RobotInput(robot_action=action)
+            with torch.no_grad():
+                feats_e = model.encoder.forward(image)
+                out = model.forward(cam, rin, rob)
+                out0 = model.forward(cam, rin, ref_model.RobotInput(robot_action=torch.zeros_like(action)))
+                penc = PixelEncoding(features=feats_e, extrinsics=ctx_c2w, intrinsics=Kn, action=action)
+                rb = model.compute_ray_bundle(rin)
+                samples, pos, dirs, wl, sl = model.compute_proposal(rb, penc)
+                dec = model.decoder.forward(world_space_xyz=pos, world_space_dir=dirs, pixel_encoding=penc)
+            save("model_flow", image=image, features=feats_e, ctxt_c2w=ctx_c2w, ctxt_k_norm=Kn, trgt_c2w=trg_c2w,
+                 trgt_k_pix=kpix, origins=ro, directions=rd, z_near=z_near, z_far=z_far, action=action,
+                 rgb=out.standard_output.rgb, depth=out.standard_output.depth,
+                 optical_flow=out.standard_output.optical_flow, optical_flow_zero_action=out0.standard_output.optical_flow,
+                 final_starts=samples.starts, final_ends=samples.ends, final_positions=pos,
+                 dec_density=dec.density, dec_color=dec.color, dec_flow=dec.flow)
+            continue
         with torch.no_grad():
             feats_e = model.encoder.forward(image)
             out = model.forward(cam, rin, rob, compute_vis_features=True)

@@ -58,7 +58,8 @@ def test_product_package_never_imports_the_oracle():
                 assert "njf_oracle" not in src and "parity_harness" not in src and "lm_reference" not in src, f
 
 
-@pytest.mark.parametrize("tag,kind,adim", [("mlp", "jacobian_mlp", 8), ("transformer", "jacobian_transformer", 6)])
+@pytest.mark.parametrize("tag,kind,adim", [("mlp", "jacobian_mlp", 8), ("transformer", "jacobian_transformer", 6),
+                                           ("flow", "flow_mlp", 5)])
 def test_model_state_dict_matches_reference_manifest(tag, kind, adim):
     from neural_jacobian_field_amd.config import model_cfg_from_dict
     from neural_jacobian_field_amd.model import Model
@@ -101,8 +102,10 @@ encoder: {name: resnet, use_first_pool: true, num_layers: 4, norm_type: batch, u
     cfg = model_cfg_from_dict(yaml.safe_load(text))
     assert cfg.action_dim == 6 and cfg.rendering.num_proposal_samples == (256,)
     assert cfg.action_decoder.name == "jacobian_mlp" and cfg.encoder.num_layers == 4
+    flow = model_cfg_from_dict({"action_decoder": {"name": "flow_mlp", "num_frequncies": 10}})   # the reference's spelling
+    assert flow.action_decoder.name == "flow_mlp" and flow.action_decoder.num_frequncies == 10
     with pytest.raises(KeyError):
-        model_cfg_from_dict({"action_decoder": {"name": "flow_mlp"}})
+        model_cfg_from_dict({"action_decoder": {"name": "no_such_decoder"}})
 
 
 def test_anneal_schedule_matches_oracle():

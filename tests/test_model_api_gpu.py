@@ -248,6 +248,54 @@ def test_transformer_model_forward_vs_reference_golden(transformer_model_and_gol
     assert rel(out.vis_output.action_features, g["vis_action_features"]) < 1e-3
 
 
+# ---- flow_mlp decoder (the reference's direct-flow ablation, models/decoder/action_decoder_flow.py) ----
+@pytest.fixture(scope="module")
+def flow_model_and_golden(dev, golden):
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    g = golden("model_flow")
+    cfg = model_cfg_from_dict({"action_dim": 5, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                               "action_decoder": {"name": "flow_mlp"}})
+    model = Model(cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("flow_mlp", 5), seed=0), strict=True)
+    model.to(dev).eval().requires_grad_(False)
+    return model, {k: v.to(dev) for k, v in g.items()}
+
+
+def test_flow_mlp_decoder_at_reference_sample_locations(flow_model_and_golden):
+    """The action enters the flow head as a latent input; on the fused path it is a per-image bias of the hoisted map."""
+    from neural_jacobian_field_amd.decoder import PixelEncoding
+    model, g = flow_model_and_golden
+    enc = PixelEncoding(g["features"], g["ctxt_c2w"], g["ctxt_k_norm"], g["action"])
+    pos = g["final_positions"]
+    dirs = g["directions"][..., None, :].expand(pos.shape).contiguous()
+    dec = model.decoder.forward(pos, dirs, enc)
+    assert rel(dec.flow[0], g["dec_flow"][0]) < 1e-4        # identity-context batch element: tight
+    assert rel(dec.density[0], g["dec_density"][0]) < 1e-4
+    assert rel(dec.flow, g["dec_flow"]) < 5e-4              # general pose element: the encoding's ulp amplification
+    assert rel(dec.color, g["dec_color"]) < 5e-4
+    assert dec.action_features is None
+    with pytest.raises(NotImplementedError):
+        model.decoder.encode_image(pos, enc)
+
+
+def test_flow_mlp_model_forward_vs_reference_golden(flow_model_and_golden):
+    from neural_jacobian_field_amd.model import RobotInput
+    model, g = flow_model_and_golden
+    cam, rin, rob = _inputs(g)
+    out = model.forward(cam, rin, rob)
+    assert rel(out.standard_output.rgb, g["rgb"]) < 1e-4
+    assert rel(out.standard_output.depth, g["depth"]) < 5e-4
+    assert rel(out.standard_output.optical_flow, g["optical_flow"]) < 1e-3
+    # a different action on the same image: the hoisted map's feature part is cached, its action bias is not
+    out0 = model.forward(cam, rin, RobotInput(torch.zeros_like(g["action"])))
+    assert rel(out0.standard_output.optical_flow, g["optical_flow_zero_action"]) < 1e-3
+    assert rel(out0.standard_output.optical_flow, g["optical_flow"]) > 1e-2   # and the two really differ
+    with pytest.raises(NotImplementedError):
+        model.encode_image(cam, rin, rob)
+
+
 def test_hoisted_map_cache_is_not_fooled_by_recycled_memory(model_and_golden):
     """Consecutive forwards on different images (the freed feature tensor's address is typically reused by the
     allocator) must re-project the feature map."""

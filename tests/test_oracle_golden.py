@@ -27,7 +27,7 @@ def close(a, b, tol=0.0):
 def test_state_dict_manifest_matches_reference():
     with open(os.path.join(GOLDEN, "state_dict_manifest.json")) as f:
         manifest = json.load(f)
-    for tag, kind, adim in (("mlp", "jacobian_mlp", 8), ("transformer", "jacobian_transformer", 6)):
+    for tag, kind, adim in (("mlp", "jacobian_mlp", 8), ("transformer", "jacobian_transformer", 6), ("flow", "flow_mlp", 5)):
         mine = {k: list(v) for k, v in synthetic.model_shapes(kind, adim).items()}
         assert mine == manifest[tag]
 
@@ -129,6 +129,27 @@ def test_model_forward(golden, tag, kind, adim):
     close(rt.samples_list[1].starts, g["train_starts1"], tol=1e-6); close(rt.weights_list[1], g["train_w1"], tol=1e-5)
     close(rt.rgb, g["train_rgb"], tol=1e-5); close(rt.depth, g["train_depth"], tol=1e-5)
     close(rt.optical_flow, g["train_flow"], tol=1e-5)
+
+
+def test_model_forward_flow_mlp(golden):
+    """The reference's direct-flow ablation decoder (action_decoder_flow.py): Model.forward and the decoder on the final
+    samples.  The flow head's input latent is cat[pixel-aligned features, action]."""
+    g = golden("model_flow")
+    params = synthetic.seeded_state_dict(synthetic.model_shapes("flow_mlp", 5), seed=0)
+    common = dict(ctxt_c2w=g["ctxt_c2w"], ctxt_k_norm=g["ctxt_k_norm"], trgt_c2w=g["trgt_c2w"], trgt_k_pix=g["trgt_k_pix"],
+                  origins=g["origins"], directions=g["directions"], z_near=g["z_near"], z_far=g["z_far"],
+                  num_proposal_samples=[16], num_nerf_samples=12, decoder_kind="flow_mlp")
+    res = orc.model_forward(params, features=g["features"], action=g["action"], **common)
+    close(res.samples_list[1].starts, g["final_starts"]); close(res.samples_list[1].ends, g["final_ends"])
+    close(res.positions, g["final_positions"])
+    close(res.density, g["dec_density"]); close(res.color, g["dec_color"])
+    close(res.flow, g["dec_flow"], tol=1e-6)
+    close(res.rgb, g["rgb"]); close(res.depth, g["depth"])
+    close(res.optical_flow, g["optical_flow"], tol=1e-6)
+    res0 = orc.model_forward(params, features=g["features"], action=torch.zeros_like(g["action"]), **common)
+    close(res0.optical_flow, g["optical_flow_zero_action"], tol=1e-6)
+    # the action matters: its path through lin_z moves the rendered flow far more than any tolerance used here
+    assert (g["optical_flow"] - g["optical_flow_zero_action"]).abs().max() > 1e-3 * g["optical_flow"].abs().max()
 
 
 def test_composite_and_losses(golden):
