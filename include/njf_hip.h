@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 5
+#define NJF_ABI_VERSION 6
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -239,6 +239,17 @@ int njf_alpha_weights(const float* deltas, const float* densities, int rays, int
 /* PDFSampler.generate_ray_samples (ray_samplers.py:351-451) on spacing bins. */
 int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ray, int s_in, const float* u,
                      int u_per_ray, int s_out, float anneal, int rays, float* bins_out, void* stream);
+
+/* ---- training: backward of the pixel-aligned bilinear sampling -------------------------------- */
+/* Input gradient of F.grid_sample(bilinear, border, align_corners=True) as get_pixel_aligned_features uses it
+ * (model_components/pixel_aligned_features.py:29-33), in hoisted order: grad [P,channels] is the gradient w.r.t. the
+ * sampled (already lin_z-projected) latent of every point, foot_idx [P,4] (int32 texel index on the flattened
+ * [B*Hf*Wf] grid) / foot_w [P,4] the bilinear footprint the training forward dumped (NjfActivationDump).
+ * out [texels,channels] += sum over points and footprint corners (accumulates: zero it first for a fresh gradient).
+ * channels % 4 == 0.  fp32 hardware atomics: the summation order, hence the last bits, vary from run to run
+ * (as they do for ATen's grid_sampler_2d_backward on a GPU). */
+int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels, int texels,
+                          float* out, void* stream);
 
 /* ---- inverse dynamics on the composited Jacobian field ---------------------------------------- */
 /* The control loop of notebooks/real_world/2_inverse_dynamics.ipynb (cells 26-29: 100 Adam steps through

@@ -1238,6 +1238,46 @@ extern "C" int njf_solve_action(const float* mean_position, const float* jacobia
 }
 
 // =============================================================================================
+// backward of the pixel-aligned bilinear sampling (training)
+// =============================================================================================
+// out[foot_idx[p][c]] += foot_w[p][c] * grad[p]  for the four texels of every point's footprint: the input gradient of
+// F.grid_sample(bilinear, border, align_corners=True) (model_components/pixel_aligned_features.py:29-33) in hoisted
+// order, i.e. on the [P, channels] latent gradient BEFORE lin_z's transpose is applied per texel.  One thread per
+// (point, 4-channel group): 16 hardware fp32 atomics (global_atomic_add_f32, no CAS loop); neighbouring samples of a
+// ray share texels, so most of them hit the same L2 lines.
+__global__ void __launch_bounds__(256) scatter_footprint_kernel(const float* __restrict__ grad,
+                                                                const int* __restrict__ foot_idx,
+                                                                const float* __restrict__ foot_w, long long groups_total,
+                                                                int groups, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups_total) return;
+  const long long p = i / groups;
+  const int g = (int)(i - p * groups);
+  const f32x4 v = *(const f32x4*)(grad + (size_t)i * 4);
+  const int4 idx = *(const int4*)(foot_idx + (size_t)p * 4);
+  const f32x4 w = *(const f32x4*)(foot_w + (size_t)p * 4);
+  const int t[4] = {idx.x, idx.y, idx.z, idx.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float* dst = out + ((size_t)t[c] * groups + g) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, w[c] * v[e]);
+  }
+}
+
+extern "C" int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels,
+                                     int texels, float* out, void* stream) {
+  if (!grad || !foot_idx || !foot_w || !out) return NJF_E_NULL;
+  if (points < 1 || texels < 1 || channels < 4 || (channels & 3)) return NJF_E_SHAPE;
+  const int groups = channels / 4;
+  const long long total = (long long)points * groups;
+  if ((long long)texels * channels > 0x7fffffffLL * 4LL || (total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
+  scatter_footprint_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad, foot_idx, foot_w, total,
+                                                                                            groups, out);
+  return launch_status();
+}
+
+// =============================================================================================
 // stand-alone sampler ops
 // =============================================================================================
 __global__ void __launch_bounds__(256) alpha_weights_kernel(const float* __restrict__ deltas,

@@ -20,6 +20,8 @@ from typing import Callable, Dict, List, Sequence
 
 import torch
 
+from . import hip
+
 JACOBIAN_PARAM_ORDER: List[str] = (
     ["lin_in.weight", "lin_in.bias"]
     + [f"blocks.{b}.{fc}.{wb}" for b in range(5) for fc in ("fc_0", "fc_1") for wb in ("weight", "bias")]
@@ -68,7 +70,6 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     grads["lin_out.weight"] = _tn(d_out, r_out)
     grads["lin_out.bias"] = d_out.sum(0)
     delta = (d_out @ p["lin_out.weight"]) * (r_out > 0)
-    idx = None
     for blk in range(4, -1, -1):
         r0, r1 = act[2 * blk], act[2 * blk + 1]
         grads[f"blocks.{blk}.fc_1.weight"] = _tn(delta, r1)
@@ -78,11 +79,8 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
         grads[f"blocks.{blk}.fc_0.bias"] = d_net.sum(0)
         delta = delta + (d_net @ p[f"blocks.{blk}.fc_0.weight"]) * (r0 > 0)
         if blk < 3:  # lin_z[blk](bilinear(F)) was added here
-            if idx is None:
-                idx = foot_idx.long()
             d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
-            for c in range(4):
-                d_g.index_add_(0, idx[:, c], delta * foot_w[:, c:c + 1])
+            hip.scatter_footprint(delta.contiguous(), foot_idx, foot_w, d_g)   # grid_sample's input gradient, one launch
             grads[f"lin_z.{blk}.weight"] = _tn(d_g, feats_flat)
             grads[f"lin_z.{blk}.bias"] = delta.sum(0)
             if d_feats is not None:

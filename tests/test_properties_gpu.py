@@ -174,6 +174,26 @@ def test_pyramid_producer_equals_projecting_the_concatenated_map(dev, precision)
     assert err < 3e-6, err
 
 
+@pytest.mark.parametrize("points,channels,texels", [(5000, 128, 331), (777, 64, 50), (1, 4, 1)])
+def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
+    """njf_scatter_footprint = the input gradient of the bilinear sampling: four weighted index_add_ calls in one launch
+    (float64 reference; heavy collisions on purpose -- many points share few texels)."""
+    from neural_jacobian_field_amd import hip
+    g = torch.Generator().manual_seed(points)
+    grad = torch.randn(points, channels, generator=g).to(dev)
+    idx = torch.randint(0, texels, (points, 4), generator=g, dtype=torch.int32).to(dev)
+    w = torch.rand(points, 4, generator=g).to(dev)
+    out = torch.full((texels, channels), 0.5, device=dev)          # accumulates into what is there
+    hip.scatter_footprint(grad, idx, w, out)
+    ref = torch.full((texels, channels), 0.5, dtype=torch.float64, device=dev)
+    for c in range(4):
+        ref.index_add_(0, idx[:, c].long(), grad.double() * w[:, c:c + 1].double())
+    err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-6, err
+    with pytest.raises(ValueError):
+        hip.scatter_footprint(grad, idx[:, :3].contiguous(), w, out)
+
+
 def test_binding_error_behaviour(dev):
     from neural_jacobian_field_amd import hip
     z = torch.zeros(2, 300, device=dev)
