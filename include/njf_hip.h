@@ -246,10 +246,13 @@ int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ra
  * sampled (already lin_z-projected) latent of every point, foot_idx [P,4] (int32 texel index on the flattened
  * [B*Hf*Wf] grid) / foot_w [P,4] the bilinear footprint the training forward dumped (NjfActivationDump).
  * out [texels,channels] += sum over points and footprint corners (accumulates: zero it first for a fresh gradient).
- * channels % 4 == 0.  fp32 hardware atomics: the summation order, hence the last bits, vary from run to run
- * (as they do for ATen's grid_sampler_2d_backward on a GPU). */
+ * run_length >= 1: points p*run_length .. (p+1)*run_length-1 are handled by one thread per channel, which merges
+ * consecutive contributions to the same texel before touching memory -- pass the samples per ray (points are ordered
+ * ray-major, neighbouring samples mostly share texels); 1 = no merging.  The result does not depend on it beyond
+ * rounding.  fp32 hardware atomics: the summation order, hence the last bits, vary from run to run (as they do for
+ * ATen's grid_sampler_2d_backward on a GPU). */
 int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels, int texels,
-                          float* out, void* stream);
+                          int run_length, float* out, void* stream);
 
 /* ---- inverse dynamics on the composited Jacobian field ---------------------------------------- */
 /* The control loop of notebooks/real_world/2_inverse_dynamics.ipynb (cells 26-29: 100 Adam steps through

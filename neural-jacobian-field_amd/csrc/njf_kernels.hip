@@ -1243,37 +1243,52 @@ extern "C" int njf_solve_action(const float* mean_position, const float* jacobia
 // out[foot_idx[p][c]] += foot_w[p][c] * grad[p]  for the four texels of every point's footprint: the input gradient of
 // F.grid_sample(bilinear, border, align_corners=True) (model_components/pixel_aligned_features.py:29-33) in hoisted
 // order, i.e. on the [P, channels] latent gradient BEFORE lin_z's transpose is applied per texel.  One thread per
-// (point, 4-channel group): 16 hardware fp32 atomics (global_atomic_add_f32, no CAS loop); neighbouring samples of a
-// ray share texels, so most of them hit the same L2 lines.
+// (run of `run` consecutive points, channel), lane = channel: every atomic instruction of a wave covers 64 consecutive
+// floats of one texel row (two full 128-byte lines; global_atomic_add_f32, no CAS loop).  Points are ordered ray-major,
+// so consecutive points are neighbouring samples of one ray, which mostly fall into the same texels: each footprint
+// corner keeps a running sum in a register and only issues an atomic when its texel changes (2-3x fewer atomics).
 __global__ void __launch_bounds__(256) scatter_footprint_kernel(const float* __restrict__ grad,
                                                                 const int* __restrict__ foot_idx,
-                                                                const float* __restrict__ foot_w, long long groups_total,
-                                                                int groups, float* __restrict__ out) {
+                                                                const float* __restrict__ foot_w, int points, int run,
+                                                                int channels, long long total, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= groups_total) return;
-  const long long p = i / groups;
-  const int g = (int)(i - p * groups);
-  const f32x4 v = *(const f32x4*)(grad + (size_t)i * 4);
-  const int4 idx = *(const int4*)(foot_idx + (size_t)p * 4);
-  const f32x4 w = *(const f32x4*)(foot_w + (size_t)p * 4);
-  const int t[4] = {idx.x, idx.y, idx.z, idx.w};
+  if (i >= total) return;
+  const long long r = i / channels;
+  const int ch = (int)(i - r * channels);
+  const long long p0 = r * run;
+  const int n = (int)min((long long)run, (long long)points - p0);
+  int cur[4] = {-1, -1, -1, -1};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < n; ++s) {
+    const size_t p = (size_t)(p0 + s);
+    const float v = grad[p * channels + ch];
+    const int4 idx = *(const int4*)(foot_idx + p * 4);
+    const f32x4 w = *(const f32x4*)(foot_w + p * 4);
+    const int t[4] = {idx.x, idx.y, idx.z, idx.w};
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    float* dst = out + ((size_t)t[c] * groups + g) * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, w[c] * v[e]);
+    for (int c = 0; c < 4; ++c) {
+      if (t[c] != cur[c]) {  // wave-uniform: every lane of a wave works on the same points
+        if (cur[c] >= 0) unsafeAtomicAdd(out + (size_t)cur[c] * channels + ch, acc[c]);
+        cur[c] = t[c];
+        acc[c] = 0.f;
+      }
+      acc[c] = fmaf(w[c], v, acc[c]);
+    }
   }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (cur[c] >= 0) unsafeAtomicAdd(out + (size_t)cur[c] * channels + ch, acc[c]);
 }
 
 extern "C" int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels,
-                                     int texels, float* out, void* stream) {
+                                     int texels, int run_length, float* out, void* stream) {
   if (!grad || !foot_idx || !foot_w || !out) return NJF_E_NULL;
-  if (points < 1 || texels < 1 || channels < 4 || (channels & 3)) return NJF_E_SHAPE;
-  const int groups = channels / 4;
-  const long long total = (long long)points * groups;
-  if ((long long)texels * channels > 0x7fffffffLL * 4LL || (total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
-  scatter_footprint_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad, foot_idx, foot_w, total,
-                                                                                            groups, out);
+  if (points < 1 || texels < 1 || channels < 1 || run_length < 1) return NJF_E_SHAPE;
+  const long long runs = ((long long)points + run_length - 1) / run_length;
+  const long long total = runs * channels;
+  if ((total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
+  scatter_footprint_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      grad, foot_idx, foot_w, points, run_length, channels, total, out);
   return launch_status();
 }
 

@@ -102,7 +102,7 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), C.c_int, _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
-    "njf_scatter_footprint": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_scatter_footprint": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
 }
@@ -337,14 +337,15 @@ def solve_action(mean_position, jacobian, projection, target_flow, visible_mask,
                                            float(damping), _ptr(action), _stream()))
 
 
-def scatter_footprint(grad, foot_idx, foot_w, out) -> None:
+def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
     """out [T,C] += bilinear-footprint scatter of grad [P,C] (foot_idx [P,4] int32, foot_w [P,4]): the input gradient of
-    the pixel-aligned sampling, see include/njf_hip.h."""
+    the pixel-aligned sampling, see include/njf_hip.h.  ``run_length``: samples per ray (consecutive points that mostly
+    share texels are merged in registers before the atomics)."""
     points, channels = grad.shape
     if tuple(foot_idx.shape) != (points, 4) or tuple(foot_w.shape) != (points, 4) or out.shape[1] != channels:
         raise ValueError("njf_hip: scatter_footprint shape mismatch")
     _check(load_library().njf_scatter_footprint(_ptr(grad, "grad"), _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels,
-                                                out.shape[0], _ptr(out, "out"), _stream()))
+                                                out.shape[0], int(run_length), _ptr(out, "out"), _stream()))
 
 
 def alpha_weights(deltas, densities, weights) -> None:

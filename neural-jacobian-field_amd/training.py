@@ -57,7 +57,7 @@ def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
                       foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
-                      d_feats: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+                      d_feats: torch.Tensor = None, samples_per_ray: int = 1) -> Dict[str, torch.Tensor]:
     """Backward pass of one ResnetFC (resnet_fc.py:130-154) from the activations the HIP forward dumped.
 
     ``p``: the net's parameters by reference name; ``d_out`` [P, d_out]; ``act`` [11,P,128] (ReLU'd layer inputs),
@@ -80,7 +80,8 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
         delta = delta + (d_net @ p[f"blocks.{blk}.fc_0.weight"]) * (r0 > 0)
         if blk < 3:  # lin_z[blk](bilinear(F)) was added here
             d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
-            hip.scatter_footprint(delta.contiguous(), foot_idx, foot_w, d_g)   # grid_sample's input gradient, one launch
+            # grid_sample's input gradient, one launch (points are ray-major: neighbouring samples share texels)
+            hip.scatter_footprint(delta.contiguous(), foot_idx, foot_w, d_g, run_length=samples_per_ray)
             grads[f"lin_z.{blk}.weight"] = _tn(d_g, feats_flat)
             grads[f"lin_z.{blk}.bias"] = delta.sum(0)
             if d_feats is not None:
@@ -159,7 +160,8 @@ class ActionFlowFunction(torch.autograd.Function):
         feats_flat = _flat_features(features)
         if ctx.kind == "jacobian_mlp":
             p = {n[len("jacobian_head."):]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
-            grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat)
+            grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat,
+                                      samples_per_ray=s)
             result = tuple(grads[n[len("jacobian_head."):]] for n in ctx.names)
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
@@ -249,7 +251,7 @@ class FieldFunction(torch.autograd.Function):
             if g_sigma is not None:
                 d_out[:, 15] = g_sigma.reshape(pts) * clamp_exp(outs["density"].reshape(pts))
             grads = resnetfc_backward(den, d_out, outs["den_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"],
-                                      feats_flat, d_feats)
+                                      feats_flat, d_feats, samples_per_ray=outs["weights"].shape[-1])
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[i] = grads[k]
         for lvl in range(ctx.n_prop):
@@ -259,7 +261,8 @@ class FieldFunction(torch.autograd.Function):
             d = outs["proposal_dumps"][lvl]
             net = dict(zip(JACOBIAN_PARAM_ORDER, params[n + 6 + lvl * n:n + 6 + (lvl + 1) * n]))
             d_out = (g.reshape(-1) * clamp_exp(d["density"].reshape(-1)))[:, None]
-            grads = resnetfc_backward(net, d_out, d["act"], d["pe"], d["foot_idx"], d["foot_w"], feats_flat, d_feats)
+            grads = resnetfc_backward(net, d_out, d["act"], d["pe"], d["foot_idx"], d["foot_w"], feats_flat, d_feats,
+                                      samples_per_ray=d["density"].shape[-1])
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[n + 6 + lvl * n + i] = grads[k]
         ctx.outs = None

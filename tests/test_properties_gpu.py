@@ -174,7 +174,7 @@ def test_pyramid_producer_equals_projecting_the_concatenated_map(dev, precision)
     assert err < 3e-6, err
 
 
-@pytest.mark.parametrize("points,channels,texels", [(5000, 128, 331), (777, 64, 50), (1, 4, 1)])
+@pytest.mark.parametrize("points,channels,texels", [(5000, 128, 331), (777, 64, 50), (3, 5, 2)])
 def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
     """njf_scatter_footprint = the input gradient of the bilinear sampling: four weighted index_add_ calls in one launch
     (float64 reference; heavy collisions on purpose -- many points share few texels)."""
@@ -183,8 +183,12 @@ def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
     grad = torch.randn(points, channels, generator=g).to(dev)
     idx = torch.randint(0, texels, (points, 4), generator=g, dtype=torch.int32).to(dev)
     w = torch.rand(points, 4, generator=g).to(dev)
+    idx[1::2] = idx[0::2][: idx[1::2].shape[0]]                     # runs of equal footprints exercise the in-register merge
     out = torch.full((texels, channels), 0.5, device=dev)          # accumulates into what is there
-    hip.scatter_footprint(grad, idx, w, out)
+    hip.scatter_footprint(grad, idx, w, out, run_length=7)         # ragged last run (points % 7 != 0)
+    out1 = torch.full((texels, channels), 0.5, device=dev)
+    hip.scatter_footprint(grad, idx, w, out1)                      # no merging: same sums
+    assert ((out - out1).abs().max() / out1.abs().max()).item() < 2e-6
     ref = torch.full((texels, channels), 0.5, dtype=torch.float64, device=dev)
     for c in range(4):
         ref.index_add_(0, idx[:, c].long(), grad.double() * w[:, c:c + 1].double())
