@@ -25,7 +25,8 @@ stats = max(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=lambda f: open(f
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
 PCODE = 1 if prec == "f16x2" else 0  # bench.py runs both precisions in one process: pick this one's instantiations
-KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PCODE},": "proposal", "project_kernel": "project"}
+KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PCODE},": "proposal",
+           ("project_kernel_f16x2(" if prec == "f16x2" else "project_kernel("): "project"}
 agg = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"{src}/pmc*/*/*_counter_collection.csv"):
