@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_r01_$PREC
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export NJF_PRECISION=$PREC
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \

@@ -42,7 +42,7 @@ for r in csv.DictReader(open(stats)):
         if pat in r["Name"]:
             dur[short] = float(r["AverageNs"]) * 1e-9
 
-lines = [f"# {tag}: rocprofv3 PMC summary (MI355X, `python bench.py --steps 2 --warmup 1`, per-launch means)", "",
+lines = [f"# {tag}: rocprofv3 PMC summary (MI355X; durations from `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3`, counters from `--pmc` runs of `bench.py --steps 2 --warmup 1`, per-launch means)", "",
          f"Collected by `tools/profile_r01.sh {prec}`: kernel-trace/stats and each PMC group in separate runs.", "",
          "| kernel | avg duration (kernel-trace) | launch config |", "|---|---|---|"]
 for k in ("project", "proposal", "render"):
