@@ -229,7 +229,11 @@ class ActionDecoderJacobian(ActionDecoder):
         if n_freq != 10 or cfg.geometry_feature_dim != 15:
             raise ValueError("fused path supports num_frequencies=10 and geometry_feature_dim=15")
         if cfg.use_arm_model:
-            raise NotImplementedError("use_arm_model (second Jacobian head) is not part of the fused path")
+            raise NotImplementedError(
+                "use_arm_model (second Jacobian head, selected by switch_mode('arm')) is not part of the fused path: no "
+                "shipped config enables it, nothing in the reference calls switch_mode, and its compute_flow reshapes the arm "
+                "head's output with the REGULAR action_dim (action_decoder_jacobian.py:134-140), so it only runs when "
+                "arm_action_dim == action_dim")
         if not (1 <= action_dim <= max_action):
             raise ValueError(f"action_dim must be in [1, {max_action}] for {cfg.name}")
         self.action_dim = action_dim
