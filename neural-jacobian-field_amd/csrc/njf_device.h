@@ -6,7 +6,7 @@
 // j.  Computing  out^T = W * in^T  with the weights as the A operand and the activations as the B
 // operand makes register r of the previous layer's D tile exactly K-step r of the next layer, so
 // activations never leave registers between layers; only weights stream (HBM/L2 -> LDS by
-// global_load_lds DMA, double buffered in 32 KiB chunks, one barrier per chunk).
+// buffer_load ... lds DMA, double buffered in 32 KiB chunks, one barrier per chunk).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
