@@ -7,8 +7,11 @@ weights and sample placement are constants of the backward pass (SURVEY.md secti
 Forward: the fused HIP kernels, with the final pass additionally dumping the ReLU'd input of every layer of the
 Jacobian ``ResnetFC`` (``njf_render_forward`` with ``jac_act``/``jac_pe``/``foot_*`` outputs).
 Backward (round-1 form): the layer-by-layer chain on the dumped ``[P,128]`` matrices as plain library GEMMs
-(rocBLAS through ``torch.matmul``) plus ReLU masks -- exact, tested against autograd of the CPU oracle.  Fusing this
-chain into a HIP kernel is the next step of SURVEY.md section 8f #2.  The ``jacobian_transformer`` head is
+(rocBLAS through ``torch.matmul``) plus ReLU masks -- exact, tested against autograd of the CPU oracle; the texel
+scatter of the ``lin_z`` / feature gradients (grid_sample's input gradient) is the HIP kernel ``njf_scatter_footprint``.
+The weight gradients are sums over ALL points of outer products, i.e. GEMMs with K = points: they stay library calls on
+the dumped matrices (a per-workgroup accumulation would need 11 x 64 KB of partial sums per tile); fusing the
+data-gradient chain between them into a HIP kernel is the remaining step of SURVEY.md section 8f #2.  The ``jacobian_transformer`` head is
 differentiated by recomputing it (original parameterisation, library ops) on the dumped encoding + footprint.
 Perception mode (every parameter trains; rgb / depth / per-level weights carry the graph) is ``FieldFunction``.
 """
