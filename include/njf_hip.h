@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 6
+#define NJF_ABI_VERSION 7
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -253,6 +253,14 @@ int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ra
  * ATen's grid_sampler_2d_backward on a GPU). */
 int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels, int texels,
                           int run_length, float* out, void* stream);
+
+/* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
+ * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the
+ * ReLU'd forward activation the training forward dumped (residual may be NULL), and the bias gradient of the layer below
+ * as column sums of out: partial_colsum [ceil(P / rows_per_block), C] receives one deterministic partial row per
+ * workgroup (the caller adds the rows; NULL = no sums).  C % 4 == 0 and C/4 must divide 256 (C = 64, 128, ...). */
+int njf_relu_backward(const float* upstream, const float* act, const float* residual, int points, int channels,
+                      int rows_per_block, float* out, float* partial_colsum, void* stream);
 
 /* ---- inverse dynamics on the composited Jacobian field ---------------------------------------- */
 /* The control loop of notebooks/real_world/2_inverse_dynamics.ipynb (cells 26-29: 100 Adam steps through

@@ -1292,6 +1292,68 @@ extern "C" int njf_scatter_footprint(const float* grad, const int* foot_idx, con
   return launch_status();
 }
 
+// out = residual + upstream * [act > 0]  and per-block column sums of out: one layer step of the ResnetFC backward chain
+// (model_components/resnet_fc.py:69-79,130-154 differentiated: the ReLU mask, the residual add and the bias gradient
+// that autograd would run as compare + multiply + add + sum kernels).  A workgroup owns `rows_per_block` consecutive
+// rows; a thread owns 4 consecutive channels and walks the rows in steps of 256 / (channels / 4) (8 rows per iteration
+// for 128 channels): every access is a coalesced 16-byte piece of a row.
+// Column sums are reduced per workgroup in a fixed order (registers -> LDS -> one row of `partial`): deterministic; the
+// caller adds the few partial rows.
+__global__ void __launch_bounds__(256) relu_backward_kernel(const float* __restrict__ upstream,
+                                                            const float* __restrict__ act,
+                                                            const float* __restrict__ residual, int points, int quads,
+                                                            int rows_per_block, float* __restrict__ out,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[256 * 4];
+  const int lanes_per_row = quads;                 // threads covering one row (channels / 4)
+  const int rows_per_iter = 256 / lanes_per_row;   // rows a workgroup handles per iteration
+  const int tq = threadIdx.x % lanes_per_row, tr = threadIdx.x / lanes_per_row;
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  const int nrows = (int)min((long long)rows_per_block, (long long)points - row0);
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  if (tr < rows_per_iter) {
+    for (int r = tr; r < nrows; r += rows_per_iter) {
+      const size_t o = ((size_t)(row0 + r) * quads + tq) * 4;
+      const f32x4 g = *(const f32x4*)(upstream + o);
+      const f32x4 a = *(const f32x4*)(act + o);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.f ? g[e] : 0.f;
+      if (residual != nullptr) {
+        const f32x4 d = *(const f32x4*)(residual + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += d[e];
+      }
+      *(f32x4*)(out + o) = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = sum[e];
+  __syncthreads();
+  if (threadIdx.x < lanes_per_row) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rows_per_iter; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += red[(r * lanes_per_row + threadIdx.x) * 4 + e];
+    *(f32x4*)(partial + ((size_t)blockIdx.x * quads + threadIdx.x) * 4) = t;
+  }
+}
+
+extern "C" int njf_relu_backward(const float* upstream, const float* act, const float* residual, int points, int channels,
+                                 int rows_per_block, float* out, float* partial_colsum, void* stream) {
+  if (!upstream || !act || !out) return NJF_E_NULL;
+  if (points < 1 || rows_per_block < 1) return NJF_E_SHAPE;
+  if (channels < 4 || (channels & 3) || channels > 1024 || (256 % (channels / 4)) != 0) return NJF_E_SHAPE;
+  const long long blocks = ((long long)points + rows_per_block - 1) / rows_per_block;
+  if (blocks > 0x7fffffffLL) return NJF_E_SHAPE;
+  relu_backward_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(upstream, act, residual, points, channels / 4,
+                                                                           rows_per_block, out, partial_colsum);
+  return launch_status();
+}
+
 // =============================================================================================
 // stand-alone sampler ops
 // =============================================================================================

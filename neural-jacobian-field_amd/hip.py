@@ -103,6 +103,7 @@ _SIGNATURES = {
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
 }
@@ -346,6 +347,23 @@ def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
         raise ValueError("njf_hip: scatter_footprint shape mismatch")
     _check(load_library().njf_scatter_footprint(_ptr(grad, "grad"), _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels,
                                                 out.shape[0], int(run_length), _ptr(out, "out"), _stream()))
+
+
+RELU_BACKWARD_ROWS = 512  # rows per workgroup of njf_relu_backward (one partial column-sum row each)
+
+
+def relu_backward(upstream: torch.Tensor, act: torch.Tensor, residual: Optional[torch.Tensor] = None, want_colsum: bool = True):
+    """(residual + upstream * [act > 0], its column sums) -- one layer step of the ResnetFC backward chain in one launch
+    (include/njf_hip.h: njf_relu_backward).  All tensors [P,C] contiguous fp32 on the device."""
+    points, channels = upstream.shape
+    if act.shape != upstream.shape or (residual is not None and residual.shape != upstream.shape):
+        raise ValueError("njf_hip: relu_backward shape mismatch")
+    out = torch.empty_like(upstream)
+    blocks = (points + RELU_BACKWARD_ROWS - 1) // RELU_BACKWARD_ROWS
+    partial = torch.empty(blocks, channels, dtype=torch.float32, device=upstream.device) if want_colsum else None
+    _check(load_library().njf_relu_backward(_ptr(upstream, "upstream"), _ptr(act, "act"), _ptr(residual, "residual"), points,
+                                            channels, RELU_BACKWARD_ROWS, _ptr(out, "out"), _ptr(partial, "partial"), _stream()))
+    return out, (partial.sum(0) if want_colsum else None)
 
 
 def alpha_weights(deltas, densities, weights) -> None:

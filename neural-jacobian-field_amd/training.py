@@ -72,21 +72,22 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     r_out = act[10]
     grads["lin_out.weight"] = _tn(d_out, r_out)
     grads["lin_out.bias"] = d_out.sum(0)
-    delta = (d_out @ p["lin_out.weight"]) * (r_out > 0)
+    # every layer step (ReLU mask, residual add, bias gradient = column sums) is one njf_relu_backward launch
+    delta, delta_sum = hip.relu_backward(d_out @ p["lin_out.weight"], r_out)
     for blk in range(4, -1, -1):
         r0, r1 = act[2 * blk], act[2 * blk + 1]
         grads[f"blocks.{blk}.fc_1.weight"] = _tn(delta, r1)
-        grads[f"blocks.{blk}.fc_1.bias"] = delta.sum(0)
-        d_net = (delta @ p[f"blocks.{blk}.fc_1.weight"]) * (r1 > 0)
+        grads[f"blocks.{blk}.fc_1.bias"] = delta_sum
+        d_net, d_net_sum = hip.relu_backward(delta @ p[f"blocks.{blk}.fc_1.weight"], r1)
         grads[f"blocks.{blk}.fc_0.weight"] = _tn(d_net, r0)
-        grads[f"blocks.{blk}.fc_0.bias"] = d_net.sum(0)
-        delta = delta + (d_net @ p[f"blocks.{blk}.fc_0.weight"]) * (r0 > 0)
+        grads[f"blocks.{blk}.fc_0.bias"] = d_net_sum
+        delta, delta_sum = hip.relu_backward(d_net @ p[f"blocks.{blk}.fc_0.weight"], r0, residual=delta)
         if blk < 3:  # lin_z[blk](bilinear(F)) was added here
             d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
             # grid_sample's input gradient, one launch (points are ray-major: neighbouring samples share texels)
-            hip.scatter_footprint(delta.contiguous(), foot_idx, foot_w, d_g, run_length=samples_per_ray)
+            hip.scatter_footprint(delta, foot_idx, foot_w, d_g, run_length=samples_per_ray)
             grads[f"lin_z.{blk}.weight"] = _tn(d_g, feats_flat)
-            grads[f"lin_z.{blk}.bias"] = delta.sum(0)
+            grads[f"lin_z.{blk}.bias"] = delta_sum
             if d_feats is not None:
                 d_feats.addmm_(d_g, p[f"lin_z.{blk}.weight"])
     d_in = _tn(delta, pe)  # [128, 64] in slot order
@@ -191,10 +192,10 @@ def color_head_backward(p: Dict[str, torch.Tensor], d_rgb: torch.Tensor, rgb: to
     d3 = d_rgb * rgb * (1.0 - rgb)
     grads["4.weight"] = _tn(d3, col_act[1])
     grads["4.bias"] = d3.sum(0)
-    d2 = (d3 @ p["4.weight"]) * (col_act[1] > 0)
+    d2, d2_sum = hip.relu_backward(d3 @ p["4.weight"], col_act[1])
     grads["2.weight"] = _tn(d2, col_act[0])
-    grads["2.bias"] = d2.sum(0)
-    d1 = (d2 @ p["2.weight"]) * (col_act[0] > 0)
+    grads["2.bias"] = d2_sum
+    d1, _ = hip.relu_backward(d2 @ p["2.weight"], col_act[0], want_colsum=False)
     d_w0 = _tn(d1, col_in)                     # [64, 32]: columns 0..14 geo, 15 the folded bias, 16..31 sh
     grads["0.weight"] = torch.cat([d_w0[:, :15], d_w0[:, 16:]], dim=1)
     grads["0.bias"] = d_w0[:, 15].clone()

@@ -198,6 +198,24 @@ def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
         hip.scatter_footprint(grad, idx[:, :3].contiguous(), w, out)
 
 
+@pytest.mark.parametrize("points,channels", [(5000, 128), (513, 64), (7, 128)])
+def test_relu_backward_step_equals_torch(dev, points, channels):
+    """njf_relu_backward = residual + upstream * [act > 0] and its column sums (one ResnetFC backward layer step)."""
+    from neural_jacobian_field_amd import hip
+    g = torch.Generator().manual_seed(channels + points)
+    up = torch.randn(points, channels, generator=g).to(dev)
+    act = torch.relu(torch.randn(points, channels, generator=g)).to(dev)        # ReLU'd forward activation: zeros and positives
+    res = torch.randn(points, channels, generator=g).to(dev)
+    out, colsum = hip.relu_backward(up, act, res)
+    ref = res + up * (act > 0)
+    assert torch.equal(out, ref)
+    assert ((colsum.double() - ref.double().sum(0)).abs().max() / ref.double().sum(0).abs().max()).item() < 1e-5
+    out2, none = hip.relu_backward(up, act, None, want_colsum=False)
+    assert torch.equal(out2, up * (act > 0)) and none is None
+    again, colsum2 = hip.relu_backward(up, act, res)
+    assert torch.equal(colsum, colsum2)                                          # deterministic reduction order
+
+
 def test_binding_error_behaviour(dev):
     from neural_jacobian_field_amd import hip
     z = torch.zeros(2, 300, device=dev)
