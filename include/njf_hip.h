@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 7
+#define NJF_ABI_VERSION 8
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -152,6 +152,12 @@ typedef struct NjfPyramidLevel {
 } NjfPyramidLevel;
 int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels, const float* wz, int wz_ld, const float* bz,
                         int batch, int n, float* out, float* workspace, int precision, void* stream);
+
+/* The encoder output itself, channels-last: out [B*H_0*W_0, sum C_l] = cat_l(upsample_l(latent_l)) per texel
+ * (models/encoder/encoder_resnet.py:78-86: F.interpolate(bilinear, align_corners=False) to the level-0 resolution +
+ * torch.cat) in one pass from the NCHW latents -- the matrix the lin_z weight gradients contract against on the training
+ * path (the forward pass never forms it, see njf_project_pyramid).  C_l % 4 == 0. */
+int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels, int batch, float* out, void* stream);
 
 /* ---- ray generation: rendering/geometry.py:117-134 + :170-203 ------------------------------ */
 /* coords [B,R,2] normalised pixel centres (NULL -> full H x W grid of get_pixel_coordinates),

@@ -451,6 +451,75 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The encoder's output itself, channels-last: out[t][:] = cat_l(upsample_l(latent_l))[t] (encoder_resnet.py:78-86:
+// F.interpolate(bilinear, align_corners=False) to the level-0 resolution + torch.cat) as ONE pass from the NCHW latents
+// into the [B*H0*W0, 512] matrix the lin_z weight-gradient GEMM contracts against (training backward; the forward pass
+// never needs it -- njf_project_pyramid).  One thread = 4 channels of one texel; the latents are small and stay in L2,
+// the 512-channel rows are written once, coalesced.
+// ---------------------------------------------------------------------------------------------
+struct ConcatArgs {
+  const float* src[4];
+  int c[4], h[4], w[4];
+  int c0[5];  // first output channel of each level (+ total)
+  int levels, batch;
+  float* out;
+};
+
+__global__ void __launch_bounds__(256) upsample_concat_kernel(ConcatArgs a) {
+  const int n = a.c0[a.levels], n4 = n >> 2;
+  const int height = a.h[0], width = a.w[0];
+  const long long total = (long long)a.batch * height * width * n4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % n4) * 4;
+  const long long t = i / n4;
+  const int x = (int)(t % width), y = (int)((t / width) % height), b = (int)(t / ((long long)width * height));
+  int l = 0;
+  while (l + 1 < a.levels && c >= a.c0[l + 1]) ++l;
+  const int cl = c - a.c0[l], h = a.h[l], w = a.w[l];
+  // F.interpolate(mode="bilinear", align_corners=False): src = (dst + 0.5) * in / out - 0.5, clamped at 0
+  const float sy = fmaxf(((float)y + 0.5f) * ((float)h / (float)height) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)x + 0.5f) * ((float)w / (float)width) - 0.5f, 0.f);
+  const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+  const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+  const float wy = sy - (float)y0, wx = sx - (float)x0;
+  const size_t plane = (size_t)h * w;
+  const float* base = a.src[l] + ((size_t)b * a.c[l] + cl) * plane;
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float* p = base + e * plane;
+    const float top = p[(size_t)y0 * w + x0] * (1.0f - wx) + p[(size_t)y0 * w + x1] * wx;
+    const float bot = p[(size_t)y1 * w + x0] * (1.0f - wx) + p[(size_t)y1 * w + x1] * wx;
+    o[e] = top * (1.0f - wy) + bot * wy;
+  }
+  *(f32x4*)(a.out + (size_t)t * n + c) = o;
+}
+
+extern "C" int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels, int batch, float* out, void* stream) {
+  if (!levels || !out) return NJF_E_NULL;
+  if (num_levels < 1 || num_levels > 4 || batch < 1) return NJF_E_SHAPE;
+  ConcatArgs a;
+  a.levels = num_levels;
+  a.batch = batch;
+  a.out = out;
+  a.c0[0] = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!levels[l].feats) return NJF_E_NULL;
+    if (levels[l].channels < 4 || (levels[l].channels & 3) || levels[l].height < 1 || levels[l].width < 1) return NJF_E_SHAPE;
+    a.src[l] = levels[l].feats;
+    a.c[l] = levels[l].channels;
+    a.h[l] = levels[l].height;
+    a.w[l] = levels[l].width;
+    a.c0[l + 1] = a.c0[l] + levels[l].channels;
+  }
+  const long long total = (long long)batch * a.h[0] * a.w[0] * (a.c0[num_levels] >> 2);
+  if ((total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
+  upsample_concat_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
 // =============================================================================================
 // ray generation (rendering/geometry.py:117-134, :170-203)
 // =============================================================================================

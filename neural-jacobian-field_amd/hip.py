@@ -93,6 +93,7 @@ _SIGNATURES = {
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_project_pyramid": ([C.POINTER(PyramidLevel), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp],
                             C.c_int),
+    "njf_upsample_concat": ([C.POINTER(PyramidLevel), C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_solve_action": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
@@ -259,6 +260,21 @@ def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tenso
     workspace = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=out.device)
     _check(load_library().njf_project_pyramid(arr, len(levels), _ptr(wz), n, _ptr(bz), b, n, _ptr(out), _ptr(workspace),
                                               precision_code(precision), _stream()))
+
+
+def upsample_concat(levels) -> torch.Tensor:
+    """The encoder output cat_l(upsample_l(latent_l)) as a channels-last matrix [B*H_0*W_0, sum C_l] (njf_upsample_concat):
+    what the lin_z weight gradients contract against; levels as for project_pyramid."""
+    b, _, h0, w0 = levels[0].shape
+    arr = (PyramidLevel * len(levels))()
+    keep = []
+    for i, lv in enumerate(levels):
+        lv = lv.contiguous()
+        keep.append(lv)
+        arr[i] = PyramidLevel(_ptr(lv), lv.shape[1], lv.shape[2], lv.shape[3])
+    out = torch.empty(b * h0 * w0, sum(lv.shape[1] for lv in levels), dtype=torch.float32, device=levels[0].device)
+    _check(load_library().njf_upsample_concat(arr, len(levels), b, _ptr(out), _stream()))
+    return out
 
 
 # --------------------------------------------------------------------------------------

@@ -337,8 +337,9 @@ class Model(nn.Module):
     def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
         from . import training
         names, jparams = training.action_params(self)
-        with torch.no_grad():
-            features = self.encoder.forward(camera_input.input_image)
+        # the encoder is frozen in action mode: the forward pass hoists straight from its latents; the concatenated
+        # 512-channel map is only formed in the backward pass (lin_z weight gradients), by njf_upsample_concat
+        features = self._encode_for_render(camera_input.input_image)
         box = {}
 
         def run():

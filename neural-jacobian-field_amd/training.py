@@ -24,6 +24,7 @@ from typing import Callable, Dict, List, Sequence
 import torch
 
 from . import hip
+from .encoder import FeaturePyramid
 
 JACOBIAN_PARAM_ORDER: List[str] = (
     ["lin_in.weight", "lin_in.bias"]
@@ -97,7 +98,11 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     return grads
 
 
-def _flat_features(features: torch.Tensor) -> torch.Tensor:
+def _flat_features(features) -> torch.Tensor:
+    """[T,512] channels-last view of the encoder output.  A FeaturePyramid (the un-concatenated latents the forward pass
+    hoisted from) is expanded here, once, by njf_upsample_concat -- only the backward pass needs the 512-channel map."""
+    if isinstance(features, FeaturePyramid):
+        return hip.upsample_concat(features.levels)
     return features.permute(0, 2, 3, 1).reshape(-1, features.shape[1])
 
 

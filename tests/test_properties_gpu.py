@@ -174,6 +174,21 @@ def test_pyramid_producer_equals_projecting_the_concatenated_map(dev, precision)
     assert err < 3e-6, err
 
 
+def test_upsample_concat_equals_the_encoder_tail(dev):
+    """njf_upsample_concat = F.interpolate(bilinear, align_corners=False) of every latent to the level-0 resolution +
+    torch.cat (encoder_resnet.py:78-86), written channels-last in one pass (odd sizes, non-integer scale factors)."""
+    import torch.nn.functional as F
+    from neural_jacobian_field_amd import hip
+    g = torch.Generator().manual_seed(78)
+    levels = [torch.randn(2, c, h, w, generator=g).to(dev) for c, h, w in ((64, 24, 40), (64, 12, 20), (128, 6, 10), (256, 5, 7))]
+    ref = torch.cat([F.interpolate(lv, levels[0].shape[-2:], mode="bilinear", align_corners=False) for lv in levels], dim=1)
+    out = hip.upsample_concat(levels)
+    assert out.shape == (2 * 24 * 40, 512)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, 512)
+    assert torch.equal(out[:, :64], ref[:, :64])                  # level 0 is a pure layout change
+    assert ((out - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
 @pytest.mark.parametrize("points,channels,texels", [(5000, 128, 331), (777, 64, 50), (3, 5, 2)])
 def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
     """njf_scatter_footprint = the input gradient of the bilinear sampling: four weighted index_add_ calls in one launch
