@@ -21,8 +21,7 @@ import torch.nn as nn
 
 from . import hip
 from .config import ModelCfg, RenderingCfg  # noqa: F401  (re-exported like the reference module)
-from .decoder import (DecoderOutput, DensityHeadOutput, PixelEncoding, _cameras, get_action_decoder,
-                      get_density_decoder)
+from .decoder import DensityHeadOutput, PixelEncoding, _cameras, get_action_decoder, get_density_decoder
 from .encoder import get_encoder
 from .ray_samplers import ProposalNetworkSampler, RayBundle, RaySamples, UniformSampler
 
