@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 8
+#define NJF_ABI_VERSION 9
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -158,6 +158,14 @@ int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels, const flo
  * torch.cat) in one pass from the NCHW latents -- the matrix the lin_z weight gradients contract against on the training
  * path (the forward pass never forms it, see njf_project_pyramid).  C_l % 4 == 0. */
 int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels, int batch, float* out, void* stream);
+
+/* Channel order of the hoisted map.  Inside every block of `block_channels` channels (128 for a ResnetFC's lin_z layer,
+ * 64 for the transformer head's query projection) logical feature f of the layer is stored at position
+ * njf_hoisted_channel(f, block_channels) -- the order in which the two lanes that own a point read adjacent 16-byte
+ * pieces (the njf_pack_* / njf_project_* entry points apply it themselves).  Host function, no GPU work; for callers
+ * that write hoisted channels directly (flow_mlp's per-image action bias, the transformer head's folded query weights).
+ * Returns a negative error code for an invalid argument. */
+int njf_hoisted_channel(int feature, int block_channels);
 
 /* ---- ray generation: rendering/geometry.py:117-134 + :170-203 ------------------------------ */
 /* coords [B,R,2] normalised pixel centres (NULL -> full H x W grid of get_pixel_coordinates),

@@ -127,6 +127,12 @@ __host__ __device__ inline int njf_hoist_position(int f, int mb_count) {
   return 32 * m + 8 * q + 4 * hh + e;
 }
 
+// the same function for callers that write hoisted channels themselves (per-image biases, folded projections)
+extern "C" int njf_hoisted_channel(int feature, int block_channels) {
+  if (block_channels < 32 || (block_channels & 31) || feature < 0 || feature >= block_channels) return NJF_E_SHAPE;
+  return njf_hoist_position(feature, block_channels / 32);
+}
+
 // lin_z.{0,1,2}.weight [128,512] -> wz[k * ld + 128*i + pos(f)]  (k-major: coalesced B operand of the projection)
 __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
                                  const float* b2, float* wz, int ld, float* bz) {

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_project_pyramid": ([C.POINTER(PyramidLevel), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp],
                             C.c_int),
+    "njf_hoisted_channel": ([C.c_int, C.c_int], C.c_int),
     "njf_upsample_concat": ([C.POINTER(PyramidLevel), C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_solve_action": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
@@ -260,6 +261,22 @@ def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tenso
     workspace = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=out.device)
     _check(load_library().njf_project_pyramid(arr, len(levels), _ptr(wz), n, _ptr(bz), b, n, _ptr(out), _ptr(workspace),
                                               precision_code(precision), _stream()))
+
+
+_hoist_order_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def hoisted_channel_order(block_channels: int, device) -> torch.Tensor:
+    """pos[f] = position of logical feature f inside a block of ``block_channels`` hoisted-map channels
+    (njf_hoisted_channel: the single definition of that order), as an index tensor on ``device``."""
+    key = (block_channels, str(device))
+    if key not in _hoist_order_cache:
+        lib = load_library()
+        pos = [lib.njf_hoisted_channel(f, block_channels) for f in range(block_channels)]
+        if min(pos) < 0:
+            _check(min(pos))
+        _hoist_order_cache[key] = torch.tensor(pos, dtype=torch.long, device=device)
+    return _hoist_order_cache[key]
 
 
 def upsample_concat(levels) -> torch.Tensor:

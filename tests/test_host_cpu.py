@@ -28,7 +28,46 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 8
+    assert lib.njf_abi_version() == 9
+
+
+def test_hoisted_channel_order(built):
+    """njf_hoisted_channel (a host function: runs without a GPU) is the one definition of the hoisted map's in-block
+    channel order; it must be the permutation the kernels' gather assumes (csrc/njf_device.h: add_hoisted_latent reads
+    logical feature 16*MB*hh + 16*m + 4*q + e at 32*m + 8*q + 4*hh + e) for both block widths in use."""
+    lib = ctypes.CDLL(built)
+    for width in (128, 64):
+        mb = width // 32
+        pos = [lib.njf_hoisted_channel(f, width) for f in range(width)]
+        assert sorted(pos) == list(range(width))
+        for hh in range(2):
+            for m in range(mb):
+                for q in range(4):
+                    for e in range(4):
+                        assert pos[16 * mb * hh + 16 * m + 4 * q + e] == 32 * m + 8 * q + 4 * hh + e
+    assert lib.njf_hoisted_channel(128, 128) < 0 and lib.njf_hoisted_channel(0, 100) < 0 and lib.njf_hoisted_channel(-1, 64) < 0
+
+
+def test_flow_mlp_action_fold_is_exact_algebra():
+    """What the fused flow_mlp path relies on (decoder.py::ActionDecoderFlowMlp): the action is constant per batch element
+    and enters the flow head only through lin_z, so evaluating the head on cat[features, action] equals evaluating it on
+    the features alone with lin_z's bias replaced by b + W_a a.  Checked on the CPU oracle (action_decoder_flow.py:165-183)."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import synthetic
+    a_dim, pts = 5, 37
+    p = {k[len("decoder.flow_head."):]: v for k, v in
+         synthetic.seeded_state_dict(synthetic.decoder_shapes("flow_mlp", a_dim), seed=4).items() if k.startswith("decoder.flow_head.")}
+    g = torch.Generator().manual_seed(9)
+    feats, pe = torch.randn(1, pts, 512, generator=g), torch.randn(1, pts, 63, generator=g)
+    action = torch.randn(1, a_dim, generator=g)
+    full = orc.flow_mlp({"flow_head." + k: v for k, v in p.items()}, feats, pe, action[:, None, :].expand(1, pts, a_dim))
+    folded = dict(p)
+    for i in range(3):
+        w = p[f"lin_z.{i}.weight"]
+        folded[f"lin_z.{i}.weight"] = w[:, :512].contiguous()
+        folded[f"lin_z.{i}.bias"] = p[f"lin_z.{i}.bias"] + w[:, 512:] @ action[0]
+    alone = orc.resnet_fc(folded, feats, pe)
+    assert (full - alone).abs().max().item() < 1e-5 * full.abs().max().item()
 
 
 def test_argument_validation_happens_before_any_launch(built):
@@ -333,4 +372,4 @@ def test_header_is_plain_c(tmp_path, built):
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == len(names) and int(out[1]) == 8
+    assert int(out[0]) == len(names) and int(out[1]) == 9
