@@ -373,3 +373,27 @@ def test_header_is_plain_c(tmp_path, built):
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) == len(names) and int(out[1]) == 9
+
+
+def test_static_isa_properties_of_the_fused_kernels():
+    """Regression guards that need no GPU (tools/isa_report.py, ~1 min of hipcc): (1) the weight-stream DMA must stay the
+    MUBUF form -- a FLAT-encoded global_load_lds makes hipcc force every s_waitcnt to zero while it is outstanding, which
+    silently costs the split-precision kernels their A-fragment prefetch; the symptom checked is
+    the s_waitcnt histogram: exact lgkmcnt(4)/(6) waits must dominate the LDS waits of the f16x2 kernels;
+    (2) register spills of the inference kernels stay bounded (252 spilled VGPRs once cost 10 % of the frame)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_report.py")], check=True, capture_output=True,
+                         text=True).stdout
+    rows = {}
+    for line in out.splitlines():
+        if line.startswith("#"):
+            continue
+        name, regs, mix, lgkm, _ = [c.strip() for c in line.split("|")]
+        rows[name] = dict(spill=int(regs.split()[1].split("/")[0]), lds_dma=int(mix.split("(")[1].split(")")[0]),
+                          lgkm={int(k): int(v) for k, v in (kv.split(":") for kv in lgkm.split())} if lgkm != "-" else {})
+    for name in ("void render_kernel<1, 1, 0, false>(RenderArgs)", "void proposal_kernel<1, false>(ProposalArgs)"):
+        r = rows[name]
+        assert r["lds_dma"] > 0, name                                   # the weight stream is an LDS DMA ...
+        exact = r["lgkm"].get(4, 0) + r["lgkm"].get(6, 0)
+        assert exact >= 60 and exact > r["lgkm"].get(0, 0), (name, r["lgkm"])   # ... and does not zero the wait counts
+    assert rows["void render_kernel<1, 1, 0, false>(RenderArgs)"]["spill"] <= 120
+    assert rows["void proposal_kernel<1, false>(ProposalArgs)"]["spill"] <= 16
