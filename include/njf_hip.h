@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 9
+#define NJF_ABI_VERSION 10
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -59,6 +59,12 @@ extern "C" {
 #define NJF_PRECISION_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products */
 #define NJF_PRECISION_F16X2 1  /* fp32 operands split hi+lo into two fp16; hi*hi + hi*lo + lo*hi accumulated in fp32
                                   by v_mfma_f32_32x32x16_f16: fp32-class accuracy (dropped term 2^-22) at 3/16 the cost */
+#define NJF_PRECISION_F16F6 2  /* hi*hi as above; the two correction products hi*lo + lo*hi (2^-11 of the result) in
+                                  block-scaled fp6 (e2m3, one power-of-two scale per lane and 32 K-values) by
+                                  v_mfma_scale_f32_32x32x64_f8f6f4 at 4x the f16 rate: half the matrix time of F16X2,
+                                  ~1.5e-5 relative error per ResnetFC (tools/sim_split_precision.py).  Applies to the
+                                  128-wide layers; the narrow layers (lin_out, colour head, transformer head) and
+                                  the feature projection keep the F16X2 form */
 
 #define NJF_JACOBIAN_NONE 0
 #define NJF_JACOBIAN_MLP 1          /* ActionDecoderJacobianMLP (action_decoder_jacobian.py:261-337) */

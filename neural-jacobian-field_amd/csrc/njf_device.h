@@ -18,14 +18,25 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 
 // MFMA precision of the fused MLPs (same activation layout, same chunk sizes, different A-fragment packing):
 //   PREC_F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak)
 //   PREC_F16X2 : every fp32 operand x is split as x = hi + lo (two fp16), and hi*hi + hi*lo + lo*hi is
 //                accumulated in fp32 by v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s peak, 3 instructions per product
 //                block): the dropped lo*lo term is 2^-22 relative, i.e. fp32-class accuracy at 3/16 of the cost.
+//   PREC_F16F6 : hi*hi as in PREC_F16X2; the two correction products (2^-11 of the result) in block-scaled fp6 (e2m3)
+//                by v_mfma_scale_f32_32x32x64_f8f6f4 -- K = 64 in the issue time of ONE K = 16 f16 instruction (35 vs 34
+//                clocks measured, profiles/r02_probe_mx.txt): 24 matrix instructions per 128x64 weight chunk instead of
+//                48.  Only the 128-wide layers (MBO = 4, NKB = 2 chunks) take this form; the narrow ones stay F16X2.
 #define PREC_F32 0
 #define PREC_F16X2 1
+#define PREC_F16F6 2
 
 // Workgroup = 4 waves (one per SIMD), two workgroups resident per CU: the two waves sharing a SIMD's
 // MFMA pipe belong to DIFFERENT workgroups, so one workgroup's barrier / gather / encoding phases are
@@ -169,6 +180,40 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int p, f16x8& hi,
   lo = __builtin_bit_cast(f16x8, lv);
 }
 
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+// max of two pairs of packed 16-bit patterns (asm: the compiler otherwise re-derives the halves from the fp32 sources
+// with scalar conversions instead of using the packed register the split already produced)
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// split_pair with the packed {hi0, hi1} and {lo0, lo1} halves returned as dwords
+template <bool RELU>
+__device__ __forceinline__ void split_pair_u(float x0, float x1, unsigned& hu, unsigned& lu) {
+  if (RELU) {
+    x0 = relu_bits(x0);
+    x1 = relu_bits(x1);
+  }
+  const f16x2 hp = {(_Float16)x0, (_Float16)x1};
+  hu = __builtin_bit_cast(unsigned, hp);
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "v"(x1));
+}
+
+// Layout of one PREC_F16F6 weight chunk (K = 64 inputs x 128 outputs, NJF_CHUNK floats = 32 KiB, byte offsets):
+//   [F6_HI   , +16 KiB) : hi fp16 A fragments [t][m][lane][8 x f16]   (t = K-step of 16, m = output block of 32)
+//   [F6_P1   , + 8 KiB) : fp6 fragments, bytes 0..15 of each lane's 24  [m][w][lane][16 B]   w = 0: fp6(hi), 1: fp6(lo)
+//   [F6_P2   , + 4 KiB) : fp6 fragments, bytes 16..23                   [m][w][lane][8 B]
+//   [F6_SCALE, +512 B ) : E8M0 scale bytes [w][lane] as one dword per lane (byte m = output block m)
+// A lane's 32 fp6 elements are its 32 K-values of the chunk in the order of the f16 path (element 8*t + i = value i of
+// K-step t), so the activation side is ONE v_cvt_scalef32_pk32_fp6_f16 of the 16 registers of packed hi (or lo) halves.
+#define F6_HI 0
+#define F6_P1 16384
+#define F6_P2 24576
+#define F6_SCALE 28672
+
+
 // ------------------------------------------------------------------------------------------
 // out[MBO] += W[:, kb range] * in   for the (kb,q) groups stored at `wl` (LDS, packed
 // [kb][q][mb][lane][e]).  RELU applies max(.,0) to the B operand on the fly.
@@ -208,6 +253,107 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
         }
       }
     }
+  } else if constexpr (PREC == PREC_F16F6 && MBO == 4 && NKB == 2) {
+    // 16 f16 MFMAs (hi*hi, K-steps t = 0..3 x output blocks m = 0..3) followed by 8 block-scaled fp6 MFMAs
+    // (W_lo6 * x_hi6 and W_hi6 * x_lo6 per output block, K = 64 each).  The hi/lo split of K-step t+1 rides behind
+    // the MFMAs of step t as in the F16X2 path; every packed hi pair is also folded into a running maximum, from
+    // which the lane's power-of-two scale follows: 2^(e-2) for the hi values (largest element in [4, 8), clamped at
+    // 7.5 by the conversion) and 2^(e-13) for the residuals (|lo| <= 2^-11 of its hi's binade, so <= 4 after scaling).
+    // The two 32-value conversions are long single instructions (~100 clocks each, profiles/r02_probe_mx.txt) during
+    // which this wave issues nothing else, so each is placed right behind a group of MFMAs that keeps the pipe fed.
+    typedef __attribute__((address_space(3))) const char* lds_ptr;  // explicit LDS pointers: the asm below would hide
+    const lds_ptr wb = (lds_ptr)(const char*)wl;                    // the address space from the compiler's inference
+    lds_ptr p16 = wb + lane * 16;   // made opaque: all fragment addresses become base + immediate offset (otherwise
+    lds_ptr p8 = wb + lane * 8;     // one loop-invariant address VGPR per fragment is kept alive)
+    asm volatile("" : "+v"(p16), "+v"(p8));
+    unsigned bh[4][4], bl[4][4], mx[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      split_pair_u<RELU>(in[KB0][2 * p], in[KB0][2 * p + 1], bh[0][p], bl[0][p]);
+      mx[p] = RELU ? bh[0][p] : (bh[0][p] & 0x7fff7fffu);
+    }
+#define NJF_LDS(T) const __attribute__((address_space(3))) T*
+    auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + i * 1024); };                  // hi fp16 fragment (t, m): i = 4t + m
+    auto f6frag = [&](int idx) {                                                           // fp6 fragment idx = 2m + w
+      const i32x4 a4 = *(NJF_LDS(i32x4))(p16 + F6_P1 + idx * 1024);
+      const i32x2 b2 = *(NJF_LDS(i32x2))(p8 + F6_P2 + idx * 512);
+      return i32x8{a4[0], a4[1], a4[2], a4[3], b2[0], b2[1], 0, 0};
+    };
+    auto op8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], v[2], v[3]}); };
+    f16x8 a[2] = {hfrag(0), hfrag(1)};
+    unsigned sb_h = 0, sb_l = 0;
+    i32x8 bh6 = {0, 0, 0, 0, 0, 0, 0, 0}, wl6_0 = bh6, wl6_1 = bh6;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int u = 2 * t + half;
+        f16x8 n[2] = {a[0], a[1]};
+        if (u + 1 < 8) {
+          n[0] = hfrag((u + 1) * 2);
+          n[1] = hfrag((u + 1) * 2 + 1);
+        } else {
+          wl6_0 = f6frag(1);
+          wl6_1 = f6frag(3);
+        }
+        if constexpr (SPREAD) {
+          if (u < 4) {
+            dma_issue(st, 2 * u);
+            dma_issue(st, 2 * u + 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const int m = 2 * half + mm;
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mm], op8(bh[t]), out[m], 0, 0, 0);
+          if (t + 1 < 4) {
+            const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
+            split_pair_u<RELU>(in[KB0 + kb2][8 * tt2 + 2 * m], in[KB0 + kb2][8 * tt2 + 2 * m + 1], bh[t + 1][m], bl[t + 1][m]);
+            mx[m] = pk_max_u16(mx[m], RELU ? bh[t + 1][m] : (bh[t + 1][m] & 0x7fff7fffu));
+          }
+        }
+        if (u == 6) {
+          // every hi value of the chunk exists now: lane scale (fp16 bit patterns of non-negative values order like
+          // integers) and the fp6 image of the 32 hi values
+          unsigned m2 = pk_max_u16(pk_max_u16(mx[0], mx[1]), pk_max_u16(mx[2], mx[3]));
+          m2 = max(m2 & 0xffffu, m2 >> 16);
+          const unsigned e5 = m2 >> 10;  // biased fp16 exponent of the maximum (0 for zero/subnormal)
+          sb_h = e5 + 110u;              // E8M0 of 2^((e5 - 15) - 2)
+          sb_l = e5 + 99u;               // ... and 2^-11 of it for the residuals
+          const u32x16 hv = {bh[0][0], bh[0][1], bh[0][2], bh[0][3], bh[1][0], bh[1][1], bh[1][2], bh[1][3],
+                             bh[2][0], bh[2][1], bh[2][2], bh[2][3], bh[3][0], bh[3][1], bh[3][2], bh[3][3]};
+          const u32x6 x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, hv), __uint_as_float(sb_h << 23));
+          bh6 = i32x8{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
+        }
+        a[0] = n[0];
+        a[1] = n[1];
+      }
+    }
+    const unsigned s_w0 = *(NJF_LDS(unsigned))(p8 + F6_SCALE - lane * 4);        // [w = 0][lane]: p8 = wb + 8*lane
+    const unsigned s_w1 = *(NJF_LDS(unsigned))(p8 + F6_SCALE + 256 - lane * 4);  // [w = 1][lane]
+#undef NJF_LDS
+    i32x8 wl6_2 = f6frag(5), wl6_3 = f6frag(7);
+    __builtin_amdgcn_sched_barrier(0);
+    // fragment idx = 2*m + w: w = 1 (fp6 of W_lo) pairs with x_hi6, w = 0 (fp6 of W_hi) with x_lo6; scale byte m of the
+    // lane's scale dword is selected by the op_sel argument
+    out[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_0, bh6, out[0], 2, 2, 0, (int)s_w1, 0, (int)sb_h);
+    out[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_1, bh6, out[1], 2, 2, 1, (int)s_w1, 0, (int)sb_h);
+    i32x8 wh6_0 = f6frag(0), wh6_1 = f6frag(2);
+    const u32x16 lv = {bl[0][0], bl[0][1], bl[0][2], bl[0][3], bl[1][0], bl[1][1], bl[1][2], bl[1][3],
+                       bl[2][0], bl[2][1], bl[2][2], bl[2][3], bl[3][0], bl[3][1], bl[3][2], bl[3][3]};
+    const u32x6 y6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, lv), __uint_as_float(sb_l << 23));
+    const i32x8 bl6 = {(int)y6[0], (int)y6[1], (int)y6[2], (int)y6[3], (int)y6[4], (int)y6[5], 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
+    out[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_2, bh6, out[2], 2, 2, 2, (int)s_w1, 0, (int)sb_h);
+    out[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_3, bh6, out[3], 2, 2, 3, (int)s_w1, 0, (int)sb_h);
+    i32x8 wh6_2 = f6frag(4), wh6_3 = f6frag(6);
+    __builtin_amdgcn_sched_barrier(0);
+    out[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_0, bl6, out[0], 2, 2, 0, (int)s_w0, 0, (int)sb_l);
+    out[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_1, bl6, out[1], 2, 2, 1, (int)s_w0, 0, (int)sb_l);
+    out[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_2, bl6, out[2], 2, 2, 2, (int)s_w0, 0, (int)sb_l);
+    out[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_3, bl6, out[3], 2, 2, 3, (int)s_w0, 0, (int)sb_l);
+    __builtin_amdgcn_sched_barrier(0);  // the matrix work of a chunk stays in front of the next chunk's barrier
   } else {
     // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
     // Lane (j,hh) supplies its own registers 8*tt .. 8*tt+7 of block kb as the 8 k-values of step t = 2*kb + tt.
@@ -320,8 +466,17 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
 // in k order: that is what torch.einsum("...ij,...j->...i") lowers to on CPU, so camera-space
 // coordinates match the oracle bit for bit (they feed a positional encoding that amplifies ulps).
 // ------------------------------------------------------------------------------------------
+struct CamCtx;
+// Camera-space position of a point (the positional-encoding input) + what its bilinear footprint in the hoisted map is
+// computed from.  The footprint itself (4 texel offsets + 4 weights) is NOT kept: point_footprint() recomputes it in
+// front of each of the three gathers of a ResnetFC (~25 VALU instructions) instead of holding 8 registers live across
+// the 22 weight chunks -- the fused kernels run at the 256-register limit and every long-lived value is a spill.
 struct PointGeom {
-  float xc, yc, zc;  // camera-space position (positional-encoding input)
+  float xc, yc, zc;
+  const CamCtx* cam;  // intrinsics (wave-uniform in the ray kernels: SGPRs)
+  int hf, wf, stride;
+};
+struct Footprint {
   int t00, t01, t10, t11;  // texel offsets (floats) into the feature map of this batch element
   float w00, w01, w10, w11;
 };
@@ -359,9 +514,21 @@ __device__ __forceinline__ void point_geometry(const CamCtx& c, float px, float 
   g.xc = dot4_h(c.m + 0, px, py, pz);
   g.yc = dot4_h(c.m + 4, px, py, pz);
   g.zc = dot4_h(c.m + 8, px, py, pz);
-  const float u0 = dot3(c.k + 0, g.xc, g.yc, g.zc);
-  const float u1 = dot3(c.k + 3, g.xc, g.yc, g.zc);
-  const float u2 = dot3(c.k + 6, g.xc, g.yc, g.zc);
+  g.cam = &c;
+  g.hf = hf;
+  g.wf = wf;
+  g.stride = stride;
+}
+
+__device__ __forceinline__ void point_footprint(const PointGeom& g, Footprint& f) {
+  float xc = g.xc, yc = g.yc, zc = g.zc;
+  // opaque copies: without them the compiler merges the recomputations into one and keeps its 8 results alive
+  asm volatile("" : "+v"(xc), "+v"(yc), "+v"(zc));
+  const CamCtx& c = *g.cam;
+  const int hf = g.hf, wf = g.wf, stride = g.stride;
+  const float u0 = dot3(c.k + 0, xc, yc, zc);
+  const float u1 = dot3(c.k + 3, xc, yc, zc);
+  const float u2 = dot3(c.k + 6, xc, yc, zc);
   const float den = u2 + 1e-9f;
   const float u = u0 / den, v = u1 / den;
   const float gx = (u - 0.5f) * 2.0f, gy = (v - 0.5f) * 2.0f;
@@ -376,14 +543,14 @@ __device__ __forceinline__ void point_geometry(const CamCtx& c, float px, float 
   x0 = min(max(x0, 0), wf - 1);  // also absorbs NaN coordinates (behind-camera points)
   y0 = min(max(y0, 0), hf - 1);
   const int x1 = min(x0 + 1, wf - 1), y1 = min(y0 + 1, hf - 1);
-  g.t00 = (y0 * wf + x0) * stride;
-  g.t01 = (y0 * wf + x1) * stride;
-  g.t10 = (y1 * wf + x0) * stride;
-  g.t11 = (y1 * wf + x1) * stride;
-  g.w00 = ey * ex;
-  g.w01 = ey * fx;
-  g.w10 = fy * ex;
-  g.w11 = fy * fx;
+  f.t00 = (y0 * wf + x0) * stride;
+  f.t01 = (y0 * wf + x1) * stride;
+  f.t10 = (y1 * wf + x0) * stride;
+  f.t11 = (y1 * wf + x1) * stride;
+  f.w00 = ey * ex;
+  f.w01 = ey * fx;
+  f.w10 = fy * ex;
+  f.w11 = fy * fx;
 }
 
 // h += bilerp(G)[32*MB channels starting at `gz`].  Within a block of 32*MB channels the map stores logical
@@ -396,8 +563,10 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
   return;
 #endif
-  const float* p[4] = {gz + g.t00 + 4 * hh, gz + g.t01 + 4 * hh, gz + g.t10 + 4 * hh, gz + g.t11 + 4 * hh};
-  const float w[4] = {g.w00, g.w01, g.w10, g.w11};
+  Footprint f;
+  point_footprint(g, f);
+  const float* p[4] = {gz + f.t00 + 4 * hh, gz + f.t01 + 4 * hh, gz + f.t10 + 4 * hh, gz + f.t11 + 4 * hh};
+  const float w[4] = {f.w00, f.w01, f.w10, f.w11};
   // The gather is latency-bound: with NJF_GATHER_BATCH texels per batch, 4*MB*BATCH float4 loads are in flight
   // together (the registers `net` vacates at this point of the block), then folded into h.  The asm fence makes
   // the fmas retire into h before the next batch's loads are issued (otherwise the scheduler either hoists all

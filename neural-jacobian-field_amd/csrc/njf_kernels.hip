@@ -6,6 +6,9 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <type_traits>
+
 #include "../../include/njf_hip.h"
 #include "njf_device.h"
 
@@ -37,6 +40,10 @@ extern "C" const char* njf_error_string(int code) {
     case NJF_E_GMAP: return "feature map stride/offset does not cover NJF_ZDIM channels or is not 16-byte aligned";
     default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown njf error";
   }
+}
+
+static inline bool valid_precision(int p) {
+  return p == NJF_PRECISION_F32 || p == NJF_PRECISION_F16X2 || p == NJF_PRECISION_F16F6;
 }
 
 static inline int launch_status() {
@@ -76,6 +83,89 @@ __device__ __forceinline__ float pack_source(const PackLayer& L, int f, int k) {
   if (k < 15) return L.w[f * L.d_in + k];
   if (k == 15) return L.b[f];
   return L.w[f * L.d_in + (k - 1)];
+}
+
+// fp6 e2m3 (1 sign, 2 exponent bits with bias 1, 3 mantissa bits; max 7.5, subnormal step 1/8), round to nearest even,
+// saturating: the value set of v_mfma_scale_*_f8f6f4 with cbsz/blgp = 2.
+__device__ __forceinline__ unsigned encode_e2m3(float v) {
+  const unsigned sign = v < 0.f ? 32u : 0u;
+  const float a = fminf(fabsf(v), 7.5f);
+  unsigned code;
+  if (a < 1.0f) {
+    code = (unsigned)rintf(a * 8.0f);  // 0..8: 8 is the encoding of 1.0 (exponent field 1, mantissa 0)
+  } else {
+    int e = a >= 4.0f ? 2 : (a >= 2.0f ? 1 : 0);
+    float q = rintf(a * (8.0f / (float)(1 << e)));  // 8..16
+    if (q >= 16.0f) {
+      q = 8.0f;
+      e += 1;
+    }
+    code = ((unsigned)(e + 1) << 3) | ((unsigned)q - 8u);
+    if (e > 2) code = 31u;
+  }
+  return sign | code;
+}
+
+// PREC_F16F6 form of a 128-output layer (mb = 4): one 32 KiB chunk per K-range of 64 (njf_device.h: F6_* offsets).
+__global__ void pack_layer_f16f6_kernel(PackLayer L) {
+  const int chunks = L.kb >> 1;
+  _Float16* dst16 = (_Float16*)L.dst;
+  // (a) hi fp16 fragments [chunk][t][m][lane][8]
+  const int n = chunks * 4 * 4 * 512;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int i8 = i & 7, lane = (i >> 3) & 63;
+    int rest = i >> 9;
+    const int m = rest & 3;
+    rest >>= 2;
+    const int t = rest & 3, c = rest >> 2;
+    const int ip = lane & 31, kh = lane >> 5;
+    const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);
+    const int k = 16 * L.kb * kh + 32 * c + 8 * t + i8;
+    dst16[(size_t)c * (2 * NJF_CHUNK_FLOATS) + (F6_HI >> 1) + ((t * 4 + m) * 64 + lane) * 8 + i8] = (_Float16)pack_source(L, f, k);
+  }
+  // (b) fp6 fragments + scales: one thread per (chunk, m, w, lane)
+  const int nf = chunks * 4 * 2 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, w = (i >> 6) & 1, m = (i >> 7) & 3, c = i >> 9;
+    const int ip = lane & 31, kh = lane >> 5;
+    const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);
+    float v[32], amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float x = pack_source(L, f, 16 * L.kb * kh + 32 * c + e);
+      const float hi = (float)(_Float16)x;
+      v[e] = w == 0 ? hi : (float)(_Float16)(x - hi);  // the residual as the f16x2 path holds it
+      amax = fmaxf(amax, fabsf(v[e]));
+    }
+    int ex = amax > 0.f ? ilogbf(amax) - 2 : -126;   // largest element lands in [4, 8) (clamped at 7.5)
+    ex = max(ex, -126);
+    const float inv = ldexpf(1.0f, -ex);
+    unsigned words[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const unsigned long long code = encode_e2m3(v[e] * inv);
+      const int bit = 6 * e;
+      words[bit >> 5] |= (unsigned)(code << (bit & 31));
+      if ((bit & 31) > 26) words[(bit >> 5) + 1] |= (unsigned)(code >> (32 - (bit & 31)));
+    }
+    char* base = (char*)L.dst + (size_t)c * (NJF_CHUNK_FLOATS * 4);
+    unsigned* p1 = (unsigned*)(base + F6_P1 + ((2 * m + w) * 64 + lane) * 16);
+    unsigned* p2 = (unsigned*)(base + F6_P2 + ((2 * m + w) * 64 + lane) * 8);
+    p1[0] = words[0];
+    p1[1] = words[1];
+    p1[2] = words[2];
+    p1[3] = words[3];
+    p2[0] = words[4];
+    p2[1] = words[5];
+    ((unsigned char*)(base + F6_SCALE + w * 256 + lane * 4))[m] = (unsigned char)(ex + 127);
+  }
+  // (c) the unused tail of every chunk (the weight DMA moves whole chunks)
+  const int tail = (NJF_CHUNK_FLOATS * 4 - (F6_SCALE + 512)) >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < chunks * tail; i += gridDim.x * blockDim.x)
+    ((unsigned*)((char*)L.dst + (size_t)(i / tail) * (NJF_CHUNK_FLOATS * 4) + F6_SCALE + 512))[i % tail] = 0u;
+  if (L.bdst != nullptr && blockIdx.x == 0) {
+    for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = (f < L.d_out && L.b) ? L.b[f] : 0.f;
+  }
 }
 
 __global__ void pack_layer_kernel(PackLayer L) {
@@ -154,13 +244,21 @@ static void launch_pack(const float* w, const float* b, int d_out, int d_in, int
                         float* bdst, hipStream_t s) {
   PackLayer L{w, b, d_out, d_in, mb, kb, kind, prec, dst, bdst};
   const int n = kb * 4 * mb * 256;
+  if (prec == NJF_PRECISION_F16F6) {
+    // the 128-wide layers take the fp6-corrected chunk form; narrow layers keep the F16X2 form (njf_device.h: mma_chunk)
+    if (mb == 4 && (kb & 1) == 0) {
+      pack_layer_f16f6_kernel<<<64, 256, 0, s>>>(L);
+      return;
+    }
+    L.prec = NJF_PRECISION_F16X2;
+  }
   pack_layer_kernel<<<(n + 255) / 256, 256, 0, s>>>(L);
 }
 
 extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
                                     float* bz_out, int precision, void* stream) {
   if (!src || !w_out || !b_out) return NJF_E_NULL;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   const int P = precision;
   if (src->d_out < 1 || src->d_out > 32) return NJF_E_DOUT;
   if (!src->lin_in_w || !src->lin_in_b || !src->lin_out_w || !src->lin_out_b) return NJF_E_NULL;
@@ -195,7 +293,7 @@ extern "C" int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, fl
 extern "C" int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kind, float* w_out, float* b_out,
                                int precision, void* stream) {
   if (!w || !w_out) return NJF_E_NULL;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   if (d_out < 1 || d_in < 1) return NJF_E_SHAPE;
   if (kind == 1 && (d_in != NJF_PE_DIM || !b)) return NJF_E_SHAPE;
   if (kind != 0 && kind != 1) return NJF_E_MODE;
@@ -207,7 +305,7 @@ extern "C" int njf_pack_linear(const float* w, const float* b, int d_out, int d_
 extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, int precision,
                                    void* stream) {
   if (!src || !w_out || !b_out || !src->w0 || !src->b0 || !src->w1 || !src->b1 || !src->w2 || !src->b2) return NJF_E_NULL;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   hipStream_t s = (hipStream_t)stream;
   launch_pack(src->w0, src->b0, 64, 31, 2, 1, 2, precision, w_out, nullptr, s);
   launch_pack(src->w1, src->b1, 64, 64, 2, 2, 0, precision, w_out + 2048, b_out, s);
@@ -347,7 +445,7 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
 
 static void launch_project(const float* feats, int K, const float* wz, int ld, const float* bz, int batch, int hw, int n,
                            float* out, int precision, hipStream_t s) {
-  if (precision == NJF_PRECISION_F16X2) {
+  if (precision != NJF_PRECISION_F32) {  // F16X2 and F16F6: both operands split on the fly
     dim3 grid((hw + 255) / 256, (n + 32 * NJF_PROJ_NT - 1) / (32 * NJF_PROJ_NT), batch);
     project_kernel_f16x2<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
   } else {
@@ -360,7 +458,7 @@ extern "C" int njf_project_features_ld(const float* feats, const float* wz, int 
                                        int n, float* out, int precision, void* stream) {
   if (!feats || !wz || !bz || !out) return NJF_E_NULL;
   if (batch < 1 || hw < 1 || n < 1 || wz_ld < n) return NJF_E_SHAPE;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   launch_project(feats, 512, wz, wz_ld, bz, batch, hw, n, out, precision, (hipStream_t)stream);
   return launch_status();
 }
@@ -418,7 +516,7 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
                                    int batch, int n, float* out, float* workspace, int precision, void* stream) {
   if (!levels || !wz || !bz || !out) return NJF_E_NULL;
   if (num_levels < 1 || num_levels > 4 || batch < 1 || n < 4 || (n & 3) || wz_ld < n) return NJF_E_SHAPE;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   if (num_levels > 1 && !workspace) return NJF_E_NULL;
   int rows = 0;
   for (int l = 0; l < num_levels; ++l) {
@@ -690,16 +788,18 @@ __device__ __forceinline__ ActDump point_dump(const NjfActivationDump& d, size_t
                                               const PointGeom& g, int tex0, int texel_stride) {
   ActDump dump{d.act ? d.act + pidx * 128 + 64 * hh : nullptr, d.pe + pidx * 64 + 32 * hh, points * 128};
   if (hh == 0 && d.foot_idx != nullptr) {
+    Footprint f;
+    point_footprint(g, f);
     int* fi = d.foot_idx + pidx * 4;
-    fi[0] = tex0 + g.t00 / texel_stride;
-    fi[1] = tex0 + g.t01 / texel_stride;
-    fi[2] = tex0 + g.t10 / texel_stride;
-    fi[3] = tex0 + g.t11 / texel_stride;
+    fi[0] = tex0 + f.t00 / texel_stride;
+    fi[1] = tex0 + f.t01 / texel_stride;
+    fi[2] = tex0 + f.t10 / texel_stride;
+    fi[3] = tex0 + f.t11 / texel_stride;
     float* fw = d.foot_w + pidx * 4;
-    fw[0] = g.w00;
-    fw[1] = g.w01;
-    fw[2] = g.w10;
-    fw[3] = g.w11;
+    fw[0] = f.w00;
+    fw[1] = f.w01;
+    fw[2] = f.w10;
+    fw[3] = f.w11;
   }
   return dump;
 }
@@ -771,88 +871,85 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
 }
 
 // =============================================================================================
-// decoder evaluation of one tile: density + colour (+ Jacobian / flow)
+// decoder evaluation of one tile, stage by stage: density net -> colour head -> Jacobian head / flow.  The callers
+// composite (or store) each stage's result before the next stage starts, so that only the sample weight, the
+// camera-space position and the ray constants stay live across the 22 weight chunks of the Jacobian head.
 // =============================================================================================
-struct TileOut {
-  float sigma;
-  float rgb[3];
-  float flow[3];
-};
-
 // bias layout (LDS_BIAS): [density 1312 | colour 96 | jacobian head (MLP 1312 / transformer 800)]
 // JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
 // DUMP: 0 = inference, 1 = dump the Jacobian ResnetFC (action-mode training), 2 = dump the density ResnetFC and the
 // colour head (perception-mode training); `dump` addresses the dumped net, `cdump` the colour head.
-template <int JKIND, int PREC, int DUMP = 0>
-__device__ __forceinline__ void decoder_tile(WeightStream& st, const float* __restrict__ gz_d,
-                                             const float* __restrict__ gz_j, const PointGeom& g, float dirx, float diry,
-                                             float dirz, const float* __restrict__ action, int action_dim, int wave,
-                                             int lane, TileOut& o, f32x16 (&geo)[1], f32x16 (&jac)[1],
-                                             ActDump dump = ActDump{nullptr, nullptr, 0},
-                                             ColorDump cdump = ColorDump{nullptr, nullptr, 0}) {
+template <int PREC, int DUMP>
+__device__ __forceinline__ float density_stage(WeightStream& st, const float* __restrict__ gz_d, const PointGeom& g, int wave,
+                                               int lane, f32x16 (&geo)[1], ActDump dump) {
   const int j = lane & 31, hh = lane >> 5;
-  const float* bias = njf_lds + LDS_BIAS;
-  {
-    f32x16 pe[2];
-    positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    resnet_tile<PREC, DUMP == 2>(st, bias, gz_d, g, pe, wave, lane, geo, dump);
+  f32x16 pe[2];
+  positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+  resnet_tile<PREC, DUMP == 2>(st, njf_lds + LDS_BIAS, gz_d, g, pe, wave, lane, geo, dump);
+  return expf(__shfl(geo[0][15], j, 64) - 1.0f);
+}
+
+template <int PREC, int DUMP>
+__device__ __forceinline__ void color_stage(WeightStream& st, const f32x16 (&geo)[1], float dirx, float diry, float dirz,
+                                            int wave, int lane, float (&rgb)[3], ColorDump cdump) {
+  const int j = lane & 31, hh = lane >> 5;
+  float sh[16];
+  sh4(dirx, diry, dirz, sh);
+  f32x16 cin[1], crgb[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cin[0][r] = hh ? sh[r] : (r < 15 ? geo[0][r] : 1.0f);
+  color_tile<PREC, DUMP == 2>(st, njf_lds + LDS_BIAS + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb, cdump);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = __shfl(crgb[0][c], j, 64);
+    rgb[c] = 1.0f / (1.0f + expf(-x));
   }
-  o.sigma = expf(__shfl(geo[0][15], j, 64) - 1.0f);
-  {
-    float sh[16];
-    sh4(dirx, diry, dirz, sh);
-    f32x16 cin[1], crgb[1];
+}
+
+template <int JKIND, int PREC, int DUMP>
+__device__ __forceinline__ void jacobian_stage(WeightStream& st, const float* __restrict__ gz_j, const PointGeom& g,
+                                               const float* __restrict__ action, int action_dim, int wave, int lane,
+                                               f32x16 (&jac)[1], float (&flow)[3], ActDump dump) {
+  const int hh = lane >> 5;
+  const float* bias = njf_lds + LDS_BIAS + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS;
+  // the encoding is recomputed (~1 % of the head's time) rather than held in 32 VGPRs across density + colour
+  asm volatile("" ::: "memory");
+  f32x16 pe[2];
+  positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+  if (JKIND == 1)
+    resnet_tile<PREC, DUMP == 1>(st, bias, gz_j, g, pe, wave, lane, jac, dump);
+  else {
+    if (DUMP == 1 && dump.pe != nullptr) {  // the transformer head's backward pass recomputes it from pe + footprint
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cin[0][r] = hh ? sh[r] : (r < 15 ? geo[0][r] : 1.0f);
-    color_tile<PREC, DUMP == 2>(st, bias + NJF_RESNET_B_FLOATS, cin, wave, lane, crgb, cdump);
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float x = __shfl(crgb[0][c], j, 64);
-      o.rgb[c] = 1.0f / (1.0f + expf(-x));
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pe[kb][4 * q + e];
+          *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
+        }
+    }
+    transformer_tile<PREC>(st, bias, gz_j, g, pe, action_dim, wave, lane, jac);
+  }
+  // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
+  // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
+  float ph[3] = {0.f, 0.f, 0.f};
+  if (action) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d0 = r, d1 = 16 + r;  // logical output index for hh = 0 / 1
+      const float a0 = (d0 / 3) < action_dim ? action[d0 / 3] : 0.f;
+      const float a1 = (d1 / 3) < action_dim ? action[d1 / 3] : 0.f;
+      ph[r % 3] = fmaf(jac[0][r], hh ? a1 : a0, ph[r % 3]);
     }
   }
-  if (JKIND != 0) {
-    // the encoding is recomputed (~1 % of the head's time) rather than held in 32 VGPRs across density + colour
-    asm volatile("" ::: "memory");
-    f32x16 pe[2];
-    positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    if (JKIND == 1)
-      resnet_tile<PREC, DUMP == 1>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, wave, lane, jac, dump);
-    else {
-      if (DUMP == 1 && dump.pe != nullptr) {  // the transformer head's backward pass recomputes it from pe + footprint
+  // hh=0: spatial index s = r%3 ; hh=1: s = (16+r)%3 = (r+1)%3  ->  phase (s+2)%3
+  float mine[3];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+  for (int s = 0; s < 3; ++s) mine[s] = hh ? ph[(s + 2) % 3] : ph[s];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pe[kb][4 * q + e];
-            *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
-          }
-      }
-      transformer_tile<PREC>(st, bias + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS, gz_j, g, pe, action_dim, wave, lane, jac);
-    }
-    // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
-    // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
-    float ph[3] = {0.f, 0.f, 0.f};
-    if (action) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int d0 = r, d1 = 16 + r;  // logical output index for hh = 0 / 1
-        const float a0 = (d0 / 3) < action_dim ? action[d0 / 3] : 0.f;
-        const float a1 = (d1 / 3) < action_dim ? action[d1 / 3] : 0.f;
-        ph[r % 3] = fmaf(jac[0][r], hh ? a1 : a0, ph[r % 3]);
-      }
-    }
-    // hh=0: spatial index s = r%3 ; hh=1: s = (16+r)%3 = (r+1)%3  ->  phase (s+2)%3
-    float mine[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) mine[s] = hh ? ph[(s + 2) % 3] : ph[s];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) o.flow[s] = mine[s] + __shfl_xor(mine[s], 32, 64);
-  } else {
-    o.flow[0] = o.flow[1] = o.flow[2] = 0.f;
-  }
+  for (int s = 0; s < 3; ++s) flow[s] = mine[s] + __shfl_xor(mine[s], 32, 64);
 }
 
 // =============================================================================================
@@ -869,6 +966,24 @@ struct RenderArgs {
   int samples;
   NjfRenderOutputs out;
 };
+
+// sample placement of lane j of tile t: interval [start, end], its mid-point and the world-space position there
+// (ray_samplers.py:104-147).  Recomputed from the bins after each network instead of being kept in registers.
+struct SamplePlace {
+  float delta, tm, px, py, pz;
+};
+__device__ __forceinline__ void place_sample(const float* __restrict__ bins, int sc_i, float near, float far, float ox,
+                                             float oy, float oz, float dx, float dy, float dz, SamplePlace& sp) {
+  const float b0 = bins[sc_i], b1 = bins[sc_i + 1];
+  const float start = b0 * far + (1.0f - b0) * near;
+  const float end = b1 * far + (1.0f - b1) * near;
+  const float se = start + end;
+  sp.delta = end - start;
+  sp.tm = se / 2.0f;
+  sp.px = ox + (dx * se) / 2.0f;
+  sp.py = oy + (dy * se) / 2.0f;
+  sp.pz = oz + (dz * se) / 2.0f;
+}
 
 // AF: composite the per-sample action features (sum_s w J, 16 more accumulators per lane) -- a compile-time switch
 // because the extra live registers cost ~80 spilled VGPRs in the frames that do not ask for them
@@ -919,59 +1034,74 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     const int s = t * 32 + j;
     const bool valid = s < S;
     const int sc_i = min(s, S - 1);
-    const float b0 = bins[sc_i], b1 = bins[sc_i + 1];
-    const float start = b0 * far + (1.0f - b0) * near;
-    const float end = b1 * far + (1.0f - b1) * near;
-    const float se = start + end;
-    const float tm = se / 2.0f;
-    const float px = ox + (dx * se) / 2.0f, py = oy + (dy * se) / 2.0f, pz = oz + (dz * se) / 2.0f;
+    const size_t si = (size_t)ray * S + s;
+    const bool store = valid && ray_ok;
     PointGeom g;
-    point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
-    TileOut o;
-    f32x16 geo[1], jac[1];
+    {
+      SamplePlace sp;
+      place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      point_geometry(cam, sp.px, sp.py, sp.pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
+    }
     ActDump dump{nullptr, nullptr, 0};
     ColorDump cdump{nullptr, nullptr, 0};
-    if (DUMP != 0 && valid && ray_ok) {
-      const size_t pidx = (size_t)ray * S + s, points = (size_t)a.rc.total_rays * S;
+    if (DUMP != 0 && store) {
+      const size_t points = (size_t)a.rc.total_rays * S;
       const NjfActivationDump d{DUMP == 1 ? a.out.jac_act : a.out.den_act, a.out.jac_pe, a.out.foot_idx, a.out.foot_w};
-      dump = point_dump(d, pidx, points, hh, g, b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
-      if (DUMP == 2) cdump = ColorDump{a.out.col_in + pidx * 32 + 16 * hh, a.out.col_act + pidx * 64 + 32 * hh, points * 64};
+      dump = point_dump(d, si, points, hh, g, b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
+      if (DUMP == 2) cdump = ColorDump{a.out.col_in + si * 32 + 16 * hh, a.out.col_act + si * 64 + 32 * hh, points * 64};
     }
-    decoder_tile<JKIND, PREC, DUMP>(st, gz_d, gz_j, g, dx, dy, dz, action, A, wave, lane, o, geo, jac, dump, cdump);
-    const float w = tile_weights(end - start, o.sigma, valid, j, carry);
-    if (valid) {
-      acc_w += w;
-      acc_wt = fmaf(w, tm, acc_wt);
-      tmin = fminf(tmin, tm);
-      tmax = fmaxf(tmax, tm);
-      const float pp[3] = {px, py, pz};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        acc_rgb[c] = fmaf(w, o.rgb[c], acc_rgb[c]);
-        acc_p[c] = fmaf(w, pp[c], acc_p[c]);
-        acc_pw[c] = fmaf(w, pp[c] + o.flow[c], acc_pw[c]);
+    // ---- density net -> sample weight; everything that only needs the weight is composited right away
+    f32x16 geo[1];
+    const float sigma = density_stage<PREC, DUMP>(st, gz_d, g, wave, lane, geo, DUMP == 2 ? dump : ActDump{nullptr, nullptr, 0});
+    float w;
+    {
+      SamplePlace sp;
+      place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      w = tile_weights(sp.delta, sigma, valid, j, carry);
+      if (valid) {
+        acc_w += w;
+        acc_wt = fmaf(w, sp.tm, acc_wt);
+        tmin = fminf(tmin, sp.tm);
+        tmax = fmaxf(tmax, sp.tm);
+        acc_p[0] = fmaf(w, sp.px, acc_p[0]);
+        acc_p[1] = fmaf(w, sp.py, acc_p[1]);
+        acc_p[2] = fmaf(w, sp.pz, acc_p[2]);
       }
-      if (want_af) {
+    }
+    if (store && hh == 0) {
+      if (a.out.weights) a.out.weights[si] = w;
+      if (a.out.density) a.out.density[si] = sigma;
+    }
+    // ---- colour head
+    {
+      float rgb[3];
+      color_stage<PREC, DUMP>(st, geo, dx, dy, dz, wave, lane, rgb, cdump);
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc_rgb[c] = fmaf(w, rgb[c], acc_rgb[c]);
+      }
+      if (store && hh == 0 && a.out.color) {
+        a.out.color[3 * si] = rgb[0];
+        a.out.color[3 * si + 1] = rgb[1];
+        a.out.color[3 * si + 2] = rgb[2];
+      }
+    }
+    // ---- Jacobian head -> scene flow
+    float flow[3] = {0.f, 0.f, 0.f};
+    if (WITH_J) {
+      f32x16 jac[1];
+      jacobian_stage<JKIND, PREC, DUMP>(st, gz_j, g, action, A, wave, lane, jac, flow, DUMP == 1 ? dump : ActDump{nullptr, nullptr, 0});
+      if (valid && want_af) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_j[r] = fmaf(w, jac[0][r], acc_j[r]);
       }
-      if (ray_ok) {
-        const size_t si = (size_t)ray * S + s;
-        if (hh == 0) {
-          if (a.out.weights) a.out.weights[si] = w;
-          if (a.out.density) a.out.density[si] = o.sigma;
-          if (a.out.color) {
-            a.out.color[3 * si] = o.rgb[0];
-            a.out.color[3 * si + 1] = o.rgb[1];
-            a.out.color[3 * si + 2] = o.rgb[2];
-          }
-          if (a.out.sample_flow) {
-            a.out.sample_flow[3 * si] = o.flow[0];
-            a.out.sample_flow[3 * si + 1] = o.flow[1];
-            a.out.sample_flow[3 * si + 2] = o.flow[2];
-          }
+      if (store) {
+        if (hh == 0 && a.out.sample_flow) {
+          a.out.sample_flow[3 * si] = flow[0];
+          a.out.sample_flow[3 * si + 1] = flow[1];
+          a.out.sample_flow[3 * si + 2] = flow[2];
         }
-        if (WITH_J && a.out.jacobian) {
+        if (a.out.jacobian) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int d = 16 * hh + r;
@@ -979,6 +1109,13 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
           }
         }
       }
+    }
+    if (valid) {
+      SamplePlace sp;
+      place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      acc_pw[0] = fmaf(w, sp.px + flow[0], acc_pw[0]);
+      acc_pw[1] = fmaf(w, sp.py + flow[1], acc_pw[1]);
+      acc_pw[2] = fmaf(w, sp.pz + flow[2], acc_pw[2]);
     }
   }
 
@@ -1112,34 +1249,44 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
     }
     const int A = a.cams.action_dim;
     const float* action = a.cams.action ? a.cams.action + (size_t)b * A : nullptr;
-    TileOut o;
-    f32x16 geo[1], jac[1];
-    // NOTE: `action` is per lane here (tiles may straddle batch elements)
-    decoder_tile<(MODE >= 2 ? MODE - 1 : 0), PREC>(st, a.gmap.data + gbase + a.goff_d, a.gmap.data + gbase + a.goff_j, g, dx, dy,
-                                             dz, action, A, wave, lane, o, geo, jac);
-    if (ok) {
-      if (hh == 0) {
-        if (a.density) a.density[p] = o.sigma;
-        if (a.color) {
-          a.color[3 * (size_t)p] = o.rgb[0];
-          a.color[3 * (size_t)p + 1] = o.rgb[1];
-          a.color[3 * (size_t)p + 2] = o.rgb[2];
-        }
-        if (a.flow && MODE >= 2) {
-          a.flow[3 * (size_t)p] = o.flow[0];
-          a.flow[3 * (size_t)p + 1] = o.flow[1];
-          a.flow[3 * (size_t)p + 2] = o.flow[2];
-        }
-        if (a.geo) {
+    constexpr int JK = MODE >= 2 ? MODE - 1 : 0;
+    const ActDump nodump{nullptr, nullptr, 0};
+    // stage by stage, each result stored before the next network starts (nothing but the point itself stays live)
+    f32x16 geo[1];
+    const float sigma = density_stage<PREC, 0>(st, a.gmap.data + gbase + a.goff_d, g, wave, lane, geo, nodump);
+    if (ok && hh == 0) {
+      if (a.density) a.density[p] = sigma;
+      if (a.geo) {
 #pragma unroll
-          for (int r = 0; r < 15; ++r) a.geo[15 * (size_t)p + r] = geo[0][r];
-        }
+        for (int r = 0; r < 15; ++r) a.geo[15 * (size_t)p + r] = geo[0][r];
       }
-      if (MODE >= 2 && a.jacobian) {
+    }
+    {
+      float rgb[3];
+      color_stage<PREC, 0>(st, geo, dx, dy, dz, wave, lane, rgb, ColorDump{nullptr, nullptr, 0});
+      if (ok && hh == 0 && a.color) {
+        a.color[3 * (size_t)p] = rgb[0];
+        a.color[3 * (size_t)p + 1] = rgb[1];
+        a.color[3 * (size_t)p + 2] = rgb[2];
+      }
+    }
+    if (JK != 0) {
+      f32x16 jac[1];
+      float flow[3];
+      // NOTE: `action` is per lane here (tiles may straddle batch elements)
+      jacobian_stage<JK, PREC, 0>(st, a.gmap.data + gbase + a.goff_j, g, action, A, wave, lane, jac, flow, nodump);
+      if (ok) {
+        if (hh == 0 && a.flow) {
+          a.flow[3 * (size_t)p] = flow[0];
+          a.flow[3 * (size_t)p + 1] = flow[1];
+          a.flow[3 * (size_t)p + 2] = flow[2];
+        }
+        if (a.jacobian) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = 16 * hh + r;
-          if (d < 3 * A) a.jacobian[(size_t)p * (3 * A) + d] = jac[0][r];
+          for (int r = 0; r < 16; ++r) {
+            const int d = 16 * hh + r;
+            if (d < 3 * A) a.jacobian[(size_t)p * (3 * A) + d] = jac[0][r];
+          }
         }
       }
     }
@@ -1513,6 +1660,33 @@ static int check_gmap(const NjfFeatureMap* gmap, int off, int channels = NJF_ZDI
   return NJF_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is needed once per (kernel, device), not per launch: a lock-free
+// set of the function pointers already raised, per device (every fused kernel is always launched with the same LDS size).
+static std::atomic<const void*> g_lds_raised[16][256];
+
+static bool lds_attribute_known(const void* fn) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  const size_t h = ((uintptr_t)fn >> 4) & 255;
+  for (int i = 0; i < 256; ++i) {
+    const void* v = g_lds_raised[dev][(h + i) & 255].load(std::memory_order_acquire);
+    if (v == fn) return true;
+    if (v == nullptr) return false;
+  }
+  return false;
+}
+
+static void lds_attribute_remember(const void* fn) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+  const size_t h = ((uintptr_t)fn >> 4) & 255;
+  for (int i = 0; i < 256; ++i) {
+    const void* expected = nullptr;
+    std::atomic<const void*>& slot = g_lds_raised[dev][(h + i) & 255];
+    if (slot.compare_exchange_strong(expected, fn, std::memory_order_acq_rel) || expected == fn) return;
+  }
+}
+
 template <typename K, typename A>
 static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, int lds_floats = LDS_FLOATS_RENDER) {
   static_assert(sizeof(A) <= 4096, "kernel args too large");
@@ -1522,11 +1696,27 @@ static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, 
 #else
   const size_t lds = (size_t)lds_floats * sizeof(float);
 #endif
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  if (!lds_attribute_known((const void*)kernel)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_attribute_remember((const void*)kernel);
+  }
   kernel<<<grid, NJF_THREADS, lds, s>>>(args);
   return launch_status();
 }
+
+// run `f(std::integral_constant<int, PREC_*>)` for the MFMA precision selected at run time
+template <typename F>
+static int with_precision(int precision, F&& f) {
+#ifdef NJF_DEV_ONLY_PREC  // development builds only (static ISA checks of one precision: a third of the compile time)
+  return f(std::integral_constant<int, NJF_DEV_ONLY_PREC>{});
+#else
+  if (precision == NJF_PRECISION_F16X2) return f(std::integral_constant<int, PREC_F16X2>{});
+  if (precision == NJF_PRECISION_F16F6) return f(std::integral_constant<int, PREC_F16F6>{});
+  return f(std::integral_constant<int, PREC_F32>{});
+#endif
+}
+#define NJF_P decltype(P)::value
 
 extern "C" int njf_proposal_forward(const float* origins, const float* directions, int rays_per_batch,
                                     const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
@@ -1538,7 +1728,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   if (rc) return rc;
   if (!w_pack || !b_pack || !bins_in || !u || !bins_out) return NJF_E_NULL;
   if (s_in < 1 || s_in > 256 || s_out < 1) return NJF_E_SAMPLES;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   if ((rc = check_gmap(gmap, gmap_offset))) return rc;
   ProposalArgs a;
   a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
@@ -1559,13 +1749,13 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   if (dump != nullptr && dump->act != nullptr) {  // training forward: inputs of the proposal net's backward pass
     if (!dump->pe || !dump->foot_idx || !dump->foot_w) return NJF_E_NULL;
     a.dump = *dump;
-    if (precision == NJF_PRECISION_F16X2)
-      return launch_fused(proposal_kernel<PREC_F16X2, true>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
-    return launch_fused(proposal_kernel<PREC_F32, true>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+    return with_precision(precision, [&](auto P) {
+      return launch_fused(proposal_kernel<NJF_P, true>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+    });
   }
-  if (precision == NJF_PRECISION_F16X2)
-    return launch_fused(proposal_kernel<PREC_F16X2>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
-  return launch_fused(proposal_kernel<PREC_F32>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+  return with_precision(precision, [&](auto P) {
+    return launch_fused(proposal_kernel<NJF_P>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
+  });
 }
 
 // The decoder blobs must be one allocation laid out [density | colour | jacobian] (what
@@ -1596,7 +1786,7 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   if (rc) return rc;
   if (!w_density || !b_density || !w_color || !b_color || !bins || !out) return NJF_E_NULL;
   if (samples < 1) return NJF_E_SAMPLES;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
   if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
@@ -1621,37 +1811,27 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
     if (!out->jac_pe || !out->foot_idx || !out->foot_w) return NJF_E_NULL;
     if (jacobian_kind == NJF_JACOBIAN_MLP) {
       if (!out->jac_act) return NJF_E_NULL;
-      if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<1, PREC_F16X2, 1>, a, n, s);
-      return launch_fused(render_kernel<1, PREC_F32, 1>, a, n, s);
+      return with_precision(precision, [&](auto P) { return launch_fused(render_kernel<1, NJF_P, 1>, a, n, s); });
     }
     if (out->jac_act) return NJF_E_MODE;
-    if (precision == NJF_PRECISION_F16X2) return launch_fused(render_kernel<2, PREC_F16X2, 1>, a, n, s);
-    return launch_fused(render_kernel<2, PREC_F32, 1>, a, n, s);
+    return with_precision(precision, [&](auto P) { return launch_fused(render_kernel<2, NJF_P, 1>, a, n, s); });
   }
   if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
     if (!out->jac_pe || !out->foot_idx || !out->foot_w || !out->col_in || !out->col_act) return NJF_E_NULL;
-    if (precision == NJF_PRECISION_F16X2) {
-      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F16X2, 2>, a, n, s);
-      if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F16X2, 2>, a, n, s);
-      return launch_fused(render_kernel<0, PREC_F16X2, 2>, a, n, s);
-    }
-    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, PREC_F32, 2>, a, n, s);
-    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, PREC_F32, 2>, a, n, s);
-    return launch_fused(render_kernel<0, PREC_F32, 2>, a, n, s);
+    return with_precision(precision, [&](auto P) {
+      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, NJF_P, 2>, a, n, s);
+      if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, NJF_P, 2>, a, n, s);
+      return launch_fused(render_kernel<0, NJF_P, 2>, a, n, s);
+    });
   }
   const bool af = with_j && out->action_features != nullptr;
-  if (precision == NJF_PRECISION_F16X2) {
+  return with_precision(precision, [&](auto P) {
     if (jacobian_kind == NJF_JACOBIAN_MLP)
-      return af ? launch_fused(render_kernel<1, PREC_F16X2, 0, true>, a, n, s) : launch_fused(render_kernel<1, PREC_F16X2, 0, false>, a, n, s);
+      return af ? launch_fused(render_kernel<1, NJF_P, 0, true>, a, n, s) : launch_fused(render_kernel<1, NJF_P, 0, false>, a, n, s);
     if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER)
-      return af ? launch_fused(render_kernel<2, PREC_F16X2, 0, true>, a, n, s) : launch_fused(render_kernel<2, PREC_F16X2, 0, false>, a, n, s);
-    return launch_fused(render_kernel<0, PREC_F16X2, 0, false>, a, n, s);
-  }
-  if (jacobian_kind == NJF_JACOBIAN_MLP)
-    return af ? launch_fused(render_kernel<1, PREC_F32, 0, true>, a, n, s) : launch_fused(render_kernel<1, PREC_F32, 0, false>, a, n, s);
-  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER)
-    return af ? launch_fused(render_kernel<2, PREC_F32, 0, true>, a, n, s) : launch_fused(render_kernel<2, PREC_F32, 0, false>, a, n, s);
-  return launch_fused(render_kernel<0, PREC_F32, 0, false>, a, n, s);
+      return af ? launch_fused(render_kernel<2, NJF_P, 0, true>, a, n, s) : launch_fused(render_kernel<2, NJF_P, 0, false>, a, n, s);
+    return launch_fused(render_kernel<0, NJF_P, 0, false>, a, n, s);
+  });
 }
 
 extern "C" int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
@@ -1663,7 +1843,7 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   if (!cams->ctxt_w2c || !cams->ctxt_k || !gmap->data) return NJF_E_NULL;
   if (points_per_batch < 1 || cams->batch < 1) return NJF_E_SHAPE;
   if (mode != 0 && mode != 1) return NJF_E_MODE;
-  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
+  if (!valid_precision(precision)) return NJF_E_MODE;
   int rc;
   if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
   PointsArgs a;
@@ -1686,19 +1866,14 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   a.geo = geo;
   const int tiles = (a.total_points + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
-  const bool split = precision == NJF_PRECISION_F16X2;
-  if (mode == 0) return split ? launch_fused(points_kernel<0, PREC_F16X2>, a, tiles, s) : launch_fused(points_kernel<0, PREC_F32>, a, tiles, s);
+  if (mode == 0) return with_precision(precision, [&](auto P) { return launch_fused(points_kernel<0, NJF_P>, a, tiles, s); });
   if (!w_color || !b_color) return NJF_E_NULL;
   if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
-  if (split) {
-    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, PREC_F16X2>, a, tiles, s);
-    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, PREC_F16X2>, a, tiles, s);
-    return launch_fused(points_kernel<1, PREC_F16X2>, a, tiles, s);
-  }
-  if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, PREC_F32>, a, tiles, s);
-  if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, PREC_F32>, a, tiles, s);
-  return launch_fused(points_kernel<1, PREC_F32>, a, tiles, s);
+  return with_precision(precision, [&](auto P) {
+    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, NJF_P>, a, tiles, s);
+    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, NJF_P>, a, tiles, s);
+    return launch_fused(points_kernel<1, NJF_P>, a, tiles, s);
+  });
 }
-

@@ -28,7 +28,8 @@ QDIM = 64
 JACOBIAN_NONE, JACOBIAN_MLP, JACOBIAN_TRANSFORMER = 0, 1, 2
 # MFMA precision of the fused MLPs (include/njf_hip.h: NJF_PRECISION_*).  "f16x2" = fp32 operands split into two
 # fp16 (hi+lo), three f16 MFMAs per product block, fp32 accumulation: fp32-class accuracy, ~5x less matrix time.
-PRECISIONS = {"f32": 0, "f16x2": 1}
+# "f16f6" = the same hi*hi product, the two 2^-11-sized correction products in block-scaled fp6 (4x the f16 MFMA rate).
+PRECISIONS = {"f32": 0, "f16x2": 1, "f16f6": 2}
 DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16x2")
 
 
