@@ -40,6 +40,14 @@ class EncoderResnetCfg:
 
 
 @dataclass
+class EncoderPrecomputedCfg:
+    """Not in the reference: an encoder entry whose forward returns a feature map the caller provides (cached encoder
+    output, synthetic benchmark features) -- encoder.EncoderPrecomputed."""
+    name: Literal["precomputed"] = "precomputed"
+    dim: int = 512
+
+
+@dataclass
 class DensityDecoderMlpCfg:
     name: Literal["density_mlp"] = "density_mlp"
     mlp: MlpCfg = field(default_factory=MlpCfg)
@@ -78,7 +86,7 @@ class ActionDecoderFlowMlpCfg:
     arm_action_dim: Optional[int] = None
 
 
-EncoderCfg = EncoderResnetCfg
+EncoderCfg = Union[EncoderResnetCfg, EncoderPrecomputedCfg]
 DensityDecoderCfg = DensityDecoderMlpCfg
 ActionDecoderCfg = Union[ActionDecoderJacobianMlpCfg, ActionDecoderFlowMlpCfg, ActionDecoderJacobianTransformerCfg]
 
@@ -120,7 +128,9 @@ def _build(cls, data: Dict[str, Any]):
         if key not in known:
             raise KeyError(f"{cls.__name__}: unknown field {key!r}")
         t = hints[key]
-        if key == "action_decoder" and isinstance(value, dict):
+        if key == "encoder" and isinstance(value, dict):
+            kwargs[key] = _build(EncoderPrecomputedCfg if value.get("name") == "precomputed" else EncoderResnetCfg, value)
+        elif key == "action_decoder" and isinstance(value, dict):
             name = value.get("name")
             if name not in _ACTION_DECODER_CFGS:
                 raise KeyError(f"unknown action decoder {name!r}; known: {sorted(_ACTION_DECODER_CFGS)}")

@@ -30,6 +30,7 @@ class PixelEncoding:
     extrinsics: torch.Tensor  # [B,4,4] context cam2world
     intrinsics: torch.Tensor  # [B,3,3] normalised context intrinsics
     action: torch.Tensor      # [B,A]
+    extrinsics_inv: Optional[torch.Tensor] = None  # not in the reference: world->camera, if the caller already has it
 
 
 @dataclass
@@ -141,7 +142,8 @@ def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trg
     zeros = torch.zeros(b, dtype=torch.float32, device=dev)
     if action is None:
         action = enc.action
-    return hip.make_cameras(hip.inverse(enc.extrinsics).contiguous(), enc.intrinsics.contiguous(),
+    w2c = hip.inverse(enc.extrinsics) if enc.extrinsics_inv is None else enc.extrinsics_inv
+    return hip.make_cameras(w2c.contiguous(), enc.intrinsics.contiguous(),
                             zeros if z_near is None else z_near.contiguous(),
                             zeros if z_far is None else z_far.contiguous(), trgt_w2c, trgt_k,
                             action.contiguous() if with_action else None, action_dim)

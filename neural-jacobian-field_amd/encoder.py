@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .config import EncoderCfg, EncoderResnetCfg
+from .config import EncoderCfg, EncoderResnetCfg  # noqa: F401
 
 
 def _norm_factory(norm_type: str) -> Optional[Callable[[int], nn.Module]]:
@@ -152,7 +152,29 @@ class EncoderResnet(Encoder):
         return 512
 
 
-ENCODERS = {"resnet": EncoderResnet}
+class EncoderPrecomputed(Encoder):
+    """``forward`` returns the feature map set with ``set_features`` ([B,dim,Hf,Wf], or a FeaturePyramid): for callers
+    that already hold the encoder output -- the control loop re-rendering one image, the benchmark's synthetic feature
+    maps, the parity harness.  Has no parameters; not part of the reference's registry."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.dim = cfg.dim
+        self.features = None
+
+    def set_features(self, features) -> None:
+        self.features = features
+
+    def forward(self, rgb=None):
+        if self.features is None:
+            raise RuntimeError("EncoderPrecomputed: call set_features(feature_map) before the forward pass")
+        return self.features
+
+    def get_output_dim(self) -> int:
+        return self.dim
+
+
+ENCODERS = {"resnet": EncoderResnet, "precomputed": EncoderPrecomputed}
 
 
 def get_encoder(cfg: EncoderCfg) -> Encoder:

@@ -140,6 +140,42 @@ def _check(code: int) -> None:
     raise RuntimeError(f"njf_hip: {msg} (hipError_t {code})")
 
 
+import threading
+
+_call = threading.local()  # per-thread: the device of the tensors handed to the entry point being assembled
+
+
+def _note_device(t, name: str) -> None:
+    """`t`: a tensor, or a Cameras / FeatureMap record (which remembers the device of the tensors it points to)."""
+    new = t.device if torch.is_tensor(t) else getattr(t, "_device", None)
+    if new is None:
+        return
+    dev = getattr(_call, "device", None)
+    if dev is None:
+        _call.device = new
+    elif dev != new:
+        raise ValueError(f"njf_hip: {name} lives on {new} but other arguments of this call live on {dev}; all tensors "
+                         "of one call must be on the same GPU")
+
+
+class _RecordScope:
+    """Pointers gathered inside the scope belong to a record built ahead of its call (Cameras, FeatureMap): their device
+    is stored on the record instead of leaking into whichever entry point is assembled next."""
+
+    def __enter__(self):
+        self.prev = getattr(_call, "device", None)
+        _call.device = None
+        return self
+
+    def close(self, record):
+        record._device = getattr(_call, "device", None)
+        return record
+
+    def __exit__(self, *exc):
+        _call.device = self.prev
+        return False
+
+
 def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
     if t is None:
         return None
@@ -149,6 +185,7 @@ def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
         raise ValueError(f"njf_hip: {name} must be float32 (got {t.dtype})")
     if not t.is_contiguous():
         raise ValueError(f"njf_hip: {name} must be contiguous")
+    _note_device(t, name)
     return t.data_ptr()
 
 
@@ -159,22 +196,58 @@ def inverse(m: torch.Tensor) -> torch.Tensor:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The torch stream of the device the call's tensors live on (NOT of the current device: a model loaded on cuda:N
+    without torch.cuda.set_device(N) would otherwise launch on device 0's stream with device-N pointers)."""
+    dev = getattr(_call, "device", None)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+# Optional per-launch timing for bench.py: a list that receives (name, start_event, end_event) for every fused launch,
+# recorded on the stream the kernel is launched on.  None (default) = no events, no overhead.
+_profile_sink = None
+
+
+def set_profile_sink(sink) -> None:
+    global _profile_sink
+    _profile_sink = sink
+
+
+def _launch(name: str, fn, *args) -> None:
+    """Run one C-ABI entry point on the device (and stream) of its tensor arguments, which `_ptr` collected while the
+    argument list was built."""
+    dev = getattr(_call, "device", None)
+    _call.device = None
+    if dev is None:
+        raise ValueError(f"njf_hip: {name} called without any device tensor")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        if _profile_sink is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            _check(fn(*args, stream.cuda_stream))
+            e1.record(stream)
+            _profile_sink.append((name, e0, e1))
+        else:
+            _check(fn(*args, stream.cuda_stream))
 
 
 def make_cameras(ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c=None, trgt_k=None, action=None, action_dim=None) -> Cameras:
     batch = ctxt_w2c.shape[0]
     a_dim = (0 if action is None else action.shape[-1]) if action_dim is None else action_dim
-    cams = Cameras(_ptr(ctxt_w2c, "ctxt_w2c"), _ptr(ctxt_k, "ctxt_k"), _ptr(trgt_w2c, "trgt_w2c"),
-                   _ptr(trgt_k, "trgt_k"), _ptr(z_near, "z_near"), _ptr(z_far, "z_far"), _ptr(action, "action"),
-                   batch, a_dim)
+    with _RecordScope() as scope:
+        cams = Cameras(_ptr(ctxt_w2c, "ctxt_w2c"), _ptr(ctxt_k, "ctxt_k"), _ptr(trgt_w2c, "trgt_w2c"),
+                       _ptr(trgt_k, "trgt_k"), _ptr(z_near, "z_near"), _ptr(z_far, "z_far"), _ptr(action, "action"),
+                       batch, a_dim)
+        scope.close(cams)
     cams._keep = (ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c, trgt_k, action)  # keep tensors alive
     return cams
 
 
 def make_feature_map(gmap: torch.Tensor) -> FeatureMap:
     """gmap: [B, Hf, Wf, C] channels-last hoisted map."""
-    fm = FeatureMap(_ptr(gmap, "gmap"), gmap.shape[1], gmap.shape[2], gmap.shape[3])
+    with _RecordScope() as scope:
+        fm = FeatureMap(_ptr(gmap, "gmap"), gmap.shape[1], gmap.shape[2], gmap.shape[3])
+        scope.close(fm)
     fm._keep = gmap
     return fm
 
@@ -208,8 +281,8 @@ def pack_resnetfc(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Ten
             raise ValueError("njf_hip: wz must be [512, ld] with wz_col + 384 <= ld and bz [ld]")
         wz_ptr = _ptr(wz, "wz") + 4 * wz_col
         bz_ptr = _ptr(bz, "bz") + 4 * wz_col
-    _check(load_library().njf_pack_resnetfc_ld(C.byref(src), _ptr(w_out), _ptr(b_out), wz_ptr, ld, bz_ptr,
-                                               precision_code(precision), _stream()))
+    _launch("njf_pack_resnetfc_ld", load_library().njf_pack_resnetfc_ld, C.byref(src), _ptr(w_out), _ptr(b_out), wz_ptr, ld, bz_ptr,
+                                               precision_code(precision))
 
 
 def pack_color_head(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, b_out: torch.Tensor,
@@ -218,17 +291,16 @@ def pack_color_head(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.T
         return _ptr(params[prefix + name].detach(), prefix + name)
 
     src = ColorHeadWeights(p("0.weight"), p("0.bias"), p("2.weight"), p("2.bias"), p("4.weight"), p("4.bias"))
-    _check(load_library().njf_pack_color_head(C.byref(src), _ptr(w_out), _ptr(b_out), precision_code(precision), _stream()))
+    _launch("njf_pack_color_head", load_library().njf_pack_color_head, C.byref(src), _ptr(w_out), _ptr(b_out), precision_code(precision))
 
 
 def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], kind: int, w_out: torch.Tensor,
                 b_out: Optional[torch.Tensor] = None, precision: Optional[str] = None) -> None:
     """One Linear [d_out, d_in] -> fragment-major block (see include/njf_hip.h: njf_pack_linear)."""
     d_out, d_in = weight.shape
-    _check(load_library().njf_pack_linear(_ptr(weight.detach().contiguous(), "weight"),
+    _launch("njf_pack_linear", load_library().njf_pack_linear, _ptr(weight.detach().contiguous(), "weight"),
                                           _ptr(None if bias is None else bias.detach().contiguous(), "bias"), d_out, d_in,
-                                          kind, _ptr(w_out, "w_out"), _ptr(b_out, "b_out"), precision_code(precision),
-                                          _stream()))
+                                          kind, _ptr(w_out, "w_out"), _ptr(b_out, "b_out"), precision_code(precision))
 
 
 def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor,
@@ -238,8 +310,8 @@ def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, ou
     n = wz.shape[1]
     if k != 512 or wz.shape[0] != 512 or tuple(out.shape) != (b, hf, wf, n):
         raise ValueError("njf_hip: project_features shape mismatch")
-    _check(load_library().njf_project_features_ld(_ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out),
-                                                  precision_code(precision), _stream()))
+    _launch("njf_project_features_ld", load_library().njf_project_features_ld, _ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out),
+                                                  precision_code(precision))
 
 
 def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor, precision: Optional[str] = None) -> None:
@@ -260,8 +332,8 @@ def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tenso
         if i > 0:
             ws_floats += b * lv.shape[2] * lv.shape[3] * n
     workspace = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=out.device)
-    _check(load_library().njf_project_pyramid(arr, len(levels), _ptr(wz), n, _ptr(bz), b, n, _ptr(out), _ptr(workspace),
-                                              precision_code(precision), _stream()))
+    _launch("njf_project_pyramid", load_library().njf_project_pyramid, arr, len(levels), _ptr(wz), n, _ptr(bz), b, n, _ptr(out), _ptr(workspace),
+                                              precision_code(precision))
 
 
 _hoist_order_cache: Dict[tuple, torch.Tensor] = {}
@@ -291,7 +363,7 @@ def upsample_concat(levels) -> torch.Tensor:
         keep.append(lv)
         arr[i] = PyramidLevel(_ptr(lv), lv.shape[1], lv.shape[2], lv.shape[3])
     out = torch.empty(b * h0 * w0, sum(lv.shape[1] for lv in levels), dtype=torch.float32, device=levels[0].device)
-    _check(load_library().njf_upsample_concat(arr, len(levels), b, _ptr(out), _stream()))
+    _launch("njf_upsample_concat", load_library().njf_upsample_concat, arr, len(levels), b, _ptr(out))
     return out
 
 
@@ -300,13 +372,14 @@ def upsample_concat(levels) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 def generate_rays(coords, height, width, k_inv, c2w, origins, directions, z) -> None:
     batch, rays = origins.shape[0], origins.shape[1]
-    _check(load_library().njf_generate_rays(_ptr(coords), height, width, _ptr(k_inv), _ptr(c2w), batch, rays,
-                                            _ptr(origins), _ptr(directions), _ptr(z), _stream()))
+    _launch("njf_generate_rays", load_library().njf_generate_rays, _ptr(coords), height, width, _ptr(k_inv), _ptr(c2w), batch, rays,
+                                            _ptr(origins), _ptr(directions), _ptr(z))
 
 
 def _int_ptr(t: torch.Tensor) -> int:
     if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
         raise ValueError("njf_hip: foot_idx must be a contiguous int32 device tensor")
+    _note_device(t, "foot_idx")
     return t.data_ptr()
 
 
@@ -320,10 +393,12 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
     if dump is not None:
         dump_ref = C.byref(ActivationDump(_ptr(dump["act"]), _ptr(dump["pe"]), _int_ptr(dump["foot_idx"]),
                                           _ptr(dump["foot_w"])))
-    _check(load_library().njf_proposal_forward(
+    _note_device(cams, "cameras")
+    _note_device(fmap, "feature map")
+    _launch("njf_proposal_forward", load_library().njf_proposal_forward, 
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), gmap_offset,
         _ptr(w_pack), _ptr(b_pack), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u), int(u.dim() > 1), s_out,
-        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), dump_ref, precision_code(precision), _stream()))
+        float(anneal), _ptr(bins_out), _ptr(weights_out), _ptr(density_out), dump_ref, precision_code(precision))
 
 
 def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int,
@@ -342,10 +417,12 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     w_c = base + 4 * RESNET_W_FLOATS
     with_j = jacobian_kind != JACOBIAN_NONE
     w_j = w_c + 4 * COLOR_W_FLOATS if with_j else None
-    _check(load_library().njf_render_forward(
+    _note_device(cams, "cameras")
+    _note_device(fmap, "feature map")
+    _launch("njf_render_forward", load_library().njf_render_forward, 
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian,
         jacobian_kind, base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_j else None,
-        _ptr(bins), samples, C.byref(out), precision_code(precision), _stream()))
+        _ptr(bins), samples, C.byref(out), precision_code(precision))
 
 
 def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int, mode: int,
@@ -356,20 +433,22 @@ def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int
     w_c = base + 4 * RESNET_W_FLOATS if mode == 1 else None
     with_j = mode == 1 and jacobian_kind != JACOBIAN_NONE
     w_j = (w_c + 4 * COLOR_W_FLOATS) if with_j else None
-    _check(load_library().njf_points_forward(
+    _note_device(cams, "cameras")
+    _note_device(fmap, "feature map")
+    _launch("njf_points_forward", load_library().njf_points_forward, 
         _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
         jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,
         _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo),
-        precision_code(precision), _stream()))
+        precision_code(precision))
 
 
 def solve_action(mean_position, jacobian, projection, target_flow, visible_mask, init_action, iterations: int,
                  damping: float, action) -> None:
     """mean_position [B,R,3], jacobian [B,R,3,A], projection [B,3,4], target_flow [B,R,2] -> action [B,A]."""
     b, r = target_flow.shape[:2]
-    _check(load_library().njf_solve_action(_ptr(mean_position), _ptr(jacobian), _ptr(projection), _ptr(target_flow),
+    _launch("njf_solve_action", load_library().njf_solve_action, _ptr(mean_position), _ptr(jacobian), _ptr(projection), _ptr(target_flow),
                                            _ptr(visible_mask), _ptr(init_action), b, r, jacobian.shape[-1], int(iterations),
-                                           float(damping), _ptr(action), _stream()))
+                                           float(damping), _ptr(action))
 
 
 def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
@@ -379,8 +458,8 @@ def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
     points, channels = grad.shape
     if tuple(foot_idx.shape) != (points, 4) or tuple(foot_w.shape) != (points, 4) or out.shape[1] != channels:
         raise ValueError("njf_hip: scatter_footprint shape mismatch")
-    _check(load_library().njf_scatter_footprint(_ptr(grad, "grad"), _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels,
-                                                out.shape[0], int(run_length), _ptr(out, "out"), _stream()))
+    _launch("njf_scatter_footprint", load_library().njf_scatter_footprint, _ptr(grad, "grad"), _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels,
+                                                out.shape[0], int(run_length), _ptr(out, "out"))
 
 
 RELU_BACKWARD_ROWS = 512  # rows per workgroup of njf_relu_backward (one partial column-sum row each)
@@ -395,19 +474,19 @@ def relu_backward(upstream: torch.Tensor, act: torch.Tensor, residual: Optional[
     out = torch.empty_like(upstream)
     blocks = (points + RELU_BACKWARD_ROWS - 1) // RELU_BACKWARD_ROWS
     partial = torch.empty(blocks, channels, dtype=torch.float32, device=upstream.device) if want_colsum else None
-    _check(load_library().njf_relu_backward(_ptr(upstream, "upstream"), _ptr(act, "act"), _ptr(residual, "residual"), points,
-                                            channels, RELU_BACKWARD_ROWS, _ptr(out, "out"), _ptr(partial, "partial"), _stream()))
+    _launch("njf_relu_backward", load_library().njf_relu_backward, _ptr(upstream, "upstream"), _ptr(act, "act"), _ptr(residual, "residual"), points,
+                                            channels, RELU_BACKWARD_ROWS, _ptr(out, "out"), _ptr(partial, "partial"))
     return out, (partial.sum(0) if want_colsum else None)
 
 
 def alpha_weights(deltas, densities, weights) -> None:
     samples = deltas.shape[-1]
     rays = deltas.numel() // samples
-    _check(load_library().njf_alpha_weights(_ptr(deltas), _ptr(densities), rays, samples, _ptr(weights), _stream()))
+    _launch("njf_alpha_weights", load_library().njf_alpha_weights, _ptr(deltas), _ptr(densities), rays, samples, _ptr(weights))
 
 
 def pdf_resample(weights, bins_in, u, s_out: int, anneal: float, bins_out) -> None:
     s_in = weights.shape[-1]
     rays = weights.numel() // s_in
-    _check(load_library().njf_pdf_resample(_ptr(weights), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u),
-                                           int(u.dim() > 1), s_out, float(anneal), rays, _ptr(bins_out), _stream()))
+    _launch("njf_pdf_resample", load_library().njf_pdf_resample, _ptr(weights), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u),
+                                           int(u.dim() > 1), s_out, float(anneal), rays, _ptr(bins_out))

@@ -5,8 +5,9 @@ Reference: ``models/model.py:35-144`` (I/O records), ``:147-213`` (construction,
 ``:215-314`` (ray bundle / proposal / render_*), ``:316-396`` (forward), ``:398-525`` (inference helpers),
 ``:527-628`` (patch_render).
 
-Round-1 scope: forward/inference (eval or training-mode sampling) under ``torch.no_grad`` semantics --
-outputs carry no autograd graph; the backward of the fused path is SURVEY.md section 8f #2.
+``Model.forward`` picks its path from the autograd state: an inference pass (in-kernel compositing) when no
+gradient is required, otherwise one of the two training paths of ``training.py`` (action mode: gradients to the
+Jacobian head; perception mode: gradients to encoder, density / colour heads and proposal networks).
 """
 
 from __future__ import annotations
@@ -133,13 +134,28 @@ class Model(nn.Module):
             num_nerf_samples_per_ray=r.num_nerf_samples, num_proposal_samples_per_ray=tuple(r.num_proposal_samples),
             num_proposal_network_iterations=n_prop, single_jitter=r.single_jitter, update_sched=update_schedule,
             initial_sampler=UniformSampler(single_jitter=r.single_jitter))
+        self._profile_events = None  # optional [before proposal, between, after render] torch events (bench.py)
+        self.set_precision(hip.DEFAULT_PRECISION)
 
-    def set_precision(self, precision: str) -> "Model":
-        """MFMA precision of the fused MLPs: "f16x2" (default; fp32 operands split into fp16 hi+lo, fp32
-        accumulate) or "f32" (exact fp32 products).  Weights are re-packed lazily."""
+    def set_precision(self, precision: str, proposal_precision: Optional[str] = None) -> "Model":
+        """MFMA precision of the fused MLPs (weights are re-packed lazily):
+
+        * ``"f32"``   exact fp32 products (v_mfma_f32_32x32x2_f32);
+        * ``"f16x2"`` fp32 operands split into fp16 hi + lo, hi*hi + hi*lo + lo*hi, fp32 accumulate;
+        * ``"f16f6"`` the same hi*hi, the two 2^-11-sized correction products in block-scaled fp6 -- half the matrix time
+          of f16x2 at ~1.5e-5 relative error per network.
+
+        ``proposal_precision`` applies to the proposal networks and defaults to ``precision`` -- except for ``"f16f6"``,
+        where the proposal networks stay on ``"f16x2"``: sample PLACEMENT feeds a positional encoding with a 2*pi*512
+        gain, so an error of 1e-5 in the proposal weights shows up as 3e-4 in depth / flow, while the same error inside
+        the final pass (at given sample locations) stays 1e-5 (measured: tools/prec_eval.py)."""
         hip.precision_code(precision)
-        for m in [self.decoder, *self.proposal_networks]:
-            m.precision = precision
+        if proposal_precision is None:
+            proposal_precision = "f16x2" if precision == "f16f6" else precision
+        hip.precision_code(proposal_precision)
+        self.decoder.precision = precision
+        for m in self.proposal_networks:
+            m.precision = proposal_precision
         return self
 
     # ---- schedule hooks (model.py:201-213) ---------------------------------------------
@@ -207,15 +223,29 @@ class Model(nn.Module):
     # ---- fused forward -------------------------------------------------------------------
     def _fused_render(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
                       features: torch.Tensor, want_lists: bool, want_vis: bool, want_samples: bool,
-                      dump_jacobian: bool = False, dump_perception: bool = False):
+                      dump_jacobian: bool = False, dump_perception: bool = False, want_sample_outputs: bool = False,
+                      final_bins: Optional[torch.Tensor] = None, ctxt_w2c: Optional[torch.Tensor] = None,
+                      trgt_w2c: Optional[torch.Tensor] = None, clip_depth: bool = True):
+        """THE orchestration of the fused path (one njf_proposal_forward per level, then njf_render_forward); every
+        public entry point -- forward, encode_image, patch_render, the training paths, renderer.FusedRenderer -- ends here.
+        ``want_sample_outputs`` adds per-sample colour and scene flow; ``final_bins`` ([B,R,S+1] spacing bins) skips the
+        proposal levels and renders exactly those samples; ``ctxt_w2c`` / ``trgt_w2c`` are inverses the caller already has."""
         enc = PixelEncoding(features=features, extrinsics=camera_input.ctxt_extrinsics,
-                            intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action)
+                            intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action, extrinsics_inv=ctxt_w2c)
         ray_bundle = self.compute_ray_bundle(rendering_input)
         self.proposal_sampler.train(self.training)
         proposal_dumps = [] if dump_perception else None
-        bins, weights_list, bins_list = self.proposal_sampler.generate_ray_samples_fused(
-            ray_bundle, list(self.proposal_networks), enc, rendering_input.z_near, rendering_input.z_far, want_lists,
-            dump_out=proposal_dumps)
+        ev = self._profile_events
+        if ev is not None:
+            ev[0].record()
+        if final_bins is None:
+            bins, weights_list, bins_list = self.proposal_sampler.generate_ray_samples_fused(
+                ray_bundle, list(self.proposal_networks), enc, rendering_input.z_near, rendering_input.z_far, want_lists,
+                dump_out=proposal_dumps)
+        else:
+            bins, weights_list, bins_list = final_bins.contiguous(), [], []
+        if ev is not None:
+            ev[1].record()
         o, d = rendering_input.origins.contiguous(), rendering_input.directions.contiguous()
         b, r = o.shape[:2]
         s = self.cfg.rendering.num_nerf_samples
@@ -233,6 +263,9 @@ class Model(nn.Module):
         if want_samples:
             outs["density"] = torch.empty(b, r, s, 1, **f32)
             outs["jacobian"] = torch.empty(b, r, s, a3, **f32)
+        if want_sample_outputs:
+            outs["color"] = torch.empty(b, r, s, 3, **f32)
+            outs["sample_flow"] = torch.empty(b, r, s, 3, **f32)
         if dump_jacobian:  # inputs of the Jacobian head's backward pass (training.py)
             pts = b * r * s
             outs["weights"] = outs.get("weights", torch.empty(b, r, s, **f32))
@@ -257,14 +290,16 @@ class Model(nn.Module):
         w, bd, bc, bj = self.decoder.packed()
         fmap = hip.make_feature_map(self.decoder.hoisted_map(features, enc.action))
         cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
-                        hip.inverse(camera_input.trgt_extrinsics).contiguous(),
+                        (hip.inverse(camera_input.trgt_extrinsics) if trgt_w2c is None else trgt_w2c).contiguous(),
                         camera_input.trgt_intrinsics.contiguous(), action=self.decoder.kernel_action(enc.action))
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
                            {k: v for k, v in outs.items() if torch.is_tensor(v)},
                            jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
-        # tensor-global clip of model.py:277
-        outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
-                                    max=outs["step_minmax"][..., 1].max())
+        if ev is not None:
+            ev[2].record()
+        if clip_depth:  # tensor-global clip of model.py:277
+            outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
+                                        max=outs["step_minmax"][..., 1].max())
         return outs, bins, weights_list, bins_list, ray_bundle
 
     def forward(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def dev():
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
     import __graft_entry__ as g
     g.build()
     return torch.device("cuda:0")
@@ -246,3 +247,126 @@ def test_binding_error_behaviour(dev):
     from neural_jacobian_field_amd.model import Model
     with pytest.raises(ValueError, match="action_dim"):
         Model(model_cfg_from_dict({"action_dim": 11}))
+
+
+# ---- BASELINE config 5 at its full size: 512 x 512 rays, F = [1,512,256,256], A = 6 --------------------------------------
+@pytest.fixture(scope="module")
+def full_frame_c5(dev):
+    import parity_harness as ph
+    from neural_jacobian_field_amd.renderer import RenderRequest
+    case = ph.make_case(1, 512, 512, None, 6, seed=0)
+    res, _, _ = ph.hip_forward(case, 64, 64, dev, request=RenderRequest(vis=True, sample_weights=True))
+    torch.cuda.synchronize()
+    return case, res
+
+
+def test_c5_full_size_outputs_are_sane(full_frame_c5):
+    case, res = full_frame_c5
+    assert res.rgb.shape == (1, 512 * 512, 3) and res.extras["action_features"].shape == (1, 512 * 512, 18)
+    for t in [res.rgb, res.depth, res.optical_flow, *res.extras.values()]:
+        assert torch.isfinite(t).all()
+    w = res.extras["weights"]
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()
+    assert (res.rgb >= -1e-6).all() and (res.rgb <= 1 + 1e-5).all()
+    near, far = case["cams"]["z_near"].item(), case["cams"]["z_far"].item()
+    assert (res.depth >= near - 1e-4).all() and (res.depth <= far + 1e-4).all()
+    for bins in res.bins_list:
+        assert (bins[..., 1:] >= bins[..., :-1]).all() and (bins >= 0).all() and (bins <= 1).all()
+
+
+def test_c5_full_size_ray_sharding_is_exact_and_reproducible(full_frame_c5, dev):
+    """The 8-GPU partition of config 5 (32,768 rays per rank) plus a ragged split, bit for bit; and a second full frame."""
+    import parity_harness as ph
+    case, res = full_frame_c5
+    n = 512 * 512
+    for bounds in ([n * i // 8 for i in range(9)], [0, 13, 100000, 100031, n]):
+        rgb, flow, depth = [], [], []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            sub = dict(case)
+            sub["origins"], sub["directions"] = case["origins"][:, lo:hi].contiguous(), case["directions"][:, lo:hi].contiguous()
+            r = ph.hip_forward(sub, 64, 64, dev)[0]
+            rgb.append(r.rgb); flow.append(r.optical_flow); depth.append(r.depth)
+        assert torch.equal(torch.cat(rgb, 1), res.rgb) and torch.equal(torch.cat(flow, 1), res.optical_flow)
+        assert torch.equal(torch.cat(depth, 1), res.depth)
+    again = ph.hip_forward(case, 64, 64, dev)[0]
+    assert torch.equal(again.rgb, res.rgb) and torch.equal(again.depth, res.depth) and torch.equal(again.optical_flow, res.optical_flow)
+
+
+def test_c5_fp6_corrected_final_pass_stays_within_the_bound(full_frame_c5, dev):
+    """Config 5 is the low-precision-MFMA configuration of BASELINE.json: the "f16f6" final pass against the default path
+    on the full 512 x 512 frame.  Identical proposal pass (both f16x2) => identical sample locations, so the difference is
+    the fp6 correction error alone."""
+    import parity_harness as ph
+    case, res = full_frame_c5
+    r6 = ph.hip_forward(case, 64, 64, dev, precision="f16f6")[0]
+    assert ph.rel_err(r6.rgb, res.rgb) < 1e-4 and ph.rel_err(r6.depth, res.depth) < 1e-4
+    assert ph.rel_err(r6.optical_flow, res.optical_flow) < 1e-4
+
+
+# ---- pixel-aligned sampling edge cases through the kernels' own footprint (SURVEY.md 8a row a5) ------------------------------
+def test_footprint_and_camera_transform_vs_reference_fixture(dev, golden):
+    """get_pixel_aligned_features (model_components/pixel_aligned_features.py:11-35) on the reference's fixture, which
+    holds points far outside the image (border padding) next to ordinary ones: every point becomes a one-sample ray, the
+    training-forward dump of njf_proposal_forward returns the kernel's OWN bilinear footprint (4 texel indices + weights)
+    and camera-space coordinates, and sum_c w_c F[texel_c] must equal the reference's grid_sample output."""
+    from neural_jacobian_field_amd import hip
+    from neural_jacobian_field_amd.renderer import pdf_u_eval
+    g = golden("pixel_aligned")
+    feats, xyz, c2w, k = g["feats"], g["xyz"], g["c2w"], g["k_norm"]           # [B,C,Hf,Wf], [B,N,3]
+    b, n = xyz.shape[:2]
+    hf, wf = feats.shape[-2:]
+    near, far = torch.tensor([1.0, 0.5]), torch.tensor([3.0, 2.5])
+    d = torch.tensor([0.0, 0.0, 1.0]).expand(b, n, 3).contiguous()
+    o = (xyz - d * ((near + far) / 2)[:, None, None]).contiguous()           # one sample whose mid-point is the point
+    f32 = dict(dtype=torch.float32, device=dev)
+    cams = hip.make_cameras(torch.inverse(c2w).to(dev).contiguous(), k.to(dev).contiguous(), near.to(dev), far.to(dev))
+    gmap = torch.zeros(b, hf, wf, hip.ZDIM, **f32)
+    pts = b * n
+    dump = {"act": torch.empty(11, pts, 128, **f32), "pe": torch.empty(pts, 64, **f32),
+            "foot_idx": torch.empty(pts, 4, dtype=torch.int32, device=dev), "foot_w": torch.empty(pts, 4, **f32)}
+    bins_out = torch.empty(b, n, 2, **f32)
+    hip.proposal_forward(o.to(dev), d.to(dev), cams, hip.make_feature_map(gmap), 0, torch.zeros(hip.RESNET_W_FLOATS, **f32),
+                         torch.zeros(hip.RESNET_B_FLOATS, **f32), torch.tensor([0.0, 1.0], device=dev), 1, pdf_u_eval(1, dev), 1,
+                         1.0, bins_out, precision="f32", dump=dump)
+    torch.cuda.synchronize()
+    # camera-space coordinates: encoding slots 30, 31 of the first half and 30 of the second (x, y | z)
+    pe = dump["pe"].cpu().reshape(b, n, 64)
+    cam_xyz = torch.stack([pe[..., 30], pe[..., 31], pe[..., 62]], -1)
+    ref_cam = g["out_xyz_cam"]
+    assert ((cam_xyz - ref_cam).abs().max() / ref_cam.abs().max()) < 1e-6
+    # bilinear footprint against grid_sample(bilinear, border, align_corners=True)
+    idx, w = dump["foot_idx"].cpu().long().reshape(b, n, 4), dump["foot_w"].cpu().reshape(b, n, 4)
+    flat = feats.permute(0, 2, 3, 1).reshape(b * hf * wf, -1)                  # texel-major, batch offsets included in idx
+    got = (flat[idx] * w[..., None]).sum(-2)
+    ref = g["out_feats"]
+    assert got.shape == ref.shape
+    assert ((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert (idx >= 0).all() and (idx < b * hf * wf).all() and ((w.sum(-1) - 1).abs() < 1e-6).all()
+    # the fixture's out-of-image points clamp to the border: a single texel carries (almost) all of the weight
+    assert w[0, 0].max() > 0.999 and w[1, 1].max() > 0.999
+
+
+def test_points_tile_straddling_batch_elements(dev, golden):
+    """A 32-point tile of points_kernel that spans two batch elements with DIFFERENT cameras and actions (40 points per
+    element: tile 1 holds points 32..39 of element 0 and 0..23 of element 1) equals the per-element evaluation."""
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.decoder import PixelEncoding
+    from neural_jacobian_field_amd.model import Model
+    g = {k: v.to(dev) for k, v in golden("model_mlp").items()}
+    cfg = model_cfg_from_dict({"action_dim": 8, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                               "action_decoder": {"name": "jacobian_mlp"}})
+    model = Model(cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", 8), seed=0), strict=True)
+    model.to(dev).eval().requires_grad_(False)
+    pos = g["final_positions"][:, :4, :10].contiguous()                       # [2, 4, 10, 3]: 40 points per element
+    dirs = g["directions"][:, :4, None, :].expand(pos.shape).contiguous()
+    action = torch.stack([g["action"][0], -3.0 * g["action"][1] + 0.2])
+    both = model.decoder.forward(pos, dirs, PixelEncoding(g["features"], g["ctxt_c2w"], g["ctxt_k_norm"], action))
+    for e in range(2):
+        sl = slice(e, e + 1)
+        one = model.decoder.forward(pos[sl], dirs[sl], PixelEncoding(g["features"][sl].contiguous(), g["ctxt_c2w"][sl].contiguous(),
+                                                                    g["ctxt_k_norm"][sl].contiguous(), action[sl].contiguous()))
+        for key in ("density", "color", "flow", "action_features"):
+            assert torch.equal(getattr(both, key)[sl], getattr(one, key)), (e, key)
+    assert not torch.equal(both.flow[0], both.flow[1])

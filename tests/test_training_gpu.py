@@ -13,7 +13,8 @@ def rel(a, b):
 
 @pytest.fixture(scope="module")
 def setup():
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
     import __graft_entry__ as g
     g.build()
     import parity_harness as ph
