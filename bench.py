@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: rendered rays/s of the fused hot path (BASELINE.json metric).
 
-A *step* is one full eval-mode rendering pass of ``Model.forward`` (reference
-``models/model.py:316-396``, encoder excluded -- it is per image, not per ray) over one synthetic
-256x256 frame, config C2 of SURVEY.md 8(d): B=1, 65,536 rays, 64 proposal + 64 final samples per
-ray, ``jacobian_mlp`` decoder, A=8, fp32.  Inside the timed region, per step and per rank:
+A *step* is one eval-mode ``Model.forward`` (reference ``models/model.py:316-396``) over one synthetic 256x256 frame,
+config C2 of SURVEY.md 8(d): B=1, 65,536 rays, 64 proposal + 64 final samples per ray, ``jacobian_mlp`` decoder, A=8,
+fp32 operands.  The image encoder is excluded as SURVEY 8(d) prescribes (it is per image, not per ray): the model is
+built with the ``"precomputed"`` encoder entry, whose forward returns the synthetic 512-channel feature map, so the
+timed call IS ``Model.forward`` -- per step and per rank
 
-    njf_project_features (lin_z hoist of the 512-ch feature map)  ->  njf_proposal_forward
-    ->  njf_render_forward  ->  photometric + flow loss against synthetic targets
-    ->  (N>1) RCCL all-reduce of the loss
+    per-image lin_z projection of the feature map (proposal net + decoder; the cache is reset every step)
+    -> njf_proposal_forward -> njf_render_forward -> depth clip -> photometric + flow loss against synthetic targets
 
-Inputs are resident in HBM when the clock starts.  N>1 is weak scaling: every rank renders its own
-frame (rays shard data-parallel, no data-path collective), value = total rays / max-over-ranks time.
+Inputs are resident in HBM when the clock starts.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]      (torchrun launches N>1)
+N > 1 (``torchrun``, one rank per GPU, RCCL over xGMI) -- ``--scaling strong`` (default), SURVEY.md 8(e) literally: the
+R rays of ONE frame are split into N contiguous shards (``parallel.shard_rays``), weights and feature map are
+replicated, each rank renders its shard through the same ``Model.forward``, and three small collectives run per step:
+all-reduce(MAX) of the two depth-clip bounds (``parallel.global_depth_clip``), all-reduce(SUM) of the image/flow loss
+sums (``parallel.sharded_losses``), all_gather of the [R/N, 6] pixel shards (``parallel.gather_frame``).
+value = rays of the frame / max-over-ranks time.  ``--scaling weak``: every rank renders its own full frame.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]      (torchrun launches N>1)
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,14 +36,25 @@ sys.path.insert(0, ROOT)
 
 H = W = 256
 S_PROP, S_FINAL, ACTION_DIM = 64, 64, 8
+PROFILE_ROUND = "r02"
 
 # Algorithmic work (hoisted-lin_z formulation), MACs per point
 MAC_PROPOSAL = 172_032
 MAC_DENSITY, MAC_JACOBIAN, MAC_COLOR = 173_952, 174_976, 6_272
-# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0}
-# MFMA instructions issued per algorithmic product block: the f16x2 path evaluates hi*hi + hi*lo + lo*hi
-ISSUE_FACTOR = {"f32": 1.0, "f16x2": 3.0}
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  "f16f6" issues f16 MFMAs (2.5 PFLOP/s) for the main product and
+# fp6 block-scaled MFMAs (10 PFLOP/s) for the correction terms; it is priced against the f16 peak, the slower of the two.
+PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "f16f6": 2500.0}
+# matrix-pipe time per algorithmic product block, in units of one f16 32x32x16 MFMA: f16x2 evaluates hi*hi + hi*lo + lo*hi;
+# f16f6 evaluates hi*hi in f16 and both corrections of FOUR K-steps in two fp6 instructions of the same issue time
+ISSUE_FACTOR = {"f32": 1.0, "f16x2": 3.0, "f16f6": 1.5}
+DTYPE_TEXT = {
+    "f32": "f32",
+    "f16x2": "f32 (matrix products as an error-compensated 2 x f16 split of the fp32 operands, 3 f16 MFMAs per block, fp32 "
+             "accumulate; same parity bound as the f32-MFMA path)",
+    "f16f6": "f32 (fp32 operands and accumulators; final pass: hi*hi in f16 + both 2^-11-sized correction products in "
+             "block-scaled fp6 MFMAs, proposal pass: 2 x f16 split; same parity suite and bounds as the f32-MFMA path, "
+             "profiles/r02_parity_margins.json)",
+}
 
 
 def parse():
@@ -44,46 +62,64 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: split ONE frame's rays over the ranks (SURVEY 8e, default) or one full frame per rank")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="single process: render only rank 0's shard of an N-way strong split (no collectives) -- predicts "
+                         "the per-rank step time of --gpus N on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rays", type=int, default=8192)
+    ap.add_argument("--cpu-sample-rays", type=int, default=2048, help="rays per CPU-baseline pass (one patch_render chunk)")
+    ap.add_argument("--cpu-passes", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--samples", type=int, default=S_FINAL, help="proposal and final samples per ray")
-    ap.add_argument("--precision", choices=["f16x2", "f32"], default=None,
-                    help="MFMA precision of the fused MLPs (default: package default, f16x2 split with fp32 accumulate)")
+    ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default=None,
+                    help="MFMA precision of the fused MLPs (default: the package default, hip.DEFAULT_PRECISION)")
+    ap.add_argument("--no-other-precisions", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(case, sample_rays: int):
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(case, sample_rays: int, passes: int):
     # the ONLY place bench.py touches oracle/: the reported CPU baseline (never the thing measured as `value`)
-    """Time the CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the SAME
-    workload: `sample_rays` rays of the 256x256 frame, 64+64 samples, chunked at 2048 rays exactly as
-    Model.patch_render does (models/model.py:533)."""
+    """Time the CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the SAME workload:
+    `sample_rays` rays of the 256x256 frame (one chunk of Model.patch_render, models/model.py:533), 64+64 samples.
+    One warm-up pass, then the median of `passes` timed passes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity_harness as ph
 
+    host_cores = os.cpu_count() or 1
     # 32 threads is the fastest setting on the GPU box's 256-core host (tools/cpu_threads_probe.py: 8/16/32/64/128
     # threads -> 760/762/808/707/337 rays/s; all 256 threads oversubscribe these small ops and drop to ~20 rays/s)
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
+    threads = min(host_cores, 32)
+    torch.set_num_threads(threads)
     sub = dict(case)
     sub["origins"] = case["origins"][:, :sample_rays].contiguous()
     sub["directions"] = case["directions"][:, :sample_rays].contiguous()
-    warm = dict(sub)
-    warm["origins"], warm["directions"] = sub["origins"][:, :128], sub["directions"][:, :128]
-    ph.oracle_forward(warm, S_PROP, S_FINAL)
-    t0 = time.perf_counter()
-    for lo in range(0, sample_rays, 2048):
-        chunk = dict(sub)
-        chunk["origins"] = sub["origins"][:, lo:lo + 2048]
-        chunk["directions"] = sub["directions"][:, lo:lo + 2048]
-        ph.oracle_forward(chunk, S_PROP, S_FINAL)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_rays / dt, 1), "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_rays} rays of the same 256x256 frame (64+64 samples), fp32, torch {torch.__version__} "
-                      f"CPU, {dt:.1f} s, chunked at 2048 rays like patch_render"}
+    times = []
+    for i in range(passes + 1):
+        t0 = time.perf_counter()
+        ph.oracle_forward(sub, S_PROP, S_FINAL)
+        if i:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(sample_rays / med, 1), "unit": "rays/s", "cores": threads, "threads": threads, "host_cores": host_cores,
+            "cpu_model": cpu_model_name(), "kind": "port", "passes": passes,
+            "pass_seconds": [round(t, 2) for t in times],
+            "sample": f"{sample_rays} rays of the same 256x256 frame (64+64 samples), fp32, torch {torch.__version__} CPU, "
+                      f"1 warm-up + median of {passes} passes of {med:.1f} s, one 2048-ray chunk like patch_render"}
 
 
 def main():
@@ -112,129 +148,166 @@ def main():
         entry.build()
     if dist is not None:
         dist.barrier()
-    from neural_jacobian_field_amd import geometry, hip, synthetic
-    from neural_jacobian_field_amd.renderer import FusedRenderer
+    from neural_jacobian_field_amd import geometry, hip, parallel, synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
 
-    # ---- synthetic frame: seeded weights/cameras replicated on every rank (data parallel), a per-rank
-    # feature map (each rank renders its own image); rays come from the HIP ray-generation kernel -------------------
+    strong = args.scaling == "strong"
+    sim_world = args.simulate_world if (world == 1 and args.simulate_world > 1) else 0
     HH, WW, BB, SS = args.height, args.width, args.batch, args.samples
     dev = lambda t: t.to(device)
+    # ---- synthetic frame: seeded weights / cameras replicated on every rank; the feature map is the same on
+    # every rank under strong scaling (one image) and differs per rank under weak scaling (one image each) ---------------
     params = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", ACTION_DIM, with_encoder=False), seed=0)
     cams = synthetic.synthetic_cameras(BB)
-    feats_cpu = synthetic.synthetic_features(BB, HH, WW, seed=1 + rank)
+    feats_cpu = synthetic.synthetic_features(BB, HH, WW, seed=1 + (0 if strong else rank))
     action_cpu = synthetic.synthetic_action(BB, ACTION_DIM, seed=2)
     ctxt_c2w, ctxt_k, trgt_c2w = dev(cams["ctxt_c2w"]), dev(cams["ctxt_k_norm"]), dev(cams["trgt_c2w"])
     z_near, z_far, action = dev(cams["z_near"]), dev(cams["z_far"]), dev(action_cpu)
-    origins, directions, _ = geometry.full_frame_rays(HH, WW, dev(cams["trgt_k_norm"]), trgt_c2w)
+    origins, directions, _ = geometry.full_frame_rays(HH, WW, dev(cams["trgt_k_norm"]), trgt_c2w)  # the HIP ray-generation kernel
     k_pix = geometry.denormalize_intrinsics(dev(cams["trgt_k_norm"]), WW, HH)
-    ctxt_w2c, trgt_w2c = torch.linalg.inv(ctxt_c2w), torch.linalg.inv(trgt_c2w)
     feats = dev(feats_cpu)
-    precision = args.precision or hip.DEFAULT_PRECISION
-    dev_params = {k: dev(v) for k, v in params.items()}
-    renderers = {}
-    for prec in ("f16x2", "f32"):
-        renderers[prec] = FusedRenderer(device, 1, ACTION_DIM, precision=prec)
-        renderers[prec].load_weights(dev_params)
-    fr = renderers[precision]
-    g = torch.Generator().manual_seed(100 + rank)
+    frame_rays = BB * HH * WW
+    g = torch.Generator().manual_seed(100 + (0 if strong else rank))
     trgt_rgb = dev(torch.rand(BB, HH * WW, 3, generator=g))
     trgt_flow = dev(torch.randn(BB, HH * WW, 2, generator=g))
-    rays = BB * HH * WW
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
-    loss_buf = torch.zeros(2, device=device)
+    shard_world, shard_rank = (world, rank) if (strong and world > 1) else ((sim_world, 0) if sim_world else (1, 0))
+    lo, hi = parallel.shard_bounds(HH * WW, shard_world, shard_rank)
+    o_loc, d_loc = origins[:, lo:hi].contiguous(), directions[:, lo:hi].contiguous()
+    rgb_loc, flow_loc = trgt_rgb[:, lo:hi].contiguous(), trgt_flow[:, lo:hi].contiguous()
+    local_rays = BB * (hi - lo)
 
-    def step(events=None, fr=fr):
-        if events:
-            events[0].record()
-        gmap = fr.project(feats)
-        if events:
-            events[1].record()
-        res = fr.render(gmap, origins, directions, ctxt_c2w, ctxt_k, z_near, z_far, [SS], SS,
-                        trgt_c2w=trgt_c2w, trgt_k_pix=k_pix, action=action, ctxt_w2c=ctxt_w2c, trgt_w2c=trgt_w2c,
-                        _events=events[2:5] if events else None)
-        # photometric + flow loss (model_wrapper.py:117-163), summed locally then all-reduced
-        loss_buf[0] = torch.nn.functional.mse_loss(res.rgb, trgt_rgb)
-        loss_buf[1] = 0.01 * torch.nn.functional.mse_loss(res.optical_flow, trgt_flow)
-        if dist is not None:
-            dist.all_reduce(loss_buf)
-        if events:
-            events[5].record()
-        return res
+    cfg = model_cfg_from_dict({"action_dim": ACTION_DIM, "encoder": {"name": "precomputed"},
+                               "rendering": {"num_proposal_samples": [SS], "num_nerf_samples": SS},
+                               "action_decoder": {"name": "jacobian_mlp"}})
+    precision = args.precision or hip.DEFAULT_PRECISION
+    models = {}
+    for prec in [precision] + ([] if args.no_other_precisions else [p for p in ("f16f6", "f16x2", "f32") if p != precision]):
+        m = Model(cfg).to(device).eval().requires_grad_(False)
+        m.load_state_dict({k: dev(v) for k, v in params.items()}, strict=True)
+        m.set_precision(prec)
+        m.encoder.set_features(feats)
+        if strong and world > 1:
+            parallel.enable_ray_sharding(m)
+        models[prec] = m
+    cam = CameraInput(input_image=None, ctxt_extrinsics=ctxt_c2w, ctxt_intrinsics=ctxt_k, trgt_extrinsics=trgt_c2w,
+                      trgt_intrinsics=k_pix)
+    rin = RenderingInput(o_loc, d_loc, z_near, z_far)
+    rob = RobotInput(action)
 
+    def step(model):
+        model.reset_image_cache()  # a new image every step: the per-image projection stays inside the timed region
+        out = model.forward(cam, rin, rob).standard_output
+        # photometric + flow loss (model_wrapper.py:117-163): local sums, ONE all-reduce over the ranks
+        losses = parallel.sharded_losses(out.rgb, rgb_loc, out.optical_flow, flow_loc)
+        frame = None
+        if strong and world > 1:
+            frame = parallel.gather_frame(torch.cat([out.rgb, out.depth, out.optical_flow], dim=-1), HH * WW)
+        return out, losses, frame
+
+    model = models[precision]
     for _ in range(args.warmup):
-        step()
+        step(model)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    launches = []
+    hip.set_profile_sink(launches)   # per-launch HIP events on the launch stream (roofline.achieved)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(ev[i])
+    for _ in range(args.steps):
+        step(model)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    hip.set_profile_sink(None)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # the other MFMA precision, measured briefly in the same process (not part of `value`)
-    alt = "f32" if precision == "f16x2" else "f16x2"
-    alt_steps = max(2, args.steps // 4)
-    alt_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(alt_steps)]
-    step(fr=renderers[alt])
-    torch.cuda.synchronize()
-    for i in range(alt_steps):
-        step(alt_ev[i], fr=renderers[alt])
-    torch.cuda.synchronize()
+    def kernel_ms(records, steps):
+        acc = {"project": 0.0, "proposal": 0.0, "render": 0.0}
+        for name, e0, e1 in records:
+            key = {"njf_project_features_ld": "project", "njf_project_pyramid": "project", "njf_proposal_forward": "proposal",
+                   "njf_render_forward": "render"}.get(name)
+            if key:
+                acc[key] += e0.elapsed_time(e1)
+        return {k: v / steps for k, v in acc.items()}
+
+    # the other MFMA precisions, measured briefly in the same process (never part of `value`)
+    others = {}
+    for prec, m in models.items():
+        if prec == precision:
+            continue
+        n = max(2, args.steps // 4)
+        step(m)
+        torch.cuda.synchronize()
+        rec = []
+        hip.set_profile_sink(rec)
+        ta = time.perf_counter()
+        for _ in range(n):
+            step(m)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - ta
+        hip.set_profile_sink(None)
+        others[prec] = (1e3 * dt / n, kernel_ms(rec, n))
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        value = world * rays * args.steps / elapsed
-        k_ms = {"project": 0.0, "proposal": 0.0, "render": 0.0}
-        for e in ev:
-            k_ms["project"] += e[0].elapsed_time(e[1])
-            k_ms["proposal"] += e[2].elapsed_time(e[3])
-            k_ms["render"] += e[3].elapsed_time(e[4])
-        k_ms = {k: v / args.steps for k, v in k_ms.items()}
-        render_flop = 2.0 * rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
+        total_rays = frame_rays if strong else world * frame_rays
+        if sim_world:
+            total_rays = local_rays
+        value = total_rays * args.steps / elapsed
+        k_ms = kernel_ms(launches, args.steps)
+        render_flop = 2.0 * local_rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
         achieved = render_flop / (k_ms["render"] * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"r01_render_kernel_hbm_bytes_{precision}.json")
-        if os.path.exists(pmc):
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_render_kernel_hbm_bytes_{precision}.json")
+        if os.path.exists(pmc) and local_rays == H * W and SS == S_FINAL:
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
+            traffic_source = (f"NOT measured in this run: read from profiles/{os.path.basename(pmc)} (rocprofv3 --pmc passes of "
+                              "this command on an earlier box, tools/profile_r02.sh + tools/summarize_profile.py)")
+        mode = "strong" if strong else "weak"
+        workload = ("C2: " if (BB, HH, WW, SS) == (1, 256, 256, 64) else "") + (
+            f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final samples/ray, jacobian_mlp, A=8, "
+            "eval-mode Model.forward (encoder excluded: 'precomputed' encoder entry returning the synthetic feature map; the "
+            "per-image lin_z projection is inside the timed call) + rgb/flow loss")
+        if world > 1:
+            workload += (" + RCCL: depth-clip all-reduce, loss all-reduce, all_gather of the pixel shards (rays of ONE frame split "
+                         "over the ranks)" if strong else " + RCCL loss all-reduce (one frame per rank)")
         out = {
             "metric": "rendered rays/s (64 samples/ray, 256^2 image)",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if precision == "f32" else "f32 (matrix products as an error-compensated 2 x f16 split of the fp32 "
-                     "operands, 3 f16 MFMAs per block, fp32 accumulate; same parity bound as the f32-MFMA path)",
-            "data": "synthetic",
-            "config": {"workload": ("C2: " if (BB, HH, WW, SS) == (1, 256, 256, 64) else "") +
-                                   f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final "
-                                   "samples/ray, jacobian_mlp, A=8, eval-mode Model.forward (encoder excluded), "
-                                   "+ rgb/flow loss" + (" + RCCL all-reduce" if dist is not None else ""),
-                       "rays_per_gpu": rays, "parallelism": f"dp{world} (ray-sharded, replicated weights)"},
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": mode, "vs_baseline": None,
+            "dtype": DTYPE_TEXT[precision], "data": "synthetic",
+            "config": {"workload": workload, "precision": precision, "rays_per_gpu": local_rays,
+                       "parallelism": f"dp{world} ({'one frame, rays sharded' if strong else 'one frame per rank'}, replicated weights "
+                                      "and feature map)"},
             "kernel_ms": {k: round(v, 3) for k, v in k_ms.items()},
             "roofline": {"kernel": f"render_kernel<jacobian_mlp, {precision}> (density+colour+Jacobian MLPs + compositing)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_flop_per_launch": render_flop,
                          "mfma_issue_factor": ISSUE_FACTOR[precision],
-                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_TFLOPS["f32"], 4)},
+                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_TFLOPS["f32"], 4),
+                         "timing": "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"},
         }
-        alt_ms = sum(e[0].elapsed_time(e[5]) for e in alt_ev) / alt_steps
-        alt_render = sum(e[3].elapsed_time(e[4]) for e in alt_ev) / alt_steps
-        alt_ach = render_flop / (alt_render * 1e-3) / 1e12
-        out["other_precision"] = {"precision": alt, "ms_per_step": round(alt_ms, 3), "rays_per_s_per_gpu": round(rays / (alt_ms * 1e-3), 1),
-                                  "render_kernel_ms": round(alt_render, 3), "roofline_achieved_tflops": round(alt_ach, 2),
-                                  "roofline_peak_tflops": PEAK_TFLOPS[alt], "roofline_frac": round(alt_ach / PEAK_TFLOPS[alt], 4)}
-        if world == 1 and not args.no_cpu_baseline and (BB, HH, WW, SS) == (1, 256, 256, 64):
+        if sim_world:
+            out["simulated"] = f"rank 0's shard of a {sim_world}-way strong split rendered on ONE GPU, no collectives: value counts only these rays"
+        out["other_precisions"] = {}
+        for prec, (ms, km) in others.items():
+            ach = render_flop / (km["render"] * 1e-3) / 1e12
+            out["other_precisions"][prec] = {"ms_per_step": round(ms, 3), "rays_per_s_per_gpu": round(local_rays / (ms * 1e-3), 1),
+                                             "kernel_ms": {k: round(v, 3) for k, v in km.items()},
+                                             "roofline_achieved_tflops": round(ach, 2), "roofline_peak_tflops": PEAK_TFLOPS[prec],
+                                             "roofline_frac": round(ach / PEAK_TFLOPS[prec], 4)}
+        if world == 1 and not sim_world and not args.no_cpu_baseline and (BB, HH, WW, SS) == (1, 256, 256, 64):
             case = {"params": params, "feats": feats_cpu, "cams": cams, "origins": origins.cpu(), "directions": directions.cpu(),
                     "k_pix": k_pix.cpu(), "action": action_cpu}
-            out["cpu_baseline"] = cpu_baseline(case, args.cpu_sample_rays)
+            out["cpu_baseline"] = cpu_baseline(case, args.cpu_sample_rays, args.cpu_passes)
         import ctypes
         ctypes.CDLL(None).fflush(None)  # anything native libraries buffered on stdout goes out BEFORE the JSON line
         sys.stdout.flush()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 10
+#define NJF_ABI_VERSION 11
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -116,6 +116,12 @@ typedef struct NjfFeatureMap {
 /* ---- library info ------------------------------------------------------------------------ */
 int njf_abi_version(void);
 const char* njf_error_string(int code);
+
+/* ---- camera matrices -------------------------------------------------------------------------- */
+/* out[i] = inverse(matrices[i]) for `count` row-major 4x4 fp32 matrices (Gauss-Jordan with partial pivoting evaluated
+ * in float64 and rounded once, one thread per matrix).  Replaces torch.inverse on camera extrinsics (transform_world2cam, rendering/geometry.py:59-65;
+ * project_world_coords_to_camera, :206-215), which PyTorch-ROCm runs as six rocSOLVER launches per call. */
+int njf_invert_4x4(const float* matrices, int count, float* out, void* stream);
 
 /* ---- weight packing (one-off per weight update) -------------------------------------------- */
 /* Packs one ResnetFC into `w_out` [NJF_RESNET_W_FLOATS] / `b_out` [NJF_RESNET_B_FLOATS] and its

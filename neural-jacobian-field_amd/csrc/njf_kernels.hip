@@ -625,6 +625,73 @@ extern "C" int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels
 }
 
 // =============================================================================================
+// batched 4x4 inverse (camera matrices: torch.inverse in rendering/geometry.py:52,64)
+// =============================================================================================
+// One thread per matrix: Gauss-Jordan elimination with partial pivoting on [M | I] in registers (fp64).  Replaces the
+// LAPACK-style getrf/getri sequence torch.linalg.inv launches per call (6 kernels + workspace fills, ~40 us of launch
+// latency for a 64-byte problem; three such calls per forward pass were a quarter of a 8,192-ray step).
+__global__ void invert4x4_kernel(const float* __restrict__ m, int n, float* __restrict__ out) {
+  // Evaluated in float64 and rounded once: the result is the correctly rounded inverse (to ~0.5 ulp), so it differs
+  // from the reference's fp32 LAPACK inverse only by LAPACK's own rounding error.  That matters: the context pose's
+  // inverse feeds the positional encoding (2*pi*512 gain), where one ulp of a matrix entry is ~1e-4 of the outputs --
+  // an fp32 Gauss-Jordan (2-3 ulp off) measured 4e-4 on the optical flow of a general-pose fixture, this form 7e-5.
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a[r][c] = (double)m[i * 16 + r * 4 + c];
+      a[r][4 + c] = r == c ? 1.0 : 0.0;
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int p = c;
+    double best = fabs(a[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < 4; ++r) {
+      const double v = fabs(a[r][c]);
+      if (v > best) {
+        best = v;
+        p = r;
+      }
+    }
+#pragma unroll
+    for (int r = c + 1; r < 4; ++r)  // swap rows c and p (static indices: the arrays stay in registers)
+      if (p == r) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double t = a[c][k];
+          a[c][k] = a[r][k];
+          a[r][k] = t;
+        }
+      }
+    const double inv = 1.0 / a[c][c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[r][k] = fma(-f, a[c][k], a[r][k]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[i * 16 + r * 4 + c] = (float)a[r][4 + c];
+}
+
+extern "C" int njf_invert_4x4(const float* matrices, int count, float* out, void* stream) {
+  if (!matrices || !out) return NJF_E_NULL;
+  if (count < 1) return NJF_E_SHAPE;
+  invert4x4_kernel<<<(count + 63) / 64, 64, 0, (hipStream_t)stream>>>(matrices, count, out);
+  return launch_status();
+}
+
+// =============================================================================================
 // ray generation (rendering/geometry.py:117-134, :170-203)
 // =============================================================================================
 __global__ void raygen_kernel(const float* __restrict__ coords, int height, int width, const float* __restrict__ k_inv,

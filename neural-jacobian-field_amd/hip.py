@@ -97,6 +97,7 @@ _SIGNATURES = {
     "njf_hoisted_channel": ([C.c_int, C.c_int], C.c_int),
     "njf_upsample_concat": ([C.POINTER(PyramidLevel), C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_solve_action": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp], C.c_int),
+    "njf_invert_4x4": ([_vp, C.c_int, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_proposal_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, _vp, _vp,
                               _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.POINTER(ActivationDump), C.c_int, _vp],
@@ -190,8 +191,14 @@ def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
 
 
 def inverse(m: torch.Tensor) -> torch.Tensor:
-    """Batched small-matrix inverse without the host synchronisation of torch.linalg.inv's error check
-    (camera matrices: torch.inverse in rendering/geometry.py:52,64)."""
+    """Batched small-matrix inverse (camera matrices: torch.inverse in rendering/geometry.py:52,64).  fp32 [...,4,4]
+    device tensors go through njf_invert_4x4 (one launch); anything else through torch.linalg.inv_ex, which unlike
+    torch.linalg.inv does not synchronise with the host for its error check."""
+    if m.is_cuda and m.dtype == torch.float32 and m.shape[-2:] == (4, 4) and m.numel() > 0 and not m.requires_grad:
+        src = m.contiguous()
+        out = torch.empty_like(src)
+        _launch("njf_invert_4x4", load_library().njf_invert_4x4, _ptr(src, "matrices"), src.numel() // 16, _ptr(out, "out"))
+        return out
     return torch.linalg.inv_ex(m).inverse
 
 

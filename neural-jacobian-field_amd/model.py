@@ -134,8 +134,22 @@ class Model(nn.Module):
             num_nerf_samples_per_ray=r.num_nerf_samples, num_proposal_samples_per_ray=tuple(r.num_proposal_samples),
             num_proposal_network_iterations=n_prop, single_jitter=r.single_jitter, update_sched=update_schedule,
             initial_sampler=UniformSampler(single_jitter=r.single_jitter))
-        self._profile_events = None  # optional [before proposal, between, after render] torch events (bench.py)
+        # render_depth's clip (model.py:277) takes its bounds from the WHOLE step tensor; under ray sharding
+        # parallel.enable_ray_sharding() swaps in the all-reduced form
+        self.depth_clip = self._local_depth_clip
         self.set_precision(hip.DEFAULT_PRECISION)
+
+    @staticmethod
+    def _local_depth_clip(depth: torch.Tensor, step_minmax: torch.Tensor) -> torch.Tensor:
+        return torch.clamp(depth, min=step_minmax[..., 0].min(), max=step_minmax[..., 1].max())
+
+    def reset_image_cache(self) -> "Model":
+        """Forget the hoisted feature maps.  They are cached per feature TENSOR (object + version counter), which is right
+        for a control loop that re-renders one image; a caller that refills the same tensor object behind torch's back, or
+        a benchmark that must include the per-image projection in every step, calls this first."""
+        for m in [self.decoder, *self.proposal_networks]:
+            m._hoist.key = None
+        return self
 
     def set_precision(self, precision: str, proposal_precision: Optional[str] = None) -> "Model":
         """MFMA precision of the fused MLPs (weights are re-packed lazily):
@@ -172,10 +186,12 @@ class Model(nn.Module):
 
     # ---- pieces of the forward (model.py:215-314) ---------------------------------------
     def compute_ray_bundle(self, rendering_input: RenderingInput) -> RayBundle:
-        ones = torch.ones_like(rendering_input.origins[..., 0:1])
+        # [B,R,1] views of the per-scene bounds (the reference multiplies a ones tensor, model.py:215-226: same values,
+        # two kernels and two [B,R,1] tensors more per call)
+        shape = (*rendering_input.origins.shape[:-1], 1)
         return RayBundle(origins=rendering_input.origins, directions=rendering_input.directions,
-                         nears=ones * rendering_input.z_near[:, None, None],
-                         fars=ones * rendering_input.z_far[:, None, None])
+                         nears=rendering_input.z_near[:, None, None].expand(shape),
+                         fars=rendering_input.z_far[:, None, None].expand(shape))
 
     def compute_proposal(self, ray_bundle: RayBundle, pixel_encoding: PixelEncoding):
         """model.py:228-255 through the generic sampler route (public pieces, arbitrary density_fns)."""
@@ -230,22 +246,19 @@ class Model(nn.Module):
         public entry point -- forward, encode_image, patch_render, the training paths, renderer.FusedRenderer -- ends here.
         ``want_sample_outputs`` adds per-sample colour and scene flow; ``final_bins`` ([B,R,S+1] spacing bins) skips the
         proposal levels and renders exactly those samples; ``ctxt_w2c`` / ``trgt_w2c`` are inverses the caller already has."""
+        if ctxt_w2c is None:  # one inverse per forward pass, shared by the proposal levels and the final pass
+            ctxt_w2c = hip.inverse(camera_input.ctxt_extrinsics)
         enc = PixelEncoding(features=features, extrinsics=camera_input.ctxt_extrinsics,
                             intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action, extrinsics_inv=ctxt_w2c)
         ray_bundle = self.compute_ray_bundle(rendering_input)
         self.proposal_sampler.train(self.training)
         proposal_dumps = [] if dump_perception else None
-        ev = self._profile_events
-        if ev is not None:
-            ev[0].record()
         if final_bins is None:
             bins, weights_list, bins_list = self.proposal_sampler.generate_ray_samples_fused(
                 ray_bundle, list(self.proposal_networks), enc, rendering_input.z_near, rendering_input.z_far, want_lists,
                 dump_out=proposal_dumps)
         else:
             bins, weights_list, bins_list = final_bins.contiguous(), [], []
-        if ev is not None:
-            ev[1].record()
         o, d = rendering_input.origins.contiguous(), rendering_input.directions.contiguous()
         b, r = o.shape[:2]
         s = self.cfg.rendering.num_nerf_samples
@@ -295,11 +308,8 @@ class Model(nn.Module):
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
                            {k: v for k, v in outs.items() if torch.is_tensor(v)},
                            jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
-        if ev is not None:
-            ev[2].record()
         if clip_depth:  # tensor-global clip of model.py:277
-            outs["depth"] = torch.clamp(outs["depth"], min=outs["step_minmax"][..., 0].min(),
-                                        max=outs["step_minmax"][..., 1].max())
+            outs["depth"] = self.depth_clip(outs["depth"], outs["step_minmax"])
         return outs, bins, weights_list, bins_list, ray_bundle
 
     def forward(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,

@@ -45,13 +45,17 @@ def allreduce_mean_loss(local_sq_err_sum: torch.Tensor, local_count: torch.Tenso
 
 def global_depth_clip(depth: torch.Tensor, step_minmax: torch.Tensor) -> torch.Tensor:
     """render_depth's clip bounds are min/max over the WHOLE [B,R,S] step tensor (model.py:277); under ray
-    sharding they need an all-reduce(MIN/MAX) of two scalars."""
-    lo = step_minmax[..., 0].min().reshape(1)
-    hi = step_minmax[..., 1].max().reshape(1)
+    sharding they need an all-reduce of two scalars -- ONE collective: MAX over (-min, max)."""
+    flat = step_minmax.reshape(-1, 2)
+    buf = torch.cat([-flat[:, 0], flat[:, 1]]).reshape(2, -1).amax(dim=1)   # (-min, max) in one reduction
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    return torch.clamp(depth, min=lo[0], max=hi[0])
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+    return torch.clamp(depth, min=-buf[0], max=buf[1])
+
+
+def enable_ray_sharding(model) -> None:
+    """Make ``Model.forward`` correct on a ray shard: its depth clip takes the all-reduced bounds."""
+    model.depth_clip = global_depth_clip
 
 
 def gather_frame(shard: torch.Tensor, num_rays: int) -> torch.Tensor:
@@ -71,29 +75,66 @@ def gather_frame(shard: torch.Tensor, num_rays: int) -> torch.Tensor:
 
 def sharded_losses(rgb: torch.Tensor, trgt_rgb: torch.Tensor, flow: Optional[torch.Tensor] = None,
                    trgt_flow: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """Photometric (+ 0.01 x flow) loss of a ray-sharded step, reduced over all ranks."""
-    out = {"loss/rgb": allreduce_mean_loss(((rgb - trgt_rgb) ** 2).sum(), torch.tensor(float(rgb.numel()), device=rgb.device))}
+    """Photometric (+ 0.01 x flow) loss of a ray-sharded step, reduced over all ranks in ONE all-reduce of
+    (sum, count) pairs -- the RCCL all-reduce of the image/flow loss of BASELINE.json's north_star."""
+    mse_sum = torch.nn.functional.mse_loss
+    sums = [mse_sum(rgb, trgt_rgb, reduction="sum").reshape(1)]
+    counts = [float(rgb.numel())]
     if flow is not None:
-        out["loss/flow_loss"] = 0.01 * allreduce_mean_loss(((flow - trgt_flow) ** 2).sum(),
-                                                           torch.tensor(float(flow.numel()), device=flow.device))
+        sums.append(mse_sum(flow, trgt_flow, reduction="sum").reshape(1))
+        counts.append(float(flow.numel()))
+    buf = torch.cat(sums + [_device_constant(tuple(counts), rgb.device)])
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    n = len(sums)
+    out = {"loss/rgb": buf[0] / buf[n]}
+    if flow is not None:
+        out["loss/flow_loss"] = 0.01 * buf[1] / buf[n + 1]
     return out
+
+
+_constants: Dict[tuple, torch.Tensor] = {}
+
+
+def _device_constant(values: Tuple[float, ...], device) -> torch.Tensor:
+    """A small constant vector on the device, uploaded once (per-step host-to-device copies of element counts are
+    launch latency on the critical path of a 2 ms step)."""
+    key = (values, str(device))
+    if key not in _constants:
+        _constants[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return _constants[key]
 
 
 def allreduce_gradients(parameters, average: bool = True) -> None:
     """DDP semantics for the trainable parameters (reference: Lightning `ddp_find_unused_parameters_true`,
     train.py:67-79): ONE flattened bucket per step -- action mode is 0.37 M parameters = 1.5 MB, far below where
-    bucketing matters, so the design point is a single latency-bound RCCL all-reduce over xGMI."""
-    params = [p for p in parameters if p.grad is not None]
+    bucketing matters, so the design point is a single latency-bound RCCL all-reduce over xGMI.
+
+    The bucket covers EVERY parameter that requires grad, in the given order, with zeros where this rank produced no
+    gradient -- ranks may disagree on which gradients exist (the proposal nets' `updated` schedule under
+    ``set_to_none``, a head the local graph did not reach), and buckets of different sizes would hang or corrupt the
+    collective.  A trailing flag per parameter tells whether ANY rank had a gradient; parameters nobody touched keep
+    ``grad = None`` (what the optimiser would have seen without data parallelism)."""
+    params = [p for p in parameters if p.requires_grad]
     if not params or not (dist.is_initialized() and dist.get_world_size() > 1):
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dev, dt = params[0].device, torch.float32
+    pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in params]
+    flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=dev, dtype=dt)
+    flat = torch.cat(pieces + [flags])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    seen = flat[-len(params):].tolist()
     if average:
         flat /= dist.get_world_size()
     off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+    for p, any_rank in zip(params, seen):
+        n = p.numel()
+        if any_rank > 0:
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
         off += n
 
 

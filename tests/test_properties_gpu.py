@@ -370,3 +370,23 @@ def test_points_tile_straddling_batch_elements(dev, golden):
         for key in ("density", "color", "flow", "action_features"):
             assert torch.equal(getattr(both, key)[sl], getattr(one, key)), (e, key)
     assert not torch.equal(both.flow[0], both.flow[1])
+
+
+def test_invert_4x4_vs_lapack(dev):
+    """njf_invert_4x4 (one launch) against torch.linalg.inv (six rocSOLVER launches): rigid poses, general well- and
+    ill-conditioned matrices, matrices that need row exchanges; the identity is reproduced exactly."""
+    from neural_jacobian_field_amd import hip
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(64, 4, 4, generator=g)
+    rigid = torch.eye(4).repeat(64, 1, 1)
+    rigid[:, :3, :3] = torch.matrix_exp(0.7 * (a[:, :3, :3] - a[:, :3, :3].transpose(1, 2)))
+    rigid[:, :3, 3] = a[:, :3, 3]
+    perm = torch.eye(4)[[2, 0, 3, 1]].repeat(8, 1, 1) * torch.rand(8, 1, 1, generator=g).add(0.5)   # zero pivots without exchanges
+    for name, m in (("rigid", rigid), ("general", a + 3 * torch.eye(4)), ("permuted", perm)):
+        got = hip.inverse(m.to(dev))
+        ref = torch.linalg.inv(m.double())
+        err = ((got.cpu().double() - ref).abs().amax((1, 2)) / ref.abs().amax((1, 2))).max().item()
+        cond = torch.linalg.cond(m.double()).max().item()
+        assert err < 2e-7 * max(cond, 1.0), (name, err, cond)
+    eye = torch.eye(4, device=dev).repeat(3, 2, 1, 1)
+    assert torch.equal(hip.inverse(eye), eye) and hip.inverse(eye).shape == eye.shape
