@@ -66,6 +66,10 @@ extern "C" {
                                   128-wide layers; the narrow layers (lin_out, colour head, transformer head) and
                                   the feature projection keep the F16X2 form */
 
+/* njf_render_forward / njf_points_forward: density + colour networks in precision `d`, Jacobian head in `j` (both one of
+ * the values above; mixed forms exist for the two split precisions).  A plain NJF_PRECISION_* value means d = j. */
+#define NJF_PRECISION_MIXED(d, j) ((d) | (((j) + 1) << 4))
+
 #define NJF_JACOBIAN_NONE 0
 #define NJF_JACOBIAN_MLP 1          /* ActionDecoderJacobianMLP (action_decoder_jacobian.py:261-337) */
 #define NJF_JACOBIAN_TRANSFORMER 2  /* ActionDecoderJacobianTransformer (:340-446), host-folded, see decoder.py */

@@ -42,8 +42,17 @@ extern "C" const char* njf_error_string(int code) {
   }
 }
 
-static inline bool valid_precision(int p) {
+static inline bool valid_base_precision(int p) {
   return p == NJF_PRECISION_F32 || p == NJF_PRECISION_F16X2 || p == NJF_PRECISION_F16F6;
+}
+// `precision` of the decoder entry points may name a second precision for the Jacobian head: NJF_PRECISION_MIXED(d, j)
+static inline int density_precision(int p) { return p & 15; }
+static inline int jacobian_precision(int p) { return (p >> 4) ? (p >> 4) - 1 : (p & 15); }
+static inline bool valid_precision(int p) {
+  if (p < 0 || p > 0xff || !valid_base_precision(density_precision(p)) || !valid_base_precision(jacobian_precision(p))) return false;
+  const int d = density_precision(p), j = jacobian_precision(p);
+  // mixed forms: the two split-precision modes in either order
+  return d == j || (d != NJF_PRECISION_F32 && j != NJF_PRECISION_F32);
 }
 
 static inline int launch_status() {
@@ -258,7 +267,7 @@ static void launch_pack(const float* w, const float* b, int d_out, int d_in, int
 extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
                                     float* bz_out, int precision, void* stream) {
   if (!src || !w_out || !b_out) return NJF_E_NULL;
-  if (!valid_precision(precision)) return NJF_E_MODE;
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
   const int P = precision;
   if (src->d_out < 1 || src->d_out > 32) return NJF_E_DOUT;
   if (!src->lin_in_w || !src->lin_in_b || !src->lin_out_w || !src->lin_out_b) return NJF_E_NULL;
@@ -293,7 +302,7 @@ extern "C" int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, fl
 extern "C" int njf_pack_linear(const float* w, const float* b, int d_out, int d_in, int kind, float* w_out, float* b_out,
                                int precision, void* stream) {
   if (!w || !w_out) return NJF_E_NULL;
-  if (!valid_precision(precision)) return NJF_E_MODE;
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
   if (d_out < 1 || d_in < 1) return NJF_E_SHAPE;
   if (kind == 1 && (d_in != NJF_PE_DIM || !b)) return NJF_E_SHAPE;
   if (kind != 0 && kind != 1) return NJF_E_MODE;
@@ -305,7 +314,7 @@ extern "C" int njf_pack_linear(const float* w, const float* b, int d_out, int d_
 extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out, float* b_out, int precision,
                                    void* stream) {
   if (!src || !w_out || !b_out || !src->w0 || !src->b0 || !src->w1 || !src->b1 || !src->w2 || !src->b2) return NJF_E_NULL;
-  if (!valid_precision(precision)) return NJF_E_MODE;
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
   hipStream_t s = (hipStream_t)stream;
   launch_pack(src->w0, src->b0, 64, 31, 2, 1, 2, precision, w_out, nullptr, s);
   launch_pack(src->w1, src->b1, 64, 64, 2, 2, 0, precision, w_out + 2048, b_out, s);
@@ -458,7 +467,7 @@ extern "C" int njf_project_features_ld(const float* feats, const float* wz, int 
                                        int n, float* out, int precision, void* stream) {
   if (!feats || !wz || !bz || !out) return NJF_E_NULL;
   if (batch < 1 || hw < 1 || n < 1 || wz_ld < n) return NJF_E_SHAPE;
-  if (!valid_precision(precision)) return NJF_E_MODE;
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
   launch_project(feats, 512, wz, wz_ld, bz, batch, hw, n, out, precision, (hipStream_t)stream);
   return launch_status();
 }
@@ -516,7 +525,7 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
                                    int batch, int n, float* out, float* workspace, int precision, void* stream) {
   if (!levels || !wz || !bz || !out) return NJF_E_NULL;
   if (num_levels < 1 || num_levels > 4 || batch < 1 || n < 4 || (n & 3) || wz_ld < n) return NJF_E_SHAPE;
-  if (!valid_precision(precision)) return NJF_E_MODE;
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
   if (num_levels > 1 && !workspace) return NJF_E_NULL;
   int rows = 0;
   for (int l = 0; l < num_levels; ++l) {
@@ -1054,7 +1063,8 @@ __device__ __forceinline__ void place_sample(const float* __restrict__ bins, int
 
 // AF: composite the per-sample action features (sum_s w J, 16 more accumulators per lane) -- a compile-time switch
 // because the extra live registers cost ~80 spilled VGPRs in the frames that do not ask for them
-template <int JKIND, int PREC, int DUMP = 0, bool AF = true>
+// PRECJ: MFMA precision of the Jacobian head (default: that of the density / colour networks)
+template <int JKIND, int PREC, int DUMP = 0, bool AF = true, int PRECJ = PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   constexpr bool WITH_J = JKIND != 0;
   constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
@@ -1157,7 +1167,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     float flow[3] = {0.f, 0.f, 0.f};
     if (WITH_J) {
       f32x16 jac[1];
-      jacobian_stage<JKIND, PREC, DUMP>(st, gz_j, g, action, A, wave, lane, jac, flow, DUMP == 1 ? dump : ActDump{nullptr, nullptr, 0});
+      jacobian_stage<JKIND, PRECJ, DUMP>(st, gz_j, g, action, A, wave, lane, jac, flow, DUMP == 1 ? dump : ActDump{nullptr, nullptr, 0});
       if (valid && want_af) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_j[r] = fmaf(w, jac[0][r], acc_j[r]);
@@ -1274,7 +1284,7 @@ struct PointsArgs {
 
 // MODE 0: proposal net (density only); 1: decoder without Jacobian head; 2: decoder + ResnetFC Jacobian head;
 // 3: decoder + transformer Jacobian head
-template <int MODE, int PREC>
+template <int MODE, int PREC, int PRECJ = PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1341,7 +1351,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
       f32x16 jac[1];
       float flow[3];
       // NOTE: `action` is per lane here (tiles may straddle batch elements)
-      jacobian_stage<JK, PREC, 0>(st, a.gmap.data + gbase + a.goff_j, g, action, A, wave, lane, jac, flow, nodump);
+      jacobian_stage<JK, PRECJ, 0>(st, a.gmap.data + gbase + a.goff_j, g, action, A, wave, lane, jac, flow, nodump);
       if (ok) {
         if (hh == 0 && a.flow) {
           a.flow[3 * (size_t)p] = flow[0];
@@ -1783,7 +1793,20 @@ static int with_precision(int precision, F&& f) {
   return f(std::integral_constant<int, PREC_F32>{});
 #endif
 }
+// ... and `f(P_density, P_jacobian)` for the decoder kernels, whose Jacobian head may run in the other split precision
+template <typename F>
+static int with_precisions(int precision, F&& f) {
+  const int d = density_precision(precision), j = jacobian_precision(precision);
+#ifdef NJF_DEV_ONLY_PREC
+  return f(std::integral_constant<int, NJF_DEV_ONLY_PREC>{}, std::integral_constant<int, NJF_DEV_ONLY_PREC>{});
+#else
+  if (d == j) return with_precision(d, [&](auto P) { return f(P, P); });
+  if (d == NJF_PRECISION_F16F6) return f(std::integral_constant<int, PREC_F16F6>{}, std::integral_constant<int, PREC_F16X2>{});
+  return f(std::integral_constant<int, PREC_F16X2>{}, std::integral_constant<int, PREC_F16F6>{});
+#endif
+}
 #define NJF_P decltype(P)::value
+#define NJF_PJ decltype(PJ)::value
 
 extern "C" int njf_proposal_forward(const float* origins, const float* directions, int rays_per_batch,
                                     const NjfCameras* cams, const NjfFeatureMap* gmap, int gmap_offset,
@@ -1795,7 +1818,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   if (rc) return rc;
   if (!w_pack || !b_pack || !bins_in || !u || !bins_out) return NJF_E_NULL;
   if (s_in < 1 || s_in > 256 || s_out < 1) return NJF_E_SAMPLES;
-  if (!valid_precision(precision)) return NJF_E_MODE;
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
   if ((rc = check_gmap(gmap, gmap_offset))) return rc;
   ProposalArgs a;
   a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
@@ -1878,26 +1901,27 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
     if (!out->jac_pe || !out->foot_idx || !out->foot_w) return NJF_E_NULL;
     if (jacobian_kind == NJF_JACOBIAN_MLP) {
       if (!out->jac_act) return NJF_E_NULL;
-      return with_precision(precision, [&](auto P) { return launch_fused(render_kernel<1, NJF_P, 1>, a, n, s); });
+      return with_precisions(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<1, NJF_P, 1, true, NJF_PJ>, a, n, s); });
     }
     if (out->jac_act) return NJF_E_MODE;
-    return with_precision(precision, [&](auto P) { return launch_fused(render_kernel<2, NJF_P, 1>, a, n, s); });
+    return with_precisions(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<2, NJF_P, 1, true, NJF_PJ>, a, n, s); });
   }
   if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
     if (!out->jac_pe || !out->foot_idx || !out->foot_w || !out->col_in || !out->col_act) return NJF_E_NULL;
-    return with_precision(precision, [&](auto P) {
-      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, NJF_P, 2>, a, n, s);
-      if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(render_kernel<2, NJF_P, 2>, a, n, s);
-      return launch_fused(render_kernel<0, NJF_P, 2>, a, n, s);
+    if (jacobian_kind == NJF_JACOBIAN_NONE)
+      return with_precision(density_precision(precision), [&](auto P) { return launch_fused(render_kernel<0, NJF_P, 2>, a, n, s); });
+    return with_precisions(precision, [&](auto P, auto PJ) {
+      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, NJF_P, 2, true, NJF_PJ>, a, n, s);
+      return launch_fused(render_kernel<2, NJF_P, 2, true, NJF_PJ>, a, n, s);
     });
   }
   const bool af = with_j && out->action_features != nullptr;
-  return with_precision(precision, [&](auto P) {
+  if (jacobian_kind == NJF_JACOBIAN_NONE)
+    return with_precision(density_precision(precision), [&](auto P) { return launch_fused(render_kernel<0, NJF_P, 0, false>, a, n, s); });
+  return with_precisions(precision, [&](auto P, auto PJ) {
     if (jacobian_kind == NJF_JACOBIAN_MLP)
-      return af ? launch_fused(render_kernel<1, NJF_P, 0, true>, a, n, s) : launch_fused(render_kernel<1, NJF_P, 0, false>, a, n, s);
-    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER)
-      return af ? launch_fused(render_kernel<2, NJF_P, 0, true>, a, n, s) : launch_fused(render_kernel<2, NJF_P, 0, false>, a, n, s);
-    return launch_fused(render_kernel<0, NJF_P, 0, false>, a, n, s);
+      return af ? launch_fused(render_kernel<1, NJF_P, 0, true, NJF_PJ>, a, n, s) : launch_fused(render_kernel<1, NJF_P, 0, false, NJF_PJ>, a, n, s);
+    return af ? launch_fused(render_kernel<2, NJF_P, 0, true, NJF_PJ>, a, n, s) : launch_fused(render_kernel<2, NJF_P, 0, false, NJF_PJ>, a, n, s);
   });
 }
 
@@ -1933,14 +1957,16 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   a.geo = geo;
   const int tiles = (a.total_points + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) return with_precision(precision, [&](auto P) { return launch_fused(points_kernel<0, NJF_P>, a, tiles, s); });
+  if (mode == 0)
+    return with_precision(density_precision(precision), [&](auto P) { return launch_fused(points_kernel<0, NJF_P>, a, tiles, s); });
   if (!w_color || !b_color) return NJF_E_NULL;
   if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
-  return with_precision(precision, [&](auto P) {
-    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, NJF_P>, a, tiles, s);
-    if (jacobian_kind == NJF_JACOBIAN_TRANSFORMER) return launch_fused(points_kernel<3, NJF_P>, a, tiles, s);
-    return launch_fused(points_kernel<1, NJF_P>, a, tiles, s);
+  if (!with_j)
+    return with_precision(density_precision(precision), [&](auto P) { return launch_fused(points_kernel<1, NJF_P>, a, tiles, s); });
+  return with_precisions(precision, [&](auto P, auto PJ) {
+    if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, NJF_P, NJF_PJ>, a, tiles, s);
+    return launch_fused(points_kernel<3, NJF_P, NJF_PJ>, a, tiles, s);
   });
 }

@@ -108,7 +108,8 @@ def initialize_jacobian_weights(m: nn.Module) -> None:
 
 
 def _version(module: nn.Module) -> Tuple:
-    return (getattr(module, "precision", None),) + tuple((p.data_ptr(), p._version) for p in module.parameters())
+    return ((getattr(module, "precision", None), getattr(module, "jacobian_precision", None))
+            + tuple((p.data_ptr(), p._version) for p in module.parameters()))
 
 
 class _HoistCache:
@@ -159,7 +160,7 @@ class DensityDecoderMlp(nn.Module):
             raise ValueError("fused path supports num_frequencies=10 (63-d positional encoding)")
         self.cfg = cfg
         self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=1)
-        self.precision = hip.DEFAULT_PRECISION  # "f32" | "f16x2" (MFMA precision of the fused MLP)
+        self.precision = hip.proposal_precision_for(hip.DEFAULT_PRECISION)  # MFMA precision of the fused MLP
         self._packed_version = None
         self._hoist = _HoistCache()
 
@@ -241,9 +242,21 @@ class ActionDecoderJacobian(ActionDecoder):
         self.action_dim = action_dim
         self.density_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=cfg.geometry_feature_dim + 1)
         self.mode = "regular"
-        self.precision = hip.DEFAULT_PRECISION  # "f32" | "f16x2"
+        self.precision = hip.DEFAULT_PRECISION  # "f32" | "f16x2" | "f16f6": density + colour networks
+        self.jacobian_precision = None          # the Jacobian head's, when it differs (Model.set_precision)
         self._packed_version = None
         self._hoist = _HoistCache()
+        # Reference checkpoints carry one key this module has no use for: SHEncoding(implementation="tcnn")
+        # (action_decoder_jacobian.py:284) wraps a tinycudann Encoding, which always registers a `params` Parameter -- empty
+        # for spherical harmonics.  It is accepted (and dropped) on load, so wrapper.load_state_dict(ckpt["state_dict"])
+        # works with strict=True as well as with the reference's strict=False (train.py:58).
+        self._register_load_state_dict_pre_hook(self._drop_tcnn_placeholder)
+
+    @staticmethod
+    def _drop_tcnn_placeholder(state_dict, prefix, *unused):
+        key = prefix + "directional_encoding.tcnn_encoding.params"
+        if key in state_dict and state_dict[key].numel() == 0:
+            del state_dict[key]
 
     def _make_color_head(self, cfg):
         return nn.Sequential(nn.Linear(cfg.geometry_feature_dim + 16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(),
@@ -281,6 +294,10 @@ class ActionDecoderJacobian(ActionDecoder):
         self.packed()
         return self._hoist.get(features, self._packed_version, self._wz, self._bz, self.precision)
 
+    @property
+    def j_precision(self) -> str:
+        return self.precision if self.jacobian_precision is None else self.jacobian_precision
+
     # what the kernel contracts the head's 3*A' outputs with: the robot action for the Jacobian heads
     @property
     def kernel_action_dim(self) -> int:
@@ -309,7 +326,7 @@ class ActionDecoderJacobian(ActionDecoder):
                                     action=self.kernel_action(enc.action)), fmap,
                            self.GOFF_DENSITY, self.GOFF_JACOBIAN, 1, w, bd, bc, bj,
                            jacobian_kind=self.JACOBIAN_KIND if with_jacobian else hip.JACOBIAN_NONE,
-                           precision=self.precision, **out)
+                           precision=self.precision, jacobian_precision=self.j_precision, **out)
         return out
 
     # ---- reference API -----------------------------------------------------------------
@@ -365,7 +382,7 @@ class ActionDecoderJacobianMLP(ActionDecoderJacobian):
         self.color_head = self._make_color_head(cfg)
 
     def _pack_jacobian(self, params, w_j, b_j, wz, bz):
-        hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.precision)
+        hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.j_precision)
 
 
 def initialize_flow_weights(m: nn.Module) -> None:
@@ -415,7 +432,7 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
         sliced = dict(params)
         for i in range(3):  # the kernels hoist the 512 feature columns; the action columns become a bias (hoisted_map)
             sliced[f"flow_head.lin_z.{i}.weight"] = params[f"flow_head.lin_z.{i}.weight"][:, :enc_dim].contiguous()
-        hip.pack_resnetfc(sliced, "flow_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.precision)
+        hip.pack_resnetfc(sliced, "flow_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.j_precision)
 
     @torch.no_grad()
     def hoisted_map(self, features: torch.Tensor, action: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -518,7 +535,7 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
         f32 = lambda x: x.to(torch.float32).contiguous()
         half = lambda i: w_j[4096 * i: 4096 * (i + 1)]
         qw = self.jacobian_query_mlp.weight  # [64, 63 + 512], input = cat[xyz_features, pixel_aligned_features] (:421-427)
-        hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0), precision=self.precision)
+        hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0), precision=self.j_precision)
         # hoisted query channels use the same in-block order as lin_z (csrc: njf_hoist_position, MB=2)
         pos = hip.hoisted_channel_order(64, qw.device)
         wz[:, hip.ZDIM + pos] = qw[:, 63:].t()
@@ -540,11 +557,11 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
             g2, be2 = ff.norm.weight.double(), ff.norm.bias.double()
             w1, b1 = ff.fn.net[0].weight.double(), ff.fn.net[0].bias.double()
             bl = b_j[256 * l: 256 * (l + 1)]
-            hip.pack_linear(f32(mqk * g1[None, :]), f32(mqk @ be1), 0, half(1 + 4 * l), bl[0:64], precision=self.precision)
-            hip.pack_linear(f32(nov), attn.fn.to_out[0].bias, 0, half(2 + 4 * l), bl[64:128], precision=self.precision)
-            hip.pack_linear(f32(w1 * g2[None, :]), f32(w1 @ be2 + b1), 0, half(3 + 4 * l), bl[128:192], precision=self.precision)
-            hip.pack_linear(ff.fn.net[3].weight, ff.fn.net[3].bias, 0, half(4 + 4 * l), bl[192:256], precision=self.precision)
-        hip.pack_linear(self.jacobian_head.weight, self.jacobian_head.bias, 0, half(13)[:2048], b_j[768:800], precision=self.precision)
+            hip.pack_linear(f32(mqk * g1[None, :]), f32(mqk @ be1), 0, half(1 + 4 * l), bl[0:64], precision=self.j_precision)
+            hip.pack_linear(f32(nov), attn.fn.to_out[0].bias, 0, half(2 + 4 * l), bl[64:128], precision=self.j_precision)
+            hip.pack_linear(f32(w1 * g2[None, :]), f32(w1 @ be2 + b1), 0, half(3 + 4 * l), bl[128:192], precision=self.j_precision)
+            hip.pack_linear(ff.fn.net[3].weight, ff.fn.net[3].bias, 0, half(4 + 4 * l), bl[192:256], precision=self.j_precision)
+        hip.pack_linear(self.jacobian_head.weight, self.jacobian_head.bias, 0, half(13)[:2048], b_j[768:800], precision=self.j_precision)
 
 
 # --------------------------------------------------------------------------------------

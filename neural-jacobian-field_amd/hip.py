@@ -30,14 +30,31 @@ JACOBIAN_NONE, JACOBIAN_MLP, JACOBIAN_TRANSFORMER = 0, 1, 2
 # fp16 (hi+lo), three f16 MFMAs per product block, fp32 accumulation: fp32-class accuracy, ~5x less matrix time.
 # "f16f6" = the same hi*hi product, the two 2^-11-sized correction products in block-scaled fp6 (4x the f16 MFMA rate).
 PRECISIONS = {"f32": 0, "f16x2": 1, "f16f6": 2}
-DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16x2")
+# Default: "f16f6" for the final pass with the proposal networks on "f16x2" (Model.set_precision's policy).  It passes the
+# same parity suite as the exact-fp32 path with the same bounds (profiles/r02_parity_margins.json).
+DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16f6")
 
 
-def precision_code(precision: Optional[str]) -> int:
+def proposal_precision_for(precision: str) -> str:
+    """The proposal networks' precision that goes with a decoder precision: the same, except that "f16f6" keeps sample
+    PLACEMENT on "f16x2" (an error of 1e-5 in the proposal weights moves samples enough to show up as 3e-4 in depth / flow
+    through the positional encoding's 2*pi*512 gain; inside the final pass the same error stays 1e-5)."""
+    return "f16x2" if precision == "f16f6" else precision
+
+
+def precision_code(precision: Optional[str], jacobian_precision: Optional[str] = None) -> int:
+    """include/njf_hip.h: NJF_PRECISION_* (and NJF_PRECISION_MIXED when the Jacobian head runs in another precision)."""
     name = DEFAULT_PRECISION if precision is None else precision
     if name not in PRECISIONS:
         raise ValueError(f"njf_hip: unknown precision {name!r}; choose from {sorted(PRECISIONS)}")
-    return PRECISIONS[name]
+    code = PRECISIONS[name]
+    if jacobian_precision is not None and jacobian_precision != name:
+        if jacobian_precision not in PRECISIONS:
+            raise ValueError(f"njf_hip: unknown precision {jacobian_precision!r}; choose from {sorted(PRECISIONS)}")
+        if "f32" in (name, jacobian_precision):
+            raise ValueError("njf_hip: mixed decoder precisions exist for the two split-precision modes only")
+        code |= (PRECISIONS[jacobian_precision] + 1) << 4
+    return code
 
 _vp = C.c_void_p
 
@@ -410,8 +427,10 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
 
 def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int,
                    w_all: torch.Tensor, b_density, b_color, b_jacobian, bins, samples: int, outputs: Dict[str, torch.Tensor],
-                   jacobian_kind: int = JACOBIAN_MLP, precision: Optional[str] = None) -> None:
-    """``w_all`` is the single allocation [density | colour | jacobian head] of packed weights."""
+                   jacobian_kind: int = JACOBIAN_MLP, precision: Optional[str] = None,
+                   jacobian_precision: Optional[str] = None) -> None:
+    """``w_all`` is the single allocation [density | colour | jacobian head] of packed weights; ``jacobian_precision``
+    (default: ``precision``) is the MFMA precision the Jacobian head's blob was packed for."""
     rays_per_batch = origins.shape[1]
     out = RenderOutputs()
     for name, _ in RenderOutputs._fields_:
@@ -429,12 +448,13 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     _launch("njf_render_forward", load_library().njf_render_forward, 
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian,
         jacobian_kind, base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_j else None,
-        _ptr(bins), samples, C.byref(out), precision_code(precision))
+        _ptr(bins), samples, C.byref(out), precision_code(precision, jacobian_precision))
 
 
 def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int, mode: int,
                    w_all, b_density, b_color=None, b_jacobian=None, jacobian_kind: int = JACOBIAN_NONE, density=None,
-                   color=None, flow=None, jacobian=None, geo=None, precision: Optional[str] = None) -> None:
+                   color=None, flow=None, jacobian=None, geo=None, precision: Optional[str] = None,
+                   jacobian_precision: Optional[str] = None) -> None:
     points_per_batch = xyz.shape[1]
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS if mode == 1 else None
@@ -446,7 +466,7 @@ def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int
         _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
         jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,
         _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo),
-        precision_code(precision))
+        precision_code(precision, jacobian_precision))
 
 
 def solve_action(mean_position, jacobian, projection, target_flow, visible_mask, init_action, iterations: int,

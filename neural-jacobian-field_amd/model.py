@@ -151,7 +151,8 @@ class Model(nn.Module):
             m._hoist.key = None
         return self
 
-    def set_precision(self, precision: str, proposal_precision: Optional[str] = None) -> "Model":
+    def set_precision(self, precision: str, proposal_precision: Optional[str] = None,
+                      jacobian_precision: Optional[str] = None) -> "Model":
         """MFMA precision of the fused MLPs (weights are re-packed lazily):
 
         * ``"f32"``   exact fp32 products (v_mfma_f32_32x32x2_f32);
@@ -159,18 +160,88 @@ class Model(nn.Module):
         * ``"f16f6"`` the same hi*hi, the two 2^-11-sized correction products in block-scaled fp6 -- half the matrix time
           of f16x2 at ~1.5e-5 relative error per network.
 
-        ``proposal_precision`` applies to the proposal networks and defaults to ``precision`` -- except for ``"f16f6"``,
-        where the proposal networks stay on ``"f16x2"``: sample PLACEMENT feeds a positional encoding with a 2*pi*512
-        gain, so an error of 1e-5 in the proposal weights shows up as 3e-4 in depth / flow, while the same error inside
-        the final pass (at given sample locations) stays 1e-5 (measured: tools/prec_eval.py)."""
+        ``precision`` applies to the density and colour networks of the final pass.  ``proposal_precision`` (proposal
+        networks) and ``jacobian_precision`` (Jacobian / flow head) default to it -- except under ``"f16f6"``, where both
+        default to ``"f16x2"``: sample PLACEMENT feeds a positional encoding with a 2*pi*512 gain (1e-5 in the proposal
+        weights becomes 3e-4 in depth / flow), and the optical flow is a small difference of two projections in which the
+        head's 1.5e-5 shows up amplified (2e-4 on a two-level fixture, against 2e-5 for rgb and 6e-5 for depth from the
+        density / colour side).  Measured: tools/prec_eval.py, profiles/r02_parity_margins.json, DESIGN.md section 5."""
         hip.precision_code(precision)
         if proposal_precision is None:
-            proposal_precision = "f16x2" if precision == "f16f6" else precision
+            proposal_precision = hip.proposal_precision_for(precision)
+        if jacobian_precision is None:
+            jacobian_precision = hip.proposal_precision_for(precision)
         hip.precision_code(proposal_precision)
+        hip.precision_code(precision, jacobian_precision)
         self.decoder.precision = precision
+        self.decoder.jacobian_precision = None if jacobian_precision == precision else jacobian_precision
         for m in self.proposal_networks:
             m.precision = proposal_precision
         return self
+
+    @torch.no_grad()
+    def activation_range(self, camera_input: "CameraInput", rendering_input: "RenderingInput", robot_input: "RobotInput",
+                         max_points: int = 1 << 16) -> Dict[str, float]:
+        """Largest |input of any matrix product| per network on (a prefix of) the given rays, measured on the exact-fp32
+        MFMA path through the training-forward activation dumps: the ReLU'd input of every ResnetFC layer, the positional
+        encoding, the colour head's inputs and hidden layers; plus the largest |weight|.  These are the values the
+        split-precision modes convert to fp16."""
+        s_max = max(self.cfg.rendering.num_nerf_samples, *self.cfg.rendering.num_proposal_samples)
+        b = rendering_input.origins.shape[0]
+        rays = max(1, min(rendering_input.origins.shape[1], max_points // max(1, b * s_max)))
+        rin = RenderingInput(rendering_input.origins[:, :rays].contiguous(), rendering_input.directions[:, :rays].contiguous(),
+                             rendering_input.z_near, rendering_input.z_far)
+        saved = (self.decoder.precision, [m.precision for m in self.proposal_networks], self.decoder.jacobian_precision)
+        was_training = self.training
+        self.set_precision("f32")
+        self.eval()
+        try:
+            features = self._encode_for_render(camera_input.input_image)
+            if not torch.is_tensor(features):      # the dump path projects the concatenated map
+                features = self.encoder.forward(camera_input.input_image)
+            out = {}
+            outs, *_ = self._fused_render(camera_input, rin, robot_input, features, want_lists=True, want_vis=False,
+                                          want_samples=False, dump_perception=True)
+            out["density_head"] = float(outs["den_act"].abs().max())
+            out["color_head"] = float(torch.maximum(outs["col_in"].abs().max(), outs["col_act"].abs().max()))
+            out["positional_encoding"] = float(outs["jac_pe"].abs().max())
+            for i, d in enumerate(outs["proposal_dumps"]):
+                out[f"proposal_networks.{i}"] = float(d["act"].abs().max())
+            if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:
+                outs, *_ = self._fused_render(camera_input, rin, robot_input, features, want_lists=False, want_vis=True,
+                                              want_samples=False, dump_jacobian=True)
+                out["jacobian_head"] = float(outs["jac_act"].abs().max())
+            out["weights"] = max(float(p.detach().abs().max()) for n, p in self.named_parameters() if not n.startswith("encoder."))
+        finally:
+            self.decoder.precision, self.decoder.jacobian_precision = saved[0], saved[2]
+            for m, p in zip(self.proposal_networks, saved[1]):
+                m.precision = p
+            self.train(was_training)
+        return out
+
+    def calibrate_precision(self, camera_input: "CameraInput", rendering_input: "RenderingInput", robot_input: "RobotInput",
+                            fallback: str = "f32", headroom: float = 4.0) -> str:
+        """Operating-range check of the split-precision modes, to be run once per checkpoint (or every few hundred
+        optimiser steps) on a representative batch.  "f16x2" / "f16f6" carry the leading bits of every fp32 operand in
+        fp16: values up to 65,504 are represented to fp32 accuracy, anything larger becomes inf -- and the fused kernels'
+        integer ReLU can turn the resulting negative NaNs into zeros, so an overflow is NOT guaranteed to surface as a
+        non-finite output.  This measures the largest operand on the exact-fp32 path (``activation_range``) and switches
+        the model to ``fallback`` (with a warning) when it comes within ``headroom`` x of fp16's limit.  Returns the
+        precision in force afterwards.  Costs a few small fused launches and one host synchronisation."""
+        import warnings
+
+        current = self.decoder.precision
+        if current == fallback:
+            return current
+        ranges = self.activation_range(camera_input, rendering_input, robot_input)
+        worst = max(ranges, key=ranges.get)
+        if not (ranges[worst] * headroom < 65504.0):   # also catches NaN
+            warnings.warn(f"njf: |operand| reaches {ranges[worst]:.3g} in {worst} on the calibration batch, within {headroom:g}x of "
+                          f"fp16's range (65,504): the {current!r} MFMA precision is not safe for this checkpoint.  Switching "
+                          f"this model to {fallback!r}.", RuntimeWarning)
+            self.set_precision(fallback)
+            return fallback
+        return current
 
     # ---- schedule hooks (model.py:201-213) ---------------------------------------------
     def step_before_iter(self, step):
@@ -307,7 +378,8 @@ class Model(nn.Module):
                         camera_input.trgt_intrinsics.contiguous(), action=self.decoder.kernel_action(enc.action))
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
                            {k: v for k, v in outs.items() if torch.is_tensor(v)},
-                           jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision)
+                           jacobian_kind=self.decoder.JACOBIAN_KIND, precision=self.decoder.precision,
+                           jacobian_precision=self.decoder.j_precision)
         if clip_depth:  # tensor-global clip of model.py:277
             outs["depth"] = self.depth_clip(outs["depth"], outs["step_minmax"])
         return outs, bins, weights_list, bins_list, ray_bundle

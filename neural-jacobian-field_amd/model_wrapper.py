@@ -143,6 +143,7 @@ class ModelWrapper(torch.nn.Module):
         self.mode = mode
         self.rays_per_batch = rays_per_batch
         self.register_buffer("depth_sigma", torch.tensor([0.001]))
+        self.global_step = 0  # optimiser steps taken (LightningModule.global_step)
         if mode == "action":  # model_wrapper.py:75-85
             self.model.decoder.freeze_non_action_parameters()
             for name, p in self.model.named_parameters():
@@ -167,8 +168,24 @@ class ModelWrapper(torch.nn.Module):
 
     def training_step(self, batch: Dict, batch_idx: int = 0) -> torch.Tensor:
         """model_wrapper.py:107-146: the scalar that is back-propagated (and, under data parallelism, whose gradient
-        bucket is all-reduced: parallel.allreduce_gradients)."""
-        return sum(self.evaluate_losses(batch).values())
+        bucket is all-reduced: parallel.allreduce_gradients).  Lightning brackets every batch with
+        on_train_batch_start / on_train_batch_end (model_wrapper.py:575-581), which drive the proposal-weight anneal and
+        the sampler's update schedule from ``global_step``; without Lightning this method does the bracketing itself
+        (``global_step`` counts optimiser steps: call ``optimizer_stepped()`` -- or set the attribute -- after each one)."""
+        self.on_train_batch_start(batch, batch_idx)
+        loss = sum(self.evaluate_losses(batch).values())
+        self.on_train_batch_end(None, batch, batch_idx)
+        return loss
+
+    def on_train_batch_start(self, batch=None, batch_idx: int = 0) -> None:
+        self.model.step_before_iter(self.global_step)
+
+    def on_train_batch_end(self, outputs=None, batch=None, batch_idx: int = 0) -> None:
+        self.model.step_after_iter(self.global_step)
+
+    def optimizer_stepped(self) -> None:
+        """Lightning increments ``global_step`` per optimiser step; loops without it call this after ``optimizer.step()``."""
+        self.global_step += 1
 
     def configure_optimizers(self, lr: float, warm_up_steps: int):
         """model_wrapper.py:87-105: Adam(weight_decay=1e-5) + linear warm-up."""

@@ -149,6 +149,9 @@ def data_parallel_step(loss_fn, parameters: Sequence[torch.nn.Parameter], optimi
     parameters = list(parameters)
     allreduce_gradients(parameters, average=True)
     optimizer.step()
+    owner = getattr(loss_fn, "__self__", None)   # a bound ModelWrapper.training_step: keep its step counter current
+    if hasattr(owner, "optimizer_stepped"):
+        owner.optimizer_stepped()
     mean = loss.detach().clone().reshape(1)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(mean, op=dist.ReduceOp.SUM)

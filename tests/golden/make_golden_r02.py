@@ -90,10 +90,44 @@ def main():
         rin = ref_model.RenderingInput(origins=c(ro), directions=c(rd), z_near=c(z_near), z_far=c(z_far))
         return cam, rin, ref_model.RobotInput(robot_action=c(action))
 
-    def evaluate(model, action, dtype, fixed_positions=None, with_inference=True):
+    def evaluate(model, action, dtype, fixed_positions=None, with_inference=True, perturb=None):
         """Every output the GPU tests compare, in `dtype`.  `fixed_positions` = (final_positions, prop_positions) of the
-        fp32 run: the per-sample decoder outputs are then evaluated at IDENTICAL sample locations in both precisions."""
+        fp32 run: the per-sample decoder outputs are then evaluated at IDENTICAL sample locations in both precisions.
+        `perturb` = ("ulp", seed): ray origins / directions moved by one ulp at random; ("enc", seed): encoder features
+        scaled by (1 + 1e-5 N(0,1)) -- the agreement MIOpen's convolutions reach with the reference's (test_encoder)."""
         cam, rin, rob = inputs(action, dtype)
+        enc_forward = model.encoder.forward
+        if perturb is not None:
+            gen = torch.Generator().manual_seed(perturb[1])
+            if perturb[0] == "ulp":
+                nudge = lambda t: torch.where(torch.rand(t.shape, generator=gen) < 0.5, torch.nextafter(t, t + 1), torch.nextafter(t, t - 1))
+                rin = ref_model.RenderingInput(origins=nudge(rin.origins), directions=nudge(rin.directions), z_near=rin.z_near, z_far=rin.z_far)
+            else:
+                model.encoder.forward = lambda img: (lambda f: f * (1 + 1e-5 * torch.randn(f.shape, generator=gen)))(enc_forward(img))
+        try:
+            return _evaluate(model, cam, rin, rob, dtype, fixed_positions, with_inference)
+        finally:
+            model.encoder.forward = enc_forward
+
+    def self_noise(model, action, base, keys):
+        """How far the reference's OWN fp32 outputs move under perturbations no fp32 implementation can avoid: one ulp on
+        the rays (sample placement feeds a positional encoding with a 2*pi*512 gain) and 1e-5 on the encoder features."""
+        out = {}
+        for kind, seeds in (("ulp", (1, 2, 3, 4)), ("enc", (5, 6))):
+            runs = [evaluate(model, action, torch.float32, with_inference=False, perturb=(kind, sd)) for sd in seeds]
+            for k in keys:
+                if k in base:
+                    out[f"floor_{kind}.{k}"] = np.float64(max(rel(r[k], base[k]) for r in runs))
+        return out
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+    END_TO_END = ("rgb", "depth", "optical_flow", "prop_weights", "prop_weights0", "prop_weights1", "vis_action_features", "vis_steps",
+                  "vis_weights", "vis_ray_positions", "vis_ray_positions_warped", "final_starts", "final_ends", "prop_starts1")
+
+    def _evaluate(model, cam, rin, rob, dtype, fixed_positions, with_inference):
         out = {}
         with torch.no_grad():
             feats = model.encoder.forward(cam.input_image)
@@ -146,6 +180,10 @@ def main():
                 "dec_action_features", "vis_action_features", "vis_steps", "vis_ray_positions", "vis_ray_positions_warped",
                 "vis_weights", "enc_weights", "encpos_density", "encpos_action_features", "infer_flow", "final_starts", "final_ends"]
         arrays = {k: r64[k] for k in keep if k in r64}
+        arrays.update(self_noise(model, action, r32, END_TO_END))
+        if tag == "mlp":   # enc_weights: per-sample weights at independently placed samples (encode_image)
+            pert = [evaluate(model, action, torch.float32, perturb=("ulp", sd)) for sd in (1, 2)]
+            arrays["floor_ulp.enc_weights"] = np.float64(max(rel(q["enc_weights"], r32["enc_weights"]) for q in pert))
         if tag != "mlp":
             arrays.pop("features", None)  # the encoder is shared: its fp64 output is kept once (model_mlp_f64)
         if tag == "flow":  # the zero-action run of the flow_mlp fixture; its 640 hidden "action features" are read by nothing
@@ -165,6 +203,7 @@ def main():
               "prop_starts1", "prop_ends1", "final_starts", "final_ends", "vis_action_features", "vis_weights"):
         arrays[k] = r32[k]
         arrays[k + "_f64"] = r64[k]
+    arrays.update(self_noise(model, action, r32, END_TO_END))
     save("model_mlp2", **arrays)
 
     # ---- transformer head with all eight key slots ----------------------------------------------------------------------
@@ -178,6 +217,7 @@ def main():
     for k in ("features", "rgb", "depth", "optical_flow", "dec_action_features", "dec_flow", "dec_density", "vis_action_features"):
         arrays[k] = r32[k]
         arrays[k + "_f64"] = r64[k]
+    arrays.update(self_noise(model, action, r32, END_TO_END))
     save("model_transformer8", **arrays)
 
     # ---- Model.patch_render + the Jacobian-field colouring on its output (models/model.py:527-628) ----------------------

@@ -191,6 +191,15 @@ def _gloo_worker(rank, world, port, tmp):
         q.grad = torch.full_like(q, float(rank + 1))
     par.allreduce_gradients(lin.parameters())
     grads_ok = all(torch.allclose(q.grad, torch.full_like(q, (1 + world) / 2)) for q in lin.parameters())
+    # ranks that disagree on which gradients exist (rank 1 has none for the bias; nobody has one for `extra`): same bucket
+    # size everywhere, zeros fill the gaps, a parameter nobody touched keeps grad = None
+    lin2, extra = torch.nn.Linear(5, 3), torch.nn.Parameter(torch.zeros(4))
+    lin2.weight.grad = torch.full_like(lin2.weight, float(rank + 1))
+    lin2.bias.grad = torch.full_like(lin2.bias, 4.0) if rank == 0 else None
+    par.allreduce_gradients([*lin2.parameters(), extra])
+    grads_ok = (grads_ok and torch.allclose(lin2.weight.grad, torch.full_like(lin2.weight, (1 + world) / 2))
+                and lin2.bias.grad is not None and torch.allclose(lin2.bias.grad, torch.full_like(lin2.bias, 4.0 / world))
+                and extra.grad is None)
     # data_parallel_step: two ranks on different halves of a batch == one process on the whole batch
     torch.manual_seed(7)
     net, full = torch.nn.Linear(6, 2), torch.nn.Linear(6, 2)
@@ -397,3 +406,50 @@ def test_static_isa_properties_of_the_fused_kernels():
         assert exact >= 60 and exact > r["lgkm"].get(0, 0), (name, r["lgkm"])   # ... and does not zero the wait counts
     assert rows["void render_kernel<1, 1, 0, false>(RenderArgs)"]["spill"] <= 120
     assert rows["void proposal_kernel<1, false>(ProposalArgs)"]["spill"] <= 16
+
+
+def test_reference_checkpoint_keys_load_strictly():
+    """A reference checkpoint holds `decoder.directional_encoding.tcnn_encoding.params` (tinycudann registers an empty
+    Parameter for the spherical-harmonics encoding, action_decoder_jacobian.py:284); it must load with strict=True, both
+    into Model and -- `model.`-prefixed -- into ModelWrapper, and must not appear in our own state dict."""
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    from neural_jacobian_field_amd.model_wrapper import ModelWrapper
+    for kind, a in (("jacobian_mlp", 8), ("jacobian_transformer", 6), ("flow_mlp", 5)):
+        cfg = model_cfg_from_dict({"action_dim": a, "encoder": {"name": "precomputed"},
+                                   "rendering": {"num_proposal_samples": [8], "num_nerf_samples": 8}, "action_decoder": {"name": kind}})
+        sd = synthetic.seeded_state_dict(synthetic.model_shapes(kind, a, with_encoder=False), seed=0)
+        sd["decoder.directional_encoding.tcnn_encoding.params"] = torch.zeros(0)
+        model = Model(cfg)
+        model.load_state_dict(sd, strict=True)
+        assert "decoder.directional_encoding.tcnn_encoding.params" not in model.state_dict()
+        wrapper = ModelWrapper("perception", 16, Model(cfg))
+        wsd = {"model." + k: v for k, v in sd.items()}
+        wsd["depth_sigma"] = torch.tensor([0.001])
+        wrapper.load_state_dict(wsd, strict=True)
+        bad = dict(sd)
+        bad["decoder.directional_encoding.tcnn_encoding.params"] = torch.zeros(3)   # a NON-empty stray tensor is still an error
+        with pytest.raises(RuntimeError):
+            Model(cfg).load_state_dict(bad, strict=True)
+
+
+def test_training_step_drives_the_sampler_schedule():
+    """ModelWrapper.training_step brackets the forward with step_before_iter / step_after_iter (the reference's
+    on_train_batch_start / on_train_batch_end, model_wrapper.py:575-581): the proposal-weight anneal follows global_step."""
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    from neural_jacobian_field_amd.model_wrapper import ModelWrapper
+    cfg = model_cfg_from_dict({"action_dim": 8, "encoder": {"name": "precomputed"},
+                               "rendering": {"num_proposal_samples": [8], "num_nerf_samples": 8}})
+    wrapper = ModelWrapper("perception", 16, Model(cfg))
+    seen = []
+    wrapper.evaluate_losses = lambda batch: (seen.append((wrapper.model.proposal_sampler._anneal, wrapper.model.proposal_sampler._step)),
+                                             {"l": torch.zeros(())})[1]
+    for _ in range(3):
+        wrapper.training_step({})
+        wrapper.optimizer_stepped()
+        wrapper.global_step += 499     # jump ahead: 500 optimiser steps per call
+    anneals = [a for a, _ in seen]
+    assert anneals[0] == 0.0 and 0.0 < anneals[1] < anneals[2] == 1.0     # frac = step / 1000 -> 0, 0.5, 1.0
+    assert wrapper.model.proposal_sampler._step == 1000 and wrapper.model.proposal_sampler._steps_since_update >= 1

@@ -48,40 +48,65 @@ def test_encoder_matches_reference(model_and_golden, margins):
     margins("model_mlp.encoder", "features", model.encoder(g["image"]), g["features"], g["features_f64"], tol=1e-5)  # MIOpen vs CPU
 
 
-def _check_forward(margins, case, out, g, vis=True):
-    """Model.forward's outputs against the reference's fp32 golden; every bound is max(1e-4, 2 x |ref32 - ref64|)."""
+def _noise(g, key, encoder):
+    """The reference's own fp32 movement of output `key` under a one-ulp ray perturbation (+ a 1e-5 feature perturbation when
+    the comparison runs through the MIOpen encoder); scalars stored next to the float64 golden."""
+    kinds = ("floor_ulp", "floor_enc") if encoder else ("floor_ulp",)
+    return [g[f"{k}.{key}_f64"].item() if f"{k}.{key}_f64" in g else g[f"{k}.{key}"].item() for k in kinds
+            if f"{k}.{key}_f64" in g or f"{k}.{key}" in g]
+
+
+def _check_forward(margins, case, out, g, vis=True, encoder=True):
+    """Model.forward's outputs against the reference's fp32 golden.  Bound per output: max(1e-4, 2 x floor), floor = the
+    largest of |ref32 - ref64| and the reference's own movement under unavoidable input perturbations (`_noise`)."""
     so = out.standard_output
-    margins(case, "rgb", so.rgb, g["rgb"], g["rgb_f64"])
-    margins(case, "depth", so.depth, g["depth"], g["depth_f64"])
-    margins(case, "optical_flow", so.optical_flow, g["optical_flow"], g["optical_flow_f64"])
+    m = lambda key, name, got: margins(case, key, got, g[name], g[name + "_f64"], self_noise=_noise(g, name, encoder))
+    m("rgb", "rgb", so.rgb)
+    m("depth", "depth", so.depth)
+    m("optical_flow", "optical_flow", so.optical_flow)
     if vis:
         vo = out.vis_output
-        margins(case, "vis.steps", vo.steps, g["vis_steps"], g["vis_steps_f64"])
-        margins(case, "vis.ray_positions", vo.ray_positions, g["vis_ray_positions"], g["vis_ray_positions_f64"])
-        margins(case, "vis.ray_positions_warped", vo.ray_positions_warped, g["vis_ray_positions_warped"], g["vis_ray_positions_warped_f64"])
-        margins(case, "vis.action_features", vo.action_features, g["vis_action_features"], g["vis_action_features_f64"])
-        margins(case, "vis.weights", vo.weights, g["vis_weights"], g["vis_weights_f64"])
+        m("vis.steps", "vis_steps", vo.steps)
+        m("vis.ray_positions", "vis_ray_positions", vo.ray_positions)
+        m("vis.ray_positions_warped", "vis_ray_positions_warped", vo.ray_positions_warped)
+        m("vis.action_features", "vis_action_features", vo.action_features)
+        m("vis.weights", "vis_weights", vo.weights)
+
+
+def _from_reference_features(model, g):
+    """Context manager: Model.forward on the REFERENCE's encoder output (isolates the rendering path from MIOpen)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def scope():
+        original = model._encode_for_render
+        model._encode_for_render = lambda image: g["features"]
+        try:
+            yield
+        finally:
+            model._encode_for_render = original
+    return scope()
 
 
 def test_model_forward_vs_reference_golden(model_and_golden, margins):
-    """End to end through the encoder; batch element 1 has a general context pose.  The bound of every output is
-    max(1e-4, 2 x the reference's own fp32-vs-fp64 difference of that output) (tests/golden/model_mlp_f64.npz)."""
+    """End to end through the MIOpen encoder; batch element 1 has a general context pose."""
     model, g = model_and_golden
     out = model.forward(*_inputs(g), compute_vis_features=True)
-    _check_forward(margins, "model_mlp.forward", out, g)
+    _check_forward(margins, "model_mlp.forward[through encoder]", out, g)
     assert out.training_output is None
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16f6"])
-def test_model_forward_other_precisions_vs_reference_golden(model_and_golden, margins, precision):
-    """The same golden, the same bounds, for the exact-fp32 MFMA path and the fp6-corrected final pass."""
+@pytest.mark.parametrize("precision", ["f32", "f16x2", "f16f6"])
+def test_model_forward_from_reference_features(model_and_golden, margins, precision):
+    """The rendering path alone (the reference's encoder output is fed in), in every MFMA precision, same bounds."""
     model, g = model_and_golden
     model.set_precision(precision)
     try:
-        out = model.forward(*_inputs(g), compute_vis_features=True)
+        with _from_reference_features(model, g):
+            out = model.forward(*_inputs(g), compute_vis_features=True)
     finally:
         model.set_precision("f16x2")
-    _check_forward(margins, f"model_mlp.forward[{precision}]", out, g)
+    _check_forward(margins, f"model_mlp.forward[{precision}]", out, g, encoder=False)
 
 
 def test_decoder_forward_at_reference_sample_locations(model_and_golden, margins):
@@ -131,7 +156,8 @@ def test_encode_image_and_infer_optical_flow(model_and_golden, margins):
     enc = model.encode_image(cam, rin, rob)
     assert enc.density.shape == g["enc_density"].shape and enc.action_features.shape == g["enc_action_features"].shape
     # per-sample weights at INDEPENDENTLY placed samples: the floor is the reference's own fp32-vs-fp64 run
-    margins("model_mlp.encode_image", "weights", enc.weights, g["enc_weights"], g["enc_weights_f64"])
+    margins("model_mlp.encode_image", "weights", enc.weights, g["enc_weights"], g["enc_weights_f64"],
+            self_noise=[g["floor_ulp.enc_weights_f64"].item(), g["floor_enc.vis_weights_f64"].item()])
     # infer_optical_flow on the REFERENCE's cached encoding: pure compositing + projection
     ref_enc = ModelInferenceEncoding(g["enc_density"], g["enc_action_features"], g["enc_weights"], g["enc_positions"])
     action = (g["action"] * 2 + 0.05).requires_grad_(True)
@@ -233,7 +259,8 @@ def test_generic_sampler_route_equals_fused_route(model_and_golden, margins):
                                                                     g["z_far"], True)
     assert rel(wl[0], wl2[0]) < 1e-5
     assert rel(smp.spacing_bins(), bins) < 1e-5
-    margins("model_mlp.compute_proposal", "prop_weights", wl[0], g["prop_weights"], g["prop_weights_f64"])
+    margins("model_mlp.compute_proposal", "prop_weights", wl[0], g["prop_weights"], g["prop_weights_f64"],
+            self_noise=_noise(g, "prop_weights", False))
 
 
 # ---- jacobian_transformer decoder (default Allegro head; fixture uses A=6 -> exercises key masking) ----
@@ -276,7 +303,10 @@ def test_transformer_decoder_at_reference_sample_locations(transformer_model_and
 def test_transformer_model_forward_vs_reference_golden(transformer_model_and_golden, margins):
     model, g = transformer_model_and_golden
     out = model.forward(*_inputs(g), compute_vis_features=True)
-    _check_forward(margins, "model_transformer.forward", out, g)
+    _check_forward(margins, "model_transformer.forward[through encoder]", out, g)
+    with _from_reference_features(model, g):
+        out = model.forward(*_inputs(g), compute_vis_features=True)
+    _check_forward(margins, "model_transformer.forward", out, g, encoder=False)
 
 
 def test_transformer_head_with_eight_keys(dev, golden, margins):
@@ -299,12 +329,12 @@ def test_transformer_head_with_eight_keys(dev, golden, margins):
     margins(c, "action_features", dec.action_features, g["dec_action_features"], g["dec_action_features_f64"])
     margins(c, "flow", dec.flow, g["dec_flow"], g["dec_flow_f64"])
     margins(c, "density", dec.density, g["dec_density"], g["dec_density_f64"])
-    out = model.forward(*_inputs(g), compute_vis_features=True)
+    with _from_reference_features(model, g):
+        out = model.forward(*_inputs(g), compute_vis_features=True)
     c = "model_transformer8.forward"
-    margins(c, "rgb", out.standard_output.rgb, g["rgb"], g["rgb_f64"])
-    margins(c, "depth", out.standard_output.depth, g["depth"], g["depth_f64"])
-    margins(c, "optical_flow", out.standard_output.optical_flow, g["optical_flow"], g["optical_flow_f64"])
-    margins(c, "vis.action_features", out.vis_output.action_features, g["vis_action_features"], g["vis_action_features_f64"])
+    for key, got in (("rgb", out.standard_output.rgb), ("depth", out.standard_output.depth),
+                     ("optical_flow", out.standard_output.optical_flow), ("vis_action_features", out.vis_output.action_features)):
+        margins(c, key, got, g[key], g[key + "_f64"], self_noise=_noise(g, key, False))
 
 
 def test_two_proposal_levels_vs_reference_golden(dev, golden, margins):
@@ -322,12 +352,13 @@ def test_two_proposal_levels_vs_reference_golden(dev, golden, margins):
                           strict=True)
     model.to(dev).eval().requires_grad_(False)
     cam, rin, rob = _inputs(g)
-    out = model.forward(cam, rin, rob, compute_vis_features=True)
+    with _from_reference_features(model, g):
+        out = model.forward(cam, rin, rob, compute_vis_features=True)
     c = "model_mlp2.forward"
     for key, got in (("rgb", out.standard_output.rgb), ("depth", out.standard_output.depth),
                      ("optical_flow", out.standard_output.optical_flow), ("vis_action_features", out.vis_output.action_features),
                      ("vis_weights", out.vis_output.weights)):
-        margins(c, key, got, g[key], g[key + "_f64"])
+        margins(c, key, got, g[key], g[key + "_f64"], self_noise=_noise(g, key, False))
     # per level: weights and sample placement, fused route
     enc = PixelEncoding(g["features"], g["ctxt_c2w"], g["ctxt_k_norm"], g["action"])
     rb = model.compute_ray_bundle(rin)
@@ -336,17 +367,18 @@ def test_two_proposal_levels_vs_reference_golden(dev, golden, margins):
     assert len(wl) == 2 and wl[0].shape == g["prop_weights0"].shape and wl[1].shape == g["prop_weights1"].shape
     smp = [rb.samples_from_bins(b) for b in bl] + [rb.samples_from_bins(bins)]
     c = "model_mlp2.levels[fused]"
-    margins(c, "weights0", wl[0], g["prop_weights0"], g["prop_weights0_f64"])
-    margins(c, "weights1", wl[1], g["prop_weights1"], g["prop_weights1_f64"])
-    margins(c, "starts1", smp[1].starts, g["prop_starts1"], g["prop_starts1_f64"])
-    margins(c, "final_starts", smp[2].starts, g["final_starts"], g["final_starts_f64"])
-    margins(c, "final_ends", smp[2].ends, g["final_ends"], g["final_ends_f64"])
+    n = lambda k: _noise(g, k, False)
+    margins(c, "weights0", wl[0], g["prop_weights0"], g["prop_weights0_f64"], self_noise=n("prop_weights0"))
+    margins(c, "weights1", wl[1], g["prop_weights1"], g["prop_weights1_f64"], self_noise=n("prop_weights1"))
+    margins(c, "starts1", smp[1].starts, g["prop_starts1"], g["prop_starts1_f64"], self_noise=n("prop_starts1"))
+    margins(c, "final_starts", smp[2].starts, g["final_starts"], g["final_starts_f64"], self_noise=n("final_starts"))
+    margins(c, "final_ends", smp[2].ends, g["final_ends"], g["final_ends_f64"], self_noise=n("final_ends"))
     # generic route (reference API: density_fns callbacks)
     s_fin, pos, dirs, wl2, sl2 = model.compute_proposal(rb, enc)
     c = "model_mlp2.levels[generic]"
-    margins(c, "weights0", wl2[0], g["prop_weights0"], g["prop_weights0_f64"])
-    margins(c, "weights1", wl2[1], g["prop_weights1"], g["prop_weights1_f64"])
-    margins(c, "final_starts", s_fin.starts, g["final_starts"], g["final_starts_f64"])
+    margins(c, "weights0", wl2[0], g["prop_weights0"], g["prop_weights0_f64"], self_noise=n("prop_weights0"))
+    margins(c, "weights1", wl2[1], g["prop_weights1"], g["prop_weights1_f64"], self_noise=n("prop_weights1"))
+    margins(c, "final_starts", s_fin.starts, g["final_starts"], g["final_starts_f64"], self_noise=n("final_starts"))
 
 
 # ---- flow_mlp decoder (the reference's direct-flow ablation, models/decoder/action_decoder_flow.py) ----
@@ -389,11 +421,11 @@ def test_flow_mlp_model_forward_vs_reference_golden(flow_model_and_golden, margi
     model, g = flow_model_and_golden
     cam, rin, rob = _inputs(g)
     out = model.forward(cam, rin, rob)
-    _check_forward(margins, "model_flow.forward", out, g, vis=False)
+    _check_forward(margins, "model_flow.forward[through encoder]", out, g, vis=False)
     # a different action on the same image: the hoisted map's feature part is cached, its action bias is not
     out0 = model.forward(cam, rin, RobotInput(torch.zeros_like(g["action"])))
     margins("model_flow.forward[zero action]", "optical_flow", out0.standard_output.optical_flow, g["optical_flow_zero_action"],
-            g["optical_flow_zero_action_f64"])
+            g["optical_flow_zero_action_f64"], self_noise=_noise(g, "optical_flow", True))
     assert rel(out0.standard_output.optical_flow, g["optical_flow"]) > 1e-2   # and the two really differ
     with pytest.raises(NotImplementedError):
         model.encode_image(cam, rin, rob)
@@ -479,3 +511,34 @@ def test_solve_action_kernel_matches_the_tensor_restatement(dev):
             assert torch.equal(got, solve_action(lin, target, **kwargs))
         if 2 * r >= a:
             assert rel(lin.optical_flow(solve_action(lin, target)), target) < 1e-3
+
+
+def test_fp16_range_guard_falls_back_to_f32(model_and_golden):
+    """The split-precision modes hold the leading bits of every operand in fp16: a checkpoint whose hidden activations
+    exceed 65,504 must be detected and moved to the exact-fp32 MFMA path by calibrate_precision (measured on the fp32
+    path's activation dumps -- the kernels' integer ReLU can hide the NaNs an overflow produces); a normal checkpoint
+    keeps its precision."""
+    import copy
+    import warnings
+    model, g = model_and_golden
+    cam, rin, rob = _inputs(g)
+    ranges = model.activation_range(cam, rin, rob)
+    assert {"density_head", "jacobian_head", "color_head", "proposal_networks.0", "positional_encoding", "weights"} <= set(ranges)
+    assert all(0 < v < 1000 for v in ranges.values()), ranges
+    for prec in ("f16x2", "f16f6"):
+        model.set_precision(prec)
+        assert model.calibrate_precision(cam, rin, rob) == prec and model.decoder.precision == prec
+    for head in ("density_head", "jacobian_head"):
+        big = copy.deepcopy(model)
+        with torch.no_grad():   # blow up the first hidden layer of one head: activations ~1e6
+            getattr(big.decoder, head).lin_in.weight.mul_(3.0e5)
+            getattr(big.decoder, head).lin_in.bias.mul_(3.0e5)
+        for prec in ("f16x2", "f16f6"):
+            big.set_precision(prec)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                assert big.calibrate_precision(cam, rin, rob) == "f32"
+            assert any("fp16's range" in str(w.message) and head in str(w.message) for w in caught), [str(w.message) for w in caught]
+            out = big.forward(cam, rin, rob).standard_output
+            assert torch.isfinite(out.rgb).all() and big.decoder.precision == "f32"
+    model.set_precision("f16x2")
