@@ -160,17 +160,17 @@ class Model(nn.Module):
         * ``"f16f6"`` the same hi*hi, the two 2^-11-sized correction products in block-scaled fp6 -- half the matrix time
           of f16x2 at ~1.5e-5 relative error per network.
 
-        ``precision`` applies to the density and colour networks of the final pass.  ``proposal_precision`` (proposal
-        networks) and ``jacobian_precision`` (Jacobian / flow head) default to it -- except under ``"f16f6"``, where both
-        default to ``"f16x2"``: sample PLACEMENT feeds a positional encoding with a 2*pi*512 gain (1e-5 in the proposal
-        weights becomes 3e-4 in depth / flow), and the optical flow is a small difference of two projections in which the
-        head's 1.5e-5 shows up amplified (2e-4 on a two-level fixture, against 2e-5 for rgb and 6e-5 for depth from the
-        density / colour side).  Measured: tools/prec_eval.py, profiles/r02_parity_margins.json, DESIGN.md section 5."""
+        ``precision`` applies to the networks of the final pass (density, colour, Jacobian / flow head; the head can be
+        given its own split precision through ``jacobian_precision``).  ``proposal_precision`` applies to the proposal
+        networks and defaults to ``precision`` -- except under ``"f16f6"``, where the proposal networks stay on
+        ``"f16x2"``: sample PLACEMENT feeds a positional encoding with a 2*pi*512 gain, so an error of 1e-5 in the proposal
+        weights shows up as 3e-4 in depth / flow, while the same error inside the final pass (at given sample locations)
+        stays 1e-5 (measured: tools/prec_eval.py, tools/prec_mix_eval.py)."""
         hip.precision_code(precision)
         if proposal_precision is None:
             proposal_precision = hip.proposal_precision_for(precision)
         if jacobian_precision is None:
-            jacobian_precision = hip.proposal_precision_for(precision)
+            jacobian_precision = precision
         hip.precision_code(proposal_precision)
         hip.precision_code(precision, jacobian_precision)
         self.decoder.precision = precision
