@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 11
+#define NJF_ABI_VERSION 12
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -283,6 +283,20 @@ int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ra
  * ATen's grid_sampler_2d_backward on a GPU). */
 int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels, int texels,
                           int run_length, float* out, void* stream);
+
+/* The whole data-gradient chain of one ResnetFC's backward pass in one launch: what autograd runs as 11 x (GEMM with the
+ * transposed weight + ReLU mask + residual add) for model_components/resnet_fc.py:69-79,130-154.  `w_backward`
+ * [NJF_RESNET_BACKWARD_CHUNKS * NJF_CHUNK_FLOATS] comes from njf_pack_resnetfc_backward (transposed weights, re-packed
+ * after every optimiser step); `activations` [11,P,128] are the ReLU'd layer inputs the training forward dumped
+ * (NjfActivationDump.act / NjfRenderOutputs.jac_act / den_act); `d_out` [P,d_out_dim] is the gradient w.r.t. lin_out's
+ * output.  Writes `deltas` [11,P,128]: deltas[l+1] is the gradient w.r.t. the OUTPUT of the layer whose input is
+ * activations[l] (l = 0..9), so that layer's weight gradient is deltas[l+1]^T activations[l] and its bias gradient the
+ * column sum of deltas[l+1]; deltas[0], deltas[2], deltas[4] are the gradients w.r.t. the three hoisted latents
+ * (lin_z outputs) and deltas[0] also w.r.t. lin_in's output.  Exact-fp32 MFMA. */
+#define NJF_RESNET_BACKWARD_CHUNKS 21
+int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, void* stream);
+int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward, int points,
+                          float* deltas, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

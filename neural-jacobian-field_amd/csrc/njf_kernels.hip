@@ -68,7 +68,7 @@ struct PackLayer {
   const float* b;  // [d_out] or NULL
   int d_out, d_in;
   int mb, kb;  // output / input 32-blocks
-  int kind;    // 0 plain, 1 lin_in (PE slots + bias column), 2 colour layer 0 (geo|1|sh slots)
+  int kind;    // 0 plain, 1 lin_in (PE slots + bias column), 2 colour layer 0 (geo|1|sh slots), 3 transposed (backward chain)
   int prec;    // NJF_PRECISION_*
   float* dst;  // kb*4*mb*256 floats (same byte count in both precisions)
   float* bdst;  // 32*mb floats (logical order, zero padded) or NULL
@@ -88,6 +88,7 @@ __device__ __forceinline__ float pack_source(const PackLayer& L, int f, int k) {
     else ch = -1;
     return ch >= 0 ? L.w[f * L.d_in + ch] : L.b[f];
   }
+  if (L.kind == 3) return k < L.d_in ? L.w[k * L.d_out + f] : 0.f;  // transposed layer: row f of W^T, W stored [d_in, d_out]
   // slots: [geo 0..14 | bias || sh 0..15]
   if (k < 15) return L.w[f * L.d_in + k];
   if (k == 15) return L.b[f];
@@ -1654,6 +1655,126 @@ extern "C" int njf_relu_backward(const float* upstream, const float* act, const 
 }
 
 // =============================================================================================
+// backward data-gradient chain of one ResnetFC (training)
+// =============================================================================================
+// The reverse of resnet_tile: delta^T = W^T * upstream^T layer by layer, with the weights (transposed, packed once per
+// weight update by njf_pack_resnetfc_backward) as the MFMA A operand streamed through LDS exactly like the forward pass
+// and the gradient kept in the accumulator registers across all 11 layers of the net (model_components/resnet_fc.py:
+// 69-79, 130-154 differentiated).  Per layer the wave reads the ReLU'd layer input the forward pass dumped (the ReLU
+// mask) and writes the gradient the weight-gradient GEMM of that layer contracts with:
+//   deltas[10]      = [act[10] > 0] * (W_out^T d_out)                       gradient w.r.t. h after block 4
+//   deltas[2b + 1]  = [act[2b+1] > 0] * (W_fc1,b^T deltas[2b + 2])          gradient w.r.t. fc_0's output of block b
+//   deltas[2b]      = deltas[2b + 2] + [act[2b] > 0] * (W_fc0,b^T deltas[2b + 1])   gradient w.r.t. h before block b
+// (for b = 4 read deltas[10] where the formulas say deltas[2b + 2]).  Hence dW of the layer whose input is act[l] is
+// deltas[l + 1]^T act[l] for l = 0..9, its bias gradient the column sum of deltas[l + 1], and deltas[2b] (b < 3) / deltas[0]
+// are the gradients w.r.t. the hoisted latents / the lin_in output.  Exact-fp32 MFMA: gradients span many orders of
+// magnitude (the split-precision forms are only exact inside fp16's range), and the work is small (0.33 MFLOP/point).
+struct BackwardArgs {
+  const float* d_out;   // [P, d_out_dim]
+  int d_out_dim;
+  const float* act;     // [11, P, 128]
+  const float* w_pack;  // 21 chunks: lin_out^T | (fc_1^T, fc_0^T) of blocks 4..0
+  int points;
+  float* deltas;        // [11, P, 128]
+};
+
+// acc = [act > 0] * acc (+ base), written to `dst`; act / dst address this lane's 64 features of its point
+template <bool ADD>
+__device__ __forceinline__ void mask_store(const float* __restrict__ act, float* __restrict__ dst, bool ok, f32x16 (&acc)[4],
+                                           const f32x16 (&base)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (ok) a = *(const f32x4*)(act + 16 * m + 4 * q);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = a[e] > 0.f ? acc[m][4 * q + e] : 0.f;
+        if (ADD) v += base[m][4 * q + e];
+        acc[m][4 * q + e] = v;
+        o[e] = v;
+      }
+      if (ok) *(f32x4*)(dst + 16 * m + 4 * q) = o;
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(BackwardArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int tile = blockIdx.x * NJF_WAVES + wave;
+  const int p = tile * 32 + j;
+  const bool ok = p < a.points;
+  const size_t pc = (size_t)min(p, a.points - 1);
+  const size_t layer = (size_t)a.points * 128;
+  const float* act = a.act + pc * 128 + 64 * hh;
+  float* out = a.deltas + pc * 128 + 64 * hh;
+  WeightStream st;
+  stream_begin(st, a.w_pack, 21, 1, wave, lane);
+  f32x16 din[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = 16 * hh + r;
+    din[0][r] = (ok && d < a.d_out_dim) ? a.d_out[pc * a.d_out_dim + d] : 0.f;
+  }
+  f32x16 delta[4], t[4], u[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) delta[m] = (f32x16)(0.f);
+  {
+    const float* wl = stream_step(st, wave, lane);
+    mma_chunk<PREC, 4, 1, 0, false, 1>(st, wl, lane, din, delta);   // lin_out^T (first half of the chunk)
+  }
+  mask_store<false>(act + 10 * layer, out + 10 * layer, ok, delta, delta);
+  for (int blk = 4; blk >= 0; --blk) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t[m] = (f32x16)(0.f);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 0, false, 4>(st, wl, lane, delta, t);
+    }
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, delta, t);
+    }
+    mask_store<false>(act + (size_t)(2 * blk + 1) * layer, out + (size_t)(2 * blk + 1) * layer, ok, t, t);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) u[m] = (f32x16)(0.f);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 0, false, 4>(st, wl, lane, t, u);
+    }
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, t, u);
+    }
+    mask_store<true>(act + (size_t)(2 * blk) * layer, out + (size_t)(2 * blk) * layer, ok, u, delta);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) delta[m] = u[m];
+  }
+}
+
+extern "C" int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, void* stream) {
+  if (!src || !w_out) return NJF_E_NULL;
+  if (src->d_out < 1 || src->d_out > 32) return NJF_E_DOUT;
+  if (!src->lin_out_w) return NJF_E_NULL;
+  for (int i = 0; i < 5; ++i)
+    if (!src->fc0_w[i] || !src->fc1_w[i]) return NJF_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = NJF_PRECISION_F32;
+  // chunk 0: lin_out^T  [128 x d_out -> 32], half a chunk; the other half is never read but is moved by the DMA
+  launch_pack(src->lin_out_w, nullptr, 128, src->d_out, 4, 1, 3, P, w_out, nullptr, s);
+  fill_kernel<<<16, 256, 0, s>>>(w_out + 4096, 4096, 0.f);
+  for (int blk = 4, c = 1; blk >= 0; --blk, c += 4) {
+    launch_pack(src->fc1_w[blk], nullptr, 128, 128, 4, 4, 3, P, w_out + (size_t)c * NJF_CHUNK_FLOATS, nullptr, s);
+    launch_pack(src->fc0_w[blk], nullptr, 128, 128, 4, 4, 3, P, w_out + (size_t)(c + 2) * NJF_CHUNK_FLOATS, nullptr, s);
+  }
+  return launch_status();
+}
+
+// =============================================================================================
 // stand-alone sampler ops
 // =============================================================================================
 __global__ void __launch_bounds__(256) alpha_weights_kernel(const float* __restrict__ deltas,
@@ -1969,4 +2090,13 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
     if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, NJF_P, NJF_PJ>, a, tiles, s);
     return launch_fused(points_kernel<3, NJF_P, NJF_PJ>, a, tiles, s);
   });
+}
+
+extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward,
+                                     int points, float* deltas, void* stream) {
+  if (!d_out || !activations || !w_backward || !deltas) return NJF_E_NULL;
+  if (points < 1 || (long long)points * 11 * 128 > 0x7fffffffffLL) return NJF_E_SHAPE;
+  if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
+  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas};
+  return launch_fused(resnetfc_backward_kernel<PREC_F32>, a, (points + 31) / 32, (hipStream_t)stream);
 }

@@ -270,21 +270,34 @@ class ActionDecoderJacobian(ActionDecoder):
         raise NotImplementedError
 
     def packed(self):
+        """Packed weights, rebuilt PER SUB-NETWORK: an action-mode optimiser step only touches the Jacobian head
+        (freeze_non_action_parameters), so the density and colour packs of the previous step stay valid."""
         v = _version(self)
         if v != self._packed_version:
             dev = self.density_head.lin_in.weight.device
-            f32 = dict(dtype=torch.float32, device=dev)
             n = hip.RESNET_W_FLOATS
-            self._w = torch.zeros(n + hip.COLOR_W_FLOATS + self.J_W_FLOATS, **f32)
-            self._bd = torch.empty(hip.RESNET_B_FLOATS, **f32)
-            self._bc = torch.empty(hip.COLOR_B_FLOATS, **f32)
-            self._bj = torch.zeros(self.J_B_FLOATS, **f32)
-            self._wz = torch.zeros(512, hip.ZDIM + self.J_HOIST, **f32)
-            self._bz = torch.zeros(hip.ZDIM + self.J_HOIST, **f32)
+            fresh = self._packed_version is None or self._w.device != dev
+            if fresh:
+                f32 = dict(dtype=torch.float32, device=dev)
+                self._w = torch.zeros(n + hip.COLOR_W_FLOATS + self.J_W_FLOATS, **f32)
+                self._bd = torch.empty(hip.RESNET_B_FLOATS, **f32)
+                self._bc = torch.empty(hip.COLOR_B_FLOATS, **f32)
+                self._bj = torch.zeros(self.J_B_FLOATS, **f32)
+                self._wz = torch.zeros(512, hip.ZDIM + self.J_HOIST, **f32)
+                self._bz = torch.zeros(hip.ZDIM + self.J_HOIST, **f32)
+                self._sub_versions = {}
             params = {k: p for k, p in self.named_parameters()}
-            hip.pack_resnetfc(params, "density_head.", self._w[:n], self._bd, self._wz, 0, self._bz, precision=self.precision)
-            hip.pack_color_head(params, "color_head.", self._w[n:n + hip.COLOR_W_FLOATS], self._bc, precision=self.precision)
-            self._pack_jacobian(params, self._w[n + hip.COLOR_W_FLOATS:], self._bj, self._wz, self._bz)
+            heads = ("density_head.", "color_head.")
+            subs = {"density": (self.precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(heads[0])),
+                    "color": (self.precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(heads[1])),
+                    "jacobian": (self.j_precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if not k.startswith(heads))}
+            if subs["density"] != self._sub_versions.get("density"):
+                hip.pack_resnetfc(params, heads[0], self._w[:n], self._bd, self._wz, 0, self._bz, precision=self.precision)
+            if subs["color"] != self._sub_versions.get("color"):
+                hip.pack_color_head(params, heads[1], self._w[n:n + hip.COLOR_W_FLOATS], self._bc, precision=self.precision)
+            if subs["jacobian"] != self._sub_versions.get("jacobian"):
+                self._pack_jacobian(params, self._w[n + hip.COLOR_W_FLOATS:], self._bj, self._wz, self._bz)
+            self._sub_versions = subs
             self._packed_version = v
         return self._w, self._bd, self._bc, self._bj
 

@@ -123,6 +123,8 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), C.c_int, _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
+    "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, _vp], C.c_int),
+    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
@@ -487,6 +489,34 @@ def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
         raise ValueError("njf_hip: scatter_footprint shape mismatch")
     _launch("njf_scatter_footprint", load_library().njf_scatter_footprint, _ptr(grad, "grad"), _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels,
                                                 out.shape[0], int(run_length), _ptr(out, "out"))
+
+
+RESNET_BACKWARD_W_FLOATS = 21 * 8192
+
+
+def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor) -> None:
+    """Transposed weights of one ResnetFC in the chunk order njf_resnetfc_backward streams them (include/njf_hip.h)."""
+    def p(name):
+        return _ptr(params[prefix + name].detach().contiguous(), prefix + name)
+
+    src = ResnetFcWeights()
+    for i in range(5):
+        src.fc0_w[i], src.fc1_w[i] = p(f"blocks.{i}.fc_0.weight"), p(f"blocks.{i}.fc_1.weight")
+    src.lin_out_w = p("lin_out.weight")
+    src.d_out = params[prefix + "lin_out.weight"].shape[0]
+    _launch("njf_pack_resnetfc_backward", load_library().njf_pack_resnetfc_backward, C.byref(src), _ptr(w_out, "w_out"))
+
+
+def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor) -> torch.Tensor:
+    """deltas [11,P,128] of one ResnetFC's backward pass (include/njf_hip.h: njf_resnetfc_backward): d_out [P,d_out],
+    act [11,P,128] (dumped ReLU'd layer inputs), w_backward from pack_resnetfc_backward."""
+    points = d_out.shape[0]
+    if tuple(act.shape) != (11, points, 128) or w_backward.numel() != RESNET_BACKWARD_W_FLOATS:
+        raise ValueError("njf_hip: resnetfc_backward shape mismatch")
+    deltas = torch.empty_like(act)
+    _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out.contiguous(), "d_out"), d_out.shape[1],
+            _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"))
+    return deltas
 
 
 RELU_BACKWARD_ROWS = 512  # rows per workgroup of njf_relu_backward (one partial column-sum row each)

@@ -6,12 +6,12 @@ weights and sample placement are constants of the backward pass (SURVEY.md secti
 
 Forward: the fused HIP kernels, with the final pass additionally dumping the ReLU'd input of every layer of the
 Jacobian ``ResnetFC`` (``njf_render_forward`` with ``jac_act``/``jac_pe``/``foot_*`` outputs).
-Backward (round-1 form): the layer-by-layer chain on the dumped ``[P,128]`` matrices as plain library GEMMs
-(rocBLAS through ``torch.matmul``) plus ReLU masks -- exact, tested against autograd of the CPU oracle; the texel
-scatter of the ``lin_z`` / feature gradients (grid_sample's input gradient) is the HIP kernel ``njf_scatter_footprint``.
-The weight gradients are sums over ALL points of outer products, i.e. GEMMs with K = points: they stay library calls on
-the dumped matrices (a per-workgroup accumulation would need 11 x 64 KB of partial sums per tile); fusing the
-data-gradient chain between them into a HIP kernel is the remaining step of SURVEY.md section 8f #2.  The ``jacobian_transformer`` head is
+Backward: the data-gradient chain of each ``ResnetFC`` (11 transposed-weight products with ReLU masks and residual adds)
+is ONE fused HIP launch, ``njf_resnetfc_backward``, that keeps the gradient in MFMA accumulators and emits per layer the
+matrix its weight gradient contracts with -- tested against the GEMM-by-GEMM form and against autograd of the CPU oracle;
+the texel scatter of the ``lin_z`` / feature gradients (grid_sample's input gradient) is ``njf_scatter_footprint``.
+The weight gradients are sums over ALL points of outer products, i.e. GEMMs with K = points: ONE batched library GEMM on
+the emitted matrices (a per-workgroup accumulation would need 11 x 64 KB of partial sums per tile).  The ``jacobian_transformer`` head is
 differentiated by recomputing it (original parameterisation, library ops) on the dumped encoding + footprint.
 Perception mode (every parameter trains; rgb / depth / per-level weights carry the graph) is ``FieldFunction``.
 """
@@ -59,6 +59,30 @@ def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.bmm(a.reshape(groups, k // groups, -1).transpose(1, 2), b.reshape(groups, k // groups, -1)).sum(0)
 
 
+_LAYER_NAMES = [f"blocks.{l // 2}.fc_{l % 2}" for l in range(10)]   # the layer whose ReLU'd input is act[l]
+
+
+def _tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a[l]^T b[l] for every layer l at once (a, b [L,K,128], K = points): ONE batched GEMM for all weight gradients of a
+    ResnetFC.  K is split into groups like `_tn` (the [128,128] outputs are single macro-tiles: without the split each
+    product would serialise its K loop on one workgroup) and the partial products are summed."""
+    layers, k, n = a.shape
+    groups = 64
+    while groups > 1 and (k % groups or k // groups < 256):
+        groups //= 2
+    out = torch.bmm(a.reshape(layers * groups, k // groups, n).transpose(1, 2), b.reshape(layers * groups, k // groups, -1))
+    return out.reshape(layers, groups, n, -1).sum(1)
+
+
+def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    """The data-gradient chain of one ResnetFC as ONE fused launch (njf_resnetfc_backward): deltas [11,P,128], see
+    include/njf_hip.h for the meaning of each slice.  The transposed weights are packed per call (eleven small launches:
+    the weights change with every optimiser step)."""
+    w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
+    hip.pack_resnetfc_backward(p, "", w_t)
+    return hip.resnetfc_backward(d_out, act, w_t)
+
+
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
                       foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
                       d_feats: torch.Tensor = None, samples_per_ray: int = 1) -> Dict[str, torch.Tensor]:
@@ -68,34 +92,48 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     ``pe`` [P,64] (slot order), ``foot_idx``/``foot_w`` [P,4] bilinear footprint on the flattened texel grid,
     ``feats_flat`` [T,512] encoder features, channels last.  Returns the parameter gradients; when ``d_feats`` [T,512]
     is given, the gradient w.r.t. the encoder features is accumulated into it (grid_sample's input gradient followed
-    by lin_z's, in hoisted order: scatter the [P,128] latent gradient onto the texels, then one GEMM per lin_z)."""
+    by lin_z's, in hoisted order: scatter the [P,128] latent gradient onto the texels, then one GEMM per lin_z).
+
+    The data-gradient chain (transposed-weight products, ReLU masks, residual adds of all 11 layers) is one HIP launch
+    that keeps the gradient in MFMA accumulators and emits, per layer, the matrix that layer's weight gradient contracts
+    with; the weight gradients themselves are sums over ALL points of outer products (K = points) and are one batched
+    library GEMM on those matrices; the bias gradients one column-sum reduction."""
     grads: Dict[str, torch.Tensor] = {}
-    r_out = act[10]
-    grads["lin_out.weight"] = _tn(d_out, r_out)
+    deltas = resnetfc_backward_chain(p, d_out, act)
+    sums = deltas.sum(1)                                            # [11,128]: bias gradients (deltas[l+1] <-> layer l)
+    w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
+    for l, name in enumerate(_LAYER_NAMES):
+        grads[name + ".weight"] = w_grads[l]
+        grads[name + ".bias"] = sums[l + 1]
+    grads["lin_out.weight"] = _tn(d_out, act[10])
     grads["lin_out.bias"] = d_out.sum(0)
-    # every layer step (ReLU mask, residual add, bias gradient = column sums) is one njf_relu_backward launch
-    delta, delta_sum = hip.relu_backward(d_out @ p["lin_out.weight"], r_out)
-    for blk in range(4, -1, -1):
-        r0, r1 = act[2 * blk], act[2 * blk + 1]
-        grads[f"blocks.{blk}.fc_1.weight"] = _tn(delta, r1)
-        grads[f"blocks.{blk}.fc_1.bias"] = delta_sum
-        d_net, d_net_sum = hip.relu_backward(delta @ p[f"blocks.{blk}.fc_1.weight"], r1)
-        grads[f"blocks.{blk}.fc_0.weight"] = _tn(d_net, r0)
-        grads[f"blocks.{blk}.fc_0.bias"] = d_net_sum
-        delta, delta_sum = hip.relu_backward(d_net @ p[f"blocks.{blk}.fc_0.weight"], r0, residual=delta)
-        if blk < 3:  # lin_z[blk](bilinear(F)) was added here
-            d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
-            # grid_sample's input gradient, one launch (points are ray-major: neighbouring samples share texels)
-            hip.scatter_footprint(delta, foot_idx, foot_w, d_g, run_length=samples_per_ray)
-            grads[f"lin_z.{blk}.weight"] = _tn(d_g, feats_flat)
-            grads[f"lin_z.{blk}.bias"] = delta_sum
-            if d_feats is not None:
-                d_feats.addmm_(d_g, p[f"lin_z.{blk}.weight"])
-    d_in = _tn(delta, pe)  # [128, 64] in slot order
+    for blk in range(3):  # lin_z[blk](bilinear(F)) was added to h in front of block blk: its gradient is deltas[2 blk]
+        delta = deltas[2 * blk]
+        d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
+        # grid_sample's input gradient, one launch (points are ray-major: neighbouring samples share texels)
+        hip.scatter_footprint(delta, foot_idx, foot_w, d_g, run_length=samples_per_ray)
+        grads[f"lin_z.{blk}.weight"] = _tn(d_g, feats_flat)
+        grads[f"lin_z.{blk}.bias"] = sums[2 * blk]
+        if d_feats is not None:
+            d_feats.addmm_(d_g, p[f"lin_z.{blk}.weight"])
+    d_in = _tn(deltas[0], pe)  # [128, 64] in slot order
     grads["lin_in.weight"] = d_in.new_zeros(d_in.shape[0], 63).index_copy_(
         1, _slot_to_channel(d_in.device), d_in[:, :63])
     grads["lin_in.bias"] = d_in[:, 63].clone()
     return grads
+
+
+def resnetfc_backward_reference_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    """The same deltas as ``resnetfc_backward_chain`` from library GEMMs + njf_relu_backward (the round-1 form of the
+    backward pass): kept as the comparator of the fused kernel's GPU test."""
+    deltas = torch.empty_like(act)
+    delta, _ = hip.relu_backward(d_out @ p["lin_out.weight"], act[10], want_colsum=False)
+    deltas[10] = delta
+    for blk in range(4, -1, -1):
+        d_net, _ = hip.relu_backward(delta @ p[f"blocks.{blk}.fc_1.weight"], act[2 * blk + 1], want_colsum=False)
+        delta, _ = hip.relu_backward(d_net @ p[f"blocks.{blk}.fc_0.weight"], act[2 * blk], residual=delta, want_colsum=False)
+        deltas[2 * blk + 1], deltas[2 * blk] = d_net, delta
+    return deltas
 
 
 def _flat_features(features) -> torch.Tensor:

@@ -311,3 +311,55 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup):
     print("worst relative gradient error (transformer head)", worst)
     assert worst < 5e-3, worst
     assert all(p.grad is None for n, p in named.items() if n not in trainable)
+
+
+def test_fused_backward_chain_equals_the_gemm_chain(setup):
+    """njf_resnetfc_backward (one launch: 11 transposed-weight MFMA products, ReLU masks, residual adds, gradient resident
+    in registers) against the layer-by-layer form -- library GEMMs + njf_relu_backward -- on random activations with
+    ragged point counts and every d_out the model uses; and the parameter gradients built from it against autograd."""
+    from neural_jacobian_field_amd import synthetic, training
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    for points, d_out in ((1, 1), (37, 16), (4096 + 13, 24), (300, 3)):
+        shapes = synthetic.resnet_fc_shapes("", 63, 512, d_out)
+        p = {k: v.to(dev) for k, v in synthetic.seeded_state_dict(shapes, seed=2).items()}
+        act = torch.randn(11, points, 128, generator=gen).clamp_min(0).to(dev)       # ReLU'd layer inputs: ~half zeros
+        g = torch.randn(points, d_out, generator=gen).to(dev) * 1e-3
+        got = training.resnetfc_backward_chain(p, g, act)
+        ref = training.resnetfc_backward_reference_chain(p, g, act)
+        assert got.shape == ref.shape == (11, points, 128)
+        for l in range(11):
+            scale = ref[l].abs().max().item() + 1e-30
+            assert ((got[l] - ref[l]).abs().max().item() / scale) < 2e-6, (points, d_out, l)
+        assert torch.equal(got, training.resnetfc_backward_chain(p, g, act))      # bit-reproducible
+    # parameter gradients of a whole ResnetFC against autograd of the same net in torch (fp64)
+    points, d_out = 257, 16
+    shapes = synthetic.resnet_fc_shapes("", 63, 512, d_out)
+    p = {k: v.to(dev) for k, v in synthetic.seeded_state_dict(shapes, seed=3).items()}
+    pe = torch.randn(points, 64, generator=gen).to(dev)
+    pe[:, 63] = 1.0                                                                # the bias slot of lin_in
+    z = [torch.randn(points, 128, generator=gen).to(dev) for _ in range(3)]       # the three hoisted latents
+    slot = torch.tensor(training._PE_SLOT_TO_CHANNEL, device=dev)
+    leaves = {k: v.double().requires_grad_(True) for k, v in p.items() if not k.startswith("lin_z")}
+    x = pe.double().new_zeros(points, 63)
+    x[:, slot] = pe[:, :63].double()
+    h = x @ leaves["lin_in.weight"].t() + leaves["lin_in.bias"]
+    acts = []
+    for blk in range(5):
+        if blk < 3:
+            h = h + z[blk].double()
+        acts.append(torch.relu(h))
+        net = acts[-1] @ leaves[f"blocks.{blk}.fc_0.weight"].t() + leaves[f"blocks.{blk}.fc_0.bias"]
+        acts.append(torch.relu(net))
+        h = h + acts[-1] @ leaves[f"blocks.{blk}.fc_1.weight"].t() + leaves[f"blocks.{blk}.fc_1.bias"]
+    acts.append(torch.relu(h))
+    out = acts[-1] @ leaves["lin_out.weight"].t() + leaves["lin_out.bias"]
+    g = torch.randn(points, d_out, generator=gen).to(dev)
+    ref_grads = dict(zip(leaves, torch.autograd.grad(out, list(leaves.values()), g.double())))
+    act = torch.stack([a.detach().float() for a in acts])
+    feats = torch.zeros(4, 512, device=dev)
+    grads = training.resnetfc_backward(p, g, act, pe, torch.zeros(points, 4, dtype=torch.int32, device=dev),
+                                       torch.zeros(points, 4, device=dev), feats)
+    for k, r in ref_grads.items():
+        err = (grads[k].double() - r).abs().max().item() / (r.abs().max().item() + 1e-30)
+        assert err < 5e-6, (k, err)

@@ -16,17 +16,21 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x2"
 src = f"gpurun_out/prof_{tag}_{prec}"
+round_tag = tag
 tag = f"{tag}_{prec}"
-MFMA_FLOP = 4096 if prec == "f32" else 32768      # v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16
+# per MFMA instruction: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16.  The f16f6 kernels issue two kinds (f16 K=16:
+# 32 cycles, 32,768 FLOP; fp6 K=64: 32 cycles, 131,072 FLOP) in the ratio 2:1 -> 65,536 FLOP per instruction on average
+MFMA_FLOP = {"f32": 4096, "f16x2": 32768, "f16f6": 65536}[prec]
 MFMA_CYCLES = 64 if prec == "f32" else 32
 os.makedirs("profiles", exist_ok=True)
 # the traced command may fork helpers, each leaving its own stats file: take the one that holds the fused kernels
 stats = max(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=lambda f: open(f).read().count("render_kernel"))
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
-PCODE = 1 if prec == "f16x2" else 0  # bench.py runs both precisions in one process: pick this one's instantiations
-KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PCODE},": "proposal",
-           ("project_kernel_f16x2(" if prec == "f16x2" else "project_kernel("): "project"}
+PCODE = {"f32": 0, "f16x2": 1, "f16f6": 2}[prec]    # template argument of this precision's instantiations
+PROP = 1 if prec == "f16f6" else PCODE              # under f16f6 the proposal networks stay on f16x2 (Model.set_precision)
+KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PROP},": "proposal",
+           ("project_kernel(" if prec == "f32" else "project_kernel_f16x2("): "project"}
 agg = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"{src}/pmc*/*/*_counter_collection.csv"):
@@ -43,7 +47,7 @@ for r in csv.DictReader(open(stats)):
             dur[short] = float(r["AverageNs"]) * 1e-9
 
 lines = [f"# {tag}: rocprofv3 PMC summary (MI355X; durations from `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3`, counters from `--pmc` runs of `bench.py --steps 2 --warmup 1`, per-launch means)", "",
-         f"Collected by `tools/profile_r01.sh {prec}`: kernel-trace/stats and each PMC group in separate runs.", "",
+         f"Collected by `tools/profile_{round_tag}.sh {prec}`: kernel-trace/stats and each PMC group in separate runs.", "",
          "| kernel | avg duration (kernel-trace) | launch config |", "|---|---|---|"]
 for k in ("project", "proposal", "render"):
     lines.append(f"| {k} | {dur[k]*1e3:.3f} ms | {meta.get(k)} |")
@@ -84,5 +88,5 @@ for k in ("proposal", "render"):
                     "separate passes; counts L2 memory-side requests incl. Infinity-Cache hits and scratch traffic",
                     "avg_duration_s": dur[k], "mfma_util": mfma_util_insts, "mfma_util_counter_ratio": mfma_util}
 open(f"profiles/{tag}_pmc_summary.md", "w").write("\n".join(lines) + "\n")
-json.dump(out_json, open(f"profiles/r01_render_kernel_hbm_bytes_{prec}.json", "w"), indent=1)
+json.dump(out_json, open(f"profiles/{round_tag}_render_kernel_hbm_bytes_{prec}.json", "w"), indent=1)
 print("\n".join(lines[-16:]))
