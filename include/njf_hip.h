@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 12
+#define NJF_ABI_VERSION 13
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -280,9 +280,13 @@ int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ra
  * consecutive contributions to the same texel before touching memory -- pass the samples per ray (points are ordered
  * ray-major, neighbouring samples mostly share texels); 1 = no merging.  The result does not depend on it beyond
  * rounding.  fp32 hardware atomics: the summation order, hence the last bits, vary from run to run (as they do for
- * ATen's grid_sampler_2d_backward on a GPU). */
-int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels, int texels,
-                          int run_length, float* out, void* stream);
+ * ATen's grid_sampler_2d_backward on a GPU).
+ * `slices` >= 1 gradients of the same points are scattered in one launch: slice s is read at grad + s * slice_stride
+ * ([P,channels] each; the three lin_z latents of a ResnetFC are deltas[0], [2], [4] of njf_resnetfc_backward, i.e.
+ * slice_stride = 2*P*128) and lands in columns [s*channels, (s+1)*channels) of out [texels, slices*channels]
+ * (slices > 1 needs channels % 64 == 0). */
+int njf_scatter_footprint(const float* grad, int slices, long long slice_stride, const int* foot_idx, const float* foot_w,
+                          int points, int channels, int texels, int run_length, float* out, void* stream);
 
 /* The whole data-gradient chain of one ResnetFC's backward pass in one launch: what autograd runs as 11 x (GEMM with the
  * transposed weight + ReLU mask + residual add) for model_components/resnet_fc.py:69-79,130-154.  `w_backward`
@@ -292,11 +296,14 @@ int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* f
  * output.  Writes `deltas` [11,P,128]: deltas[l+1] is the gradient w.r.t. the OUTPUT of the layer whose input is
  * activations[l] (l = 0..9), so that layer's weight gradient is deltas[l+1]^T activations[l] and its bias gradient the
  * column sum of deltas[l+1]; deltas[0], deltas[2], deltas[4] are the gradients w.r.t. the three hoisted latents
- * (lin_z outputs) and deltas[0] also w.r.t. lin_in's output.  Exact-fp32 MFMA. */
+ * (lin_z outputs) and deltas[0] also w.r.t. lin_in's output.  Exact-fp32 MFMA.
+ * `colsum_partial` (may be NULL) [ceil(P / 32), 11, 128]: per 32-point tile, the column sums of every deltas slice (the
+ * bias gradients are their sum over the tiles: 32x less data than re-reading deltas; fixed summation order inside a
+ * tile). */
 #define NJF_RESNET_BACKWARD_CHUNKS 21
 int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, void* stream);
 int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward, int points,
-                          float* deltas, void* stream);
+                          float* deltas, float* colsum_partial, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

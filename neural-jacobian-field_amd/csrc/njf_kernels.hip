@@ -580,35 +580,56 @@ struct ConcatArgs {
   float* out;
 };
 
+// One workgroup = 64 texels of one row x 64 output channels.  Pass 1: lane = texel, wave = 16 of the channels, so the
+// four bilinear taps of every NCHW plane are read along x (coalesced); the tile is transposed through LDS (row pitch 65:
+// conflict-free both ways).  Pass 2: 16 consecutive threads write the 64 channels of one texel as 256 contiguous bytes.
+// (The round-1 form read the planes channel-major per thread: 16 scattered 4-byte loads per thread, 0.49 ms for the
+// 235 MB matrix of the training batch; this form is bound by the write.)
 __global__ void __launch_bounds__(256) upsample_concat_kernel(ConcatArgs a) {
-  const int n = a.c0[a.levels], n4 = n >> 2;
+  __shared__ float tile[64 * 65];
+  const int n = a.c0[a.levels];
   const int height = a.h[0], width = a.w[0];
-  const long long total = (long long)a.batch * height * width * n4;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int c = (int)(i % n4) * 4;
-  const long long t = i / n4;
-  const int x = (int)(t % width), y = (int)((t / width) % height), b = (int)(t / ((long long)width * height));
-  int l = 0;
-  while (l + 1 < a.levels && c >= a.c0[l + 1]) ++l;
-  const int cl = c - a.c0[l], h = a.h[l], w = a.w[l];
-  // F.interpolate(mode="bilinear", align_corners=False): src = (dst + 0.5) * in / out - 0.5, clamped at 0
-  const float sy = fmaxf(((float)y + 0.5f) * ((float)h / (float)height) - 0.5f, 0.f);
-  const float sx = fmaxf(((float)x + 0.5f) * ((float)w / (float)width) - 0.5f, 0.f);
-  const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
-  const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-  const float wy = sy - (float)y0, wx = sx - (float)x0;
-  const size_t plane = (size_t)h * w;
-  const float* base = a.src[l] + ((size_t)b * a.c[l] + cl) * plane;
-  f32x4 o;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groups = (n + 63) >> 6;
+  const int xt = blockIdx.x / groups, cg = blockIdx.x - xt * groups;
+  const int y = blockIdx.y, b = blockIdx.z;
+  const int x = min(xt * 64 + lane, width - 1);
+  for (int g = 0; g < 4; ++g) {  // the wave's 16 channels in groups of 4 (a level holds a multiple of 4 channels)
+    const int c = cg * 64 + 16 * wave + 4 * g;
+    if (c >= n) break;
+    int l = 0;
+    while (l + 1 < a.levels && c >= a.c0[l + 1]) ++l;
+    const int cl = c - a.c0[l], h = a.h[l], w = a.w[l];
+    // F.interpolate(mode="bilinear", align_corners=False): src = (dst + 0.5) * in / out - 0.5, clamped at 0
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)h / (float)height) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)w / (float)width) - 0.5f, 0.f);
+    const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float wy = sy - (float)y0, wx = sx - (float)x0;
+    const size_t plane = (size_t)h * w;
+    const float* base = a.src[l] + ((size_t)b * a.c[l] + cl) * plane;
+    const int o00 = y0 * w + x0, o01 = y0 * w + x1, o10 = y1 * w + x0, o11 = y1 * w + x1;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float* p = base + e * plane;
-    const float top = p[(size_t)y0 * w + x0] * (1.0f - wx) + p[(size_t)y0 * w + x1] * wx;
-    const float bot = p[(size_t)y1 * w + x0] * (1.0f - wx) + p[(size_t)y1 * w + x1] * wx;
-    o[e] = top * (1.0f - wy) + bot * wy;
+    for (int e = 0; e < 4; ++e) {
+      const float* p = base + e * plane;
+      const float top = p[o00] * (1.0f - wx) + p[o01] * wx;
+      const float bot = p[o10] * (1.0f - wx) + p[o11] * wx;
+      tile[lane * 65 + 16 * wave + 4 * g + e] = top * (1.0f - wy) + bot * wy;
+    }
   }
-  *(f32x4*)(a.out + (size_t)t * n + c) = o;
+  __syncthreads();
+  const int q = threadIdx.x & 15, tr = threadIdx.x >> 4;
+  const int cq = cg * 64 + 4 * q;
+  if (cq >= n) return;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int tx = 16 * pass + tr, gx = xt * 64 + tx;
+    if (gx >= width) continue;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = tile[tx * 65 + 4 * q + e];
+    *(f32x4*)(a.out + (((size_t)b * height + y) * width + gx) * n + cq) = o;
+  }
 }
 
 extern "C" int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels, int batch, float* out, void* stream) {
@@ -628,9 +649,9 @@ extern "C" int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels
     a.w[l] = levels[l].width;
     a.c0[l + 1] = a.c0[l] + levels[l].channels;
   }
-  const long long total = (long long)batch * a.h[0] * a.w[0] * (a.c0[num_levels] >> 2);
-  if ((total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
-  upsample_concat_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  const long long tiles = (long long)((a.w[0] + 63) / 64) * ((a.c0[num_levels] + 63) / 64);
+  if (tiles > 0x7fffffffLL || a.h[0] > 65535 || batch > 65535) return NJF_E_SHAPE;
+  upsample_concat_kernel<<<dim3((unsigned)tiles, a.h[0], batch), 256, 0, (hipStream_t)stream>>>(a);
   return launch_status();
 }
 
@@ -1547,28 +1568,31 @@ extern "C" int njf_solve_action(const float* mean_position, const float* jacobia
 // floats of one texel row (two full 128-byte lines; global_atomic_add_f32, no CAS loop).  Points are ordered ray-major,
 // so consecutive points are neighbouring samples of one ray, which mostly fall into the same texels: each footprint
 // corner keeps a running sum in a register and only issues an atomic when its texel changes (2-3x fewer atomics).
-__global__ void __launch_bounds__(256) scatter_footprint_kernel(const float* __restrict__ grad,
+__global__ void __launch_bounds__(256) scatter_footprint_kernel(const float* __restrict__ grad, long long slice_stride,
                                                                 const int* __restrict__ foot_idx,
                                                                 const float* __restrict__ foot_w, int points, int run,
-                                                                int channels, long long total, float* __restrict__ out) {
+                                                                int channels, int row, long long total,
+                                                                float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const long long r = i / channels;
-  const int ch = (int)(i - r * channels);
+  const long long r = i / row;
+  const int col = (int)(i - r * row);          // column of the [texels, slices * channels] output
+  const int slice = col / channels, ch = col - slice * channels;
+  const float* g = grad + (size_t)slice * slice_stride + ch;
   const long long p0 = r * run;
   const int n = (int)min((long long)run, (long long)points - p0);
   int cur[4] = {-1, -1, -1, -1};
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < n; ++s) {
     const size_t p = (size_t)(p0 + s);
-    const float v = grad[p * channels + ch];
+    const float v = g[p * channels];
     const int4 idx = *(const int4*)(foot_idx + p * 4);
     const f32x4 w = *(const f32x4*)(foot_w + p * 4);
     const int t[4] = {idx.x, idx.y, idx.z, idx.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (t[c] != cur[c]) {  // wave-uniform: every lane of a wave works on the same points
-        if (cur[c] >= 0) unsafeAtomicAdd(out + (size_t)cur[c] * channels + ch, acc[c]);
+        if (cur[c] >= 0) unsafeAtomicAdd(out + (size_t)cur[c] * row + col, acc[c]);
         cur[c] = t[c];
         acc[c] = 0.f;
       }
@@ -1577,18 +1601,21 @@ __global__ void __launch_bounds__(256) scatter_footprint_kernel(const float* __r
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
-    if (cur[c] >= 0) unsafeAtomicAdd(out + (size_t)cur[c] * channels + ch, acc[c]);
+    if (cur[c] >= 0) unsafeAtomicAdd(out + (size_t)cur[c] * row + col, acc[c]);
 }
 
-extern "C" int njf_scatter_footprint(const float* grad, const int* foot_idx, const float* foot_w, int points, int channels,
-                                     int texels, int run_length, float* out, void* stream) {
+extern "C" int njf_scatter_footprint(const float* grad, int slices, long long slice_stride, const int* foot_idx,
+                                     const float* foot_w, int points, int channels, int texels, int run_length, float* out,
+                                     void* stream) {
   if (!grad || !foot_idx || !foot_w || !out) return NJF_E_NULL;
-  if (points < 1 || texels < 1 || channels < 1 || run_length < 1) return NJF_E_SHAPE;
+  if (points < 1 || texels < 1 || channels < 1 || run_length < 1 || slices < 1 || slices > 64) return NJF_E_SHAPE;
+  if ((channels & 63) && slices > 1) return NJF_E_SHAPE;  // a wave must stay inside one slice (wave-uniform footprints)
   const long long runs = ((long long)points + run_length - 1) / run_length;
-  const long long total = runs * channels;
+  const int row = slices * channels;
+  const long long total = runs * row;
   if ((total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
   scatter_footprint_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      grad, foot_idx, foot_w, points, run_length, channels, total, out);
+      grad, slice_stride, foot_idx, foot_w, points, run_length, channels, row, total, out);
   return launch_status();
 }
 
@@ -1676,7 +1703,38 @@ struct BackwardArgs {
   const float* w_pack;  // 21 chunks: lin_out^T | (fc_1^T, fc_0^T) of blocks 4..0
   int points;
   float* deltas;        // [11, P, 128]
+  float* colsum;        // [tiles, 11, 128] per-tile column sums of deltas, or nullptr
 };
+
+// Sum over the 32 points of a tile (lanes of one wave half) of every accumulator register, in DPP: rotate-and-add inside
+// the rows of 16 lanes (afterwards every lane of a row holds the row's sum), then row_bcast:15 adds row 0 into row 1 and
+// row 2 into row 3 -- lanes 16..31 / 48..63 hold the sums of the half's 64 features.  Lane 16 + 4m + q (48 + ...) then
+// stores its quad: 16 predicated 16-byte stores per layer.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+
+__device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __restrict__ dst, int lane) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[m][4 * q + e];
+        v = dpp_add<0x128, 0xf>(v);  // row_ror:8
+        v = dpp_add<0x124, 0xf>(v);  // row_ror:4
+        v = dpp_add<0x122, 0xf>(v);  // row_ror:2
+        v = dpp_add<0x121, 0xf>(v);  // row_ror:1
+        v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+        o[e] = v;
+      }
+      if ((lane & 31) == 16 + 4 * m + q) *(f32x4*)(dst + 16 * m + 4 * q) = o;
+    }
+}
 
 // acc = [act > 0] * acc (+ base), written to `dst`; act / dst address this lane's 64 features of its point
 template <bool ADD>
@@ -1712,6 +1770,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
   const size_t layer = (size_t)a.points * 128;
   const float* act = a.act + pc * 128 + 64 * hh;
   float* out = a.deltas + pc * 128 + 64 * hh;
+  float* sums = a.colsum ? a.colsum + (size_t)tile * (11 * 128) + 64 * hh : nullptr;
   WeightStream st;
   stream_begin(st, a.w_pack, 21, 1, wave, lane);
   f32x16 din[1];
@@ -1728,6 +1787,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
     mma_chunk<PREC, 4, 1, 0, false, 1>(st, wl, lane, din, delta);   // lin_out^T (first half of the chunk)
   }
   mask_store<false>(act + 10 * layer, out + 10 * layer, ok, delta, delta);
+  const bool live = tile * 32 < a.points;  // wave-uniform
+  if (sums && live) tile_colsum(delta, sums + 10 * 128, lane);
   for (int blk = 4; blk >= 0; --blk) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) t[m] = (f32x16)(0.f);
@@ -1740,6 +1801,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, delta, t);
     }
     mask_store<false>(act + (size_t)(2 * blk + 1) * layer, out + (size_t)(2 * blk + 1) * layer, ok, t, t);
+    if (sums && live) tile_colsum(t, sums + (2 * blk + 1) * 128, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) u[m] = (f32x16)(0.f);
     {
@@ -1751,6 +1813,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, t, u);
     }
     mask_store<true>(act + (size_t)(2 * blk) * layer, out + (size_t)(2 * blk) * layer, ok, u, delta);
+    if (sums && live) tile_colsum(u, sums + (2 * blk) * 128, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) delta[m] = u[m];
   }
@@ -2093,10 +2156,10 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
 }
 
 extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward,
-                                     int points, float* deltas, void* stream) {
+                                     int points, float* deltas, float* colsum_partial, void* stream) {
   if (!d_out || !activations || !w_backward || !deltas) return NJF_E_NULL;
   if (points < 1 || (long long)points * 11 * 128 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
-  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas};
+  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial};
   return launch_fused(resnetfc_backward_kernel<PREC_F32>, a, (points + 31) / 32, (hipStream_t)stream);
 }

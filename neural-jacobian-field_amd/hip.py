@@ -124,8 +124,8 @@ _SIGNATURES = {
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, _vp], C.c_int),
-    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
-    "njf_scatter_footprint": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
+    "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
@@ -481,14 +481,26 @@ def solve_action(mean_position, jacobian, projection, target_flow, visible_mask,
 
 
 def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
-    """out [T,C] += bilinear-footprint scatter of grad [P,C] (foot_idx [P,4] int32, foot_w [P,4]): the input gradient of
-    the pixel-aligned sampling, see include/njf_hip.h.  ``run_length``: samples per ray (consecutive points that mostly
-    share texels are merged in registers before the atomics)."""
-    points, channels = grad.shape
-    if tuple(foot_idx.shape) != (points, 4) or tuple(foot_w.shape) != (points, 4) or out.shape[1] != channels:
+    """out [T,S*C] += bilinear-footprint scatter of grad [P,C] or [S,P,C] (foot_idx [P,4] int32, foot_w [P,4]): the input
+    gradient of the pixel-aligned sampling, see include/njf_hip.h.  A 3-D ``grad`` may be a strided view along its first
+    axis (e.g. ``deltas[0:6:2]``): S gradients of the same points land side by side in ``out``'s columns, one launch.
+    ``run_length``: samples per ray (consecutive points that mostly share texels are merged in registers before the
+    atomics)."""
+    if grad.dim() == 2:
+        grad = grad.unsqueeze(0)
+    slices, points, channels = grad.shape
+    if grad.stride(2) != 1 or grad.stride(1) != channels:
+        raise ValueError("njf_hip: scatter_footprint needs [P,C]-contiguous gradient slices")
+    if tuple(foot_idx.shape) != (points, 4) or tuple(foot_w.shape) != (points, 4) or out.shape[1] != slices * channels:
         raise ValueError("njf_hip: scatter_footprint shape mismatch")
-    _launch("njf_scatter_footprint", load_library().njf_scatter_footprint, _ptr(grad, "grad"), _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels,
-                                                out.shape[0], int(run_length), _ptr(out, "out"))
+    if not out.is_contiguous():
+        raise ValueError("njf_hip: scatter_footprint output must be contiguous")
+    if not grad.is_cuda or grad.dtype != torch.float32:
+        raise ValueError("njf_hip: grad must be a float32 GPU tensor; there is no CPU path")
+    _note_device(grad, "grad")
+    _launch("njf_scatter_footprint", load_library().njf_scatter_footprint, grad.data_ptr(), slices,
+            grad.stride(0) if slices > 1 else 0, _int_ptr(foot_idx), _ptr(foot_w, "foot_w"), points, channels, out.shape[0],
+            int(run_length), _ptr(out, "out"))
 
 
 RESNET_BACKWARD_W_FLOATS = 21 * 8192
@@ -507,16 +519,18 @@ def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: 
     _launch("njf_pack_resnetfc_backward", load_library().njf_pack_resnetfc_backward, C.byref(src), _ptr(w_out, "w_out"))
 
 
-def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor) -> torch.Tensor:
+def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor, want_colsum: bool = False):
     """deltas [11,P,128] of one ResnetFC's backward pass (include/njf_hip.h: njf_resnetfc_backward): d_out [P,d_out],
-    act [11,P,128] (dumped ReLU'd layer inputs), w_backward from pack_resnetfc_backward."""
+    act [11,P,128] (dumped ReLU'd layer inputs), w_backward from pack_resnetfc_backward.  ``want_colsum``: also return
+    the column sums [11,128] of every deltas slice (the bias gradients), reduced from the kernel's per-tile partials."""
     points = d_out.shape[0]
     if tuple(act.shape) != (11, points, 128) or w_backward.numel() != RESNET_BACKWARD_W_FLOATS:
         raise ValueError("njf_hip: resnetfc_backward shape mismatch")
     deltas = torch.empty_like(act)
+    partial = torch.empty((points + 31) // 32, 11, 128, dtype=torch.float32, device=act.device) if want_colsum else None
     _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out.contiguous(), "d_out"), d_out.shape[1],
-            _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"))
-    return deltas
+            _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"), _ptr(partial, "colsum_partial"))
+    return (deltas, partial.sum(0)) if want_colsum else deltas
 
 
 RELU_BACKWARD_ROWS = 512  # rows per workgroup of njf_relu_backward (one partial column-sum row each)

@@ -74,13 +74,14 @@ def _tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out.reshape(layers, groups, n, -1).sum(1)
 
 
-def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, want_colsum: bool = False):
     """The data-gradient chain of one ResnetFC as ONE fused launch (njf_resnetfc_backward): deltas [11,P,128], see
-    include/njf_hip.h for the meaning of each slice.  The transposed weights are packed per call (eleven small launches:
-    the weights change with every optimiser step)."""
+    include/njf_hip.h for the meaning of each slice (with ``want_colsum`` also their column sums [11,128], from the
+    kernel's per-tile partial sums).  The transposed weights are packed per call (eleven small launches: the weights
+    change with every optimiser step)."""
     w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
     hip.pack_resnetfc_backward(p, "", w_t)
-    return hip.resnetfc_backward(d_out, act, w_t)
+    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum)
 
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
@@ -99,23 +100,24 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     with; the weight gradients themselves are sums over ALL points of outer products (K = points) and are one batched
     library GEMM on those matrices; the bias gradients one column-sum reduction."""
     grads: Dict[str, torch.Tensor] = {}
-    deltas = resnetfc_backward_chain(p, d_out, act)
-    sums = deltas.sum(1)                                            # [11,128]: bias gradients (deltas[l+1] <-> layer l)
+    deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True)   # sums [11,128]: deltas[l+1] <-> bias of layer l
     w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
     for l, name in enumerate(_LAYER_NAMES):
         grads[name + ".weight"] = w_grads[l]
         grads[name + ".bias"] = sums[l + 1]
     grads["lin_out.weight"] = _tn(d_out, act[10])
     grads["lin_out.bias"] = d_out.sum(0)
-    for blk in range(3):  # lin_z[blk](bilinear(F)) was added to h in front of block blk: its gradient is deltas[2 blk]
-        delta = deltas[2 * blk]
-        d_g = torch.zeros(feats_flat.shape[0], delta.shape[1], dtype=delta.dtype, device=delta.device)
-        # grid_sample's input gradient, one launch (points are ray-major: neighbouring samples share texels)
-        hip.scatter_footprint(delta, foot_idx, foot_w, d_g, run_length=samples_per_ray)
-        grads[f"lin_z.{blk}.weight"] = _tn(d_g, feats_flat)
+    # lin_z[blk](bilinear(F)) was added to h in front of block blk: its gradient is deltas[2 blk].  grid_sample's input
+    # gradient of all three latents is ONE launch into [T,384] (points are ray-major: neighbouring samples share texels),
+    # the three weight gradients one GEMM against the channels-last features
+    d_g = torch.zeros(feats_flat.shape[0], 3 * 128, dtype=deltas.dtype, device=deltas.device)
+    hip.scatter_footprint(deltas[0:6:2], foot_idx, foot_w, d_g, run_length=samples_per_ray)
+    wz_grad = _tn(d_g, feats_flat)                                   # [384,512]
+    for blk in range(3):
+        grads[f"lin_z.{blk}.weight"] = wz_grad[128 * blk:128 * (blk + 1)]
         grads[f"lin_z.{blk}.bias"] = sums[2 * blk]
-        if d_feats is not None:
-            d_feats.addmm_(d_g, p[f"lin_z.{blk}.weight"])
+    if d_feats is not None:
+        d_feats.addmm_(d_g, torch.cat([p[f"lin_z.{blk}.weight"] for blk in range(3)]))
     d_in = _tn(deltas[0], pe)  # [128, 64] in slot order
     grads["lin_in.weight"] = d_in.new_zeros(d_in.shape[0], 63).index_copy_(
         1, _slot_to_channel(d_in.device), d_in[:, :63])

@@ -212,6 +212,17 @@ def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
     assert err < 2e-6, err
     with pytest.raises(ValueError):
         hip.scatter_footprint(grad, idx[:, :3].contiguous(), w, out)
+    if channels % 64 == 0:   # several gradients of the same points in one launch (a strided view, like deltas[0:6:2])
+        stack = torch.randn(5, points, channels, generator=g).to(dev)
+        view = stack[0:5:2]
+        out3 = torch.zeros(texels, 3 * channels, device=dev)
+        hip.scatter_footprint(view, idx, w, out3, run_length=7)
+        for s in range(3):
+            ref = torch.zeros(texels, channels, dtype=torch.float64, device=dev)
+            for c in range(4):
+                ref.index_add_(0, idx[:, c].long(), view[s].double() * w[:, c:c + 1].double())
+            got = out3[:, s * channels:(s + 1) * channels].double()
+            assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6, s
 
 
 @pytest.mark.parametrize("points,channels", [(5000, 128), (513, 64), (7, 128)])

@@ -331,7 +331,11 @@ def test_fused_backward_chain_equals_the_gemm_chain(setup):
         for l in range(11):
             scale = ref[l].abs().max().item() + 1e-30
             assert ((got[l] - ref[l]).abs().max().item() / scale) < 2e-6, (points, d_out, l)
-        assert torch.equal(got, training.resnetfc_backward_chain(p, g, act))      # bit-reproducible
+        again, sums = training.resnetfc_backward_chain(p, g, act, want_colsum=True)
+        assert torch.equal(got, again)                                            # bit-reproducible
+        ref_sums = got.double().sum(1)                                            # the in-kernel per-tile column sums
+        assert sums.shape == (11, 128)
+        assert ((sums.double() - ref_sums).abs().max() / (ref_sums.abs().max() + 1e-30)).item() < 2e-6, (points, d_out)
     # parameter gradients of a whole ResnetFC against autograd of the same net in torch (fp64)
     points, d_out = 257, 16
     shapes = synthetic.resnet_fc_shapes("", 63, 512, d_out)
