@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 13
+#define NJF_ABI_VERSION 14
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -177,11 +177,13 @@ int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels, int batch
 
 /* Channel order of the hoisted map.  Inside every block of `block_channels` channels (128 for a ResnetFC's lin_z layer,
  * 64 for the transformer head's query projection) logical feature f of the layer is stored at position
- * njf_hoisted_channel(f, block_channels) -- the order in which the two lanes that own a point read adjacent 16-byte
- * pieces (the njf_pack_* / njf_project_* entry points apply it themselves).  Host function, no GPU work; for callers
- * that write hoisted channels directly (flow_mlp's per-image action bias, the transformer head's folded query weights).
- * Returns a negative error code for an invalid argument. */
-int njf_hoisted_channel(int feature, int block_channels);
+ * njf_hoisted_channel(f, block_channels, precision) -- the order in which the fused kernels' gather reads it, which
+ * follows the MFMA precision (NJF_PRECISION_F32 / _F16X2 / _F16F6, not a MIXED code) the network that owns the block is
+ * packed for: F32 and F16X2 networks fetch per lane (the two lanes that own a point read adjacent 16-byte pieces),
+ * F16F6 networks per quad of lanes (csrc/njf_device.h: add_hoisted_latent).  The njf_pack_* entry points apply it
+ * themselves.  Host function, no GPU work; for callers that write hoisted channels directly (flow_mlp's per-image action
+ * bias, the transformer head's folded query weights).  Returns a negative error code for an invalid argument. */
+int njf_hoisted_channel(int feature, int block_channels, int precision);
 
 /* ---- ray generation: rendering/geometry.py:117-134 + :170-203 ------------------------------ */
 /* coords [B,R,2] normalised pixel centres (NULL -> full H x W grid of get_pixel_coordinates),

@@ -86,7 +86,26 @@ struct WeightStream {
   int dma_soff;    // byte offset (wave-uniform) of this wave's share of round 0 of the chunk being prefetched
   float* dma_dst;  // this wave's LDS destination of round 0
   int dma_next;    // 0 = job pending, NJF_DMA_ROUNDS = issued (or nothing to prefetch)
+#ifdef NJF_STAMPS
+  int stamp_i;     // next free slot of this wave's time-stamp log in LDS (-1: this wave does not log)
+#endif
 };
+// Timeline instrumentation of ONE wave (experiment builds only, -DNJF_STAMPS; tools/stamps.py): (tag << 24 | low 24
+// bits of s_memtime) words, logged to a spare LDS area and copied out by the render kernel when the wave retires.
+#ifdef NJF_STAMPS
+#define NJF_STAMP_SLOTS 1024
+__device__ unsigned njf_stamp_out[NJF_STAMP_SLOTS];
+#define NJF_STAMP(st, tag)                                                                                   \
+  do {                                                                                                       \
+    if ((st).stamp_i >= 0 && (st).stamp_i < NJF_STAMP_SLOTS) {                                               \
+      njf_lds[LDS_FLOATS_RENDER + (st).stamp_i] =                                                            \
+          __uint_as_float(((unsigned)(tag) << 24) | ((unsigned)__builtin_readcyclecounter() & 0xffffffu));   \
+      (st).stamp_i += 1;                                                                                     \
+    }                                                                                                        \
+  } while (0)
+#else
+#define NJF_STAMP(st, tag) do {} while (0)
+#endif
 #define NJF_DMA_ROUNDS (NJF_CHUNK / (NJF_THREADS * 4))
 
 __device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
@@ -124,6 +143,9 @@ __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, i
   st.idx = 0;
   st.in_pass = 0;
   st.dma_voff = lane * 16;
+#ifdef NJF_STAMPS
+  st.stamp_i = -1;
+#endif
   dma_job(st, 0, 0, wave);
   stream_flush(st);
 }
@@ -135,12 +157,15 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
   return njf_lds + (st.idx++ & 1) * NJF_CHUNK;
 #endif
   stream_flush(st);  // rounds the previous consumer did not issue (chunk shapes without interleaving)
+  NJF_STAMP(st, 1);  // chunk's work issued
   // Every wave must have ITS share of the chunk in LDS before anyone passes the barrier.  LDS-DMA completion is
   // counted by vmcnt, and the workgroup fence of __syncthreads() does not cover it (the compiler only waits vmcnt
   // in front of this wave's own reads of the buffer): without the explicit wait another wave can read a round that
   // is still in flight -- a race the full-frame ray-sharding test caught once the rounds were issued later.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NJF_STAMP(st, 2);  // own memory operations drained
   __syncthreads();
+  NJF_STAMP(st, 3);  // barrier passed
   const float* cur = njf_lds + (st.idx & 1) * NJF_CHUNK;
   st.idx += 1;
   st.in_pass += 1;
@@ -191,6 +216,11 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 // split_pair with the packed {hi0, hi1} and {lo0, lo1} halves returned as dwords
 template <bool RELU>
 __device__ __forceinline__ void split_pair_u(float x0, float x1, unsigned& hu, unsigned& lu) {
+#ifdef NJF_ABLATE_SPLIT  // experiment builds only: no conversion work (results are garbage)
+  hu = __float_as_uint(x0) >> 3;
+  lu = __float_as_uint(x1) >> 3;
+  return;
+#endif
   if (RELU) {
     x0 = relu_bits(x0);
     x1 = relu_bits(x1);
@@ -273,12 +303,17 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
       mx[p] = RELU ? bh[0][p] : (bh[0][p] & 0x7fff7fffu);
     }
 #define NJF_LDS(T) const __attribute__((address_space(3))) T*
+#ifdef NJF_ABLATE_AFRAG  // experiment builds only: no LDS reads of the weight fragments
+    auto hfrag = [&](int i) { return __builtin_bit_cast(f16x8, u32x4{(unsigned)i, (unsigned)lane, 3u, 4u}); };
+    auto f6frag = [&](int idx) { return i32x8{idx, lane, 2, 3, 4, 5, 0, 0}; };
+#else
     auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + i * 1024); };                  // hi fp16 fragment (t, m): i = 4t + m
     auto f6frag = [&](int idx) {                                                           // fp6 fragment idx = 2m + w
       const i32x4 a4 = *(NJF_LDS(i32x4))(p16 + F6_P1 + idx * 1024);
       const i32x2 b2 = *(NJF_LDS(i32x2))(p8 + F6_P2 + idx * 512);
       return i32x8{a4[0], a4[1], a4[2], a4[3], b2[0], b2[1], 0, 0};
     };
+#endif
     auto op8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], v[2], v[3]}); };
     f16x8 a[2] = {hfrag(0), hfrag(1)};
     unsigned sb_h = 0, sb_l = 0;
@@ -306,7 +341,11 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
           const int m = 2 * half + mm;
+#ifdef NJF_ABLATE_MFMA
+          asm volatile("" :: "v"(a[mm]), "v"(op8(bh[t])));
+#else
           out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mm], op8(bh[t]), out[m], 0, 0, 0);
+#endif
           if (t + 1 < 4) {
             const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
             split_pair_u<RELU>(in[KB0 + kb2][8 * tt2 + 2 * m], in[KB0 + kb2][8 * tt2 + 2 * m + 1], bh[t + 1][m], bl[t + 1][m]);
@@ -323,7 +362,11 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
           sb_l = e5 + 99u;               // ... and 2^-11 of it for the residuals
           const u32x16 hv = {bh[0][0], bh[0][1], bh[0][2], bh[0][3], bh[1][0], bh[1][1], bh[1][2], bh[1][3],
                              bh[2][0], bh[2][1], bh[2][2], bh[2][3], bh[3][0], bh[3][1], bh[3][2], bh[3][3]};
+#ifdef NJF_ABLATE_CVT6
+          const u32x6 x6 = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5]};
+#else
           const u32x6 x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, hv), __uint_as_float(sb_h << 23));
+#endif
           bh6 = i32x8{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
         }
         a[0] = n[0];
@@ -335,24 +378,34 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 #undef NJF_LDS
     i32x8 wl6_2 = f6frag(5), wl6_3 = f6frag(7);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef NJF_ABLATE_MFMA
+#define NJF_MFMA6(o, a6, b6, sel, sa, sb) asm volatile("" :: "v"(a6), "v"(b6), "v"(sa), "v"(sb))
+#else
+#define NJF_MFMA6(o, a6, b6, sel, sa, sb) o = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, b6, o, 2, 2, sel, (int)(sa), 0, (int)(sb))
+#endif
     // fragment idx = 2*m + w: w = 1 (fp6 of W_lo) pairs with x_hi6, w = 0 (fp6 of W_hi) with x_lo6; scale byte m of the
     // lane's scale dword is selected by the op_sel argument
-    out[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_0, bh6, out[0], 2, 2, 0, (int)s_w1, 0, (int)sb_h);
-    out[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_1, bh6, out[1], 2, 2, 1, (int)s_w1, 0, (int)sb_h);
+    NJF_MFMA6(out[0], wl6_0, bh6, 0, s_w1, sb_h);
+    NJF_MFMA6(out[1], wl6_1, bh6, 1, s_w1, sb_h);
     i32x8 wh6_0 = f6frag(0), wh6_1 = f6frag(2);
     const u32x16 lv = {bl[0][0], bl[0][1], bl[0][2], bl[0][3], bl[1][0], bl[1][1], bl[1][2], bl[1][3],
                        bl[2][0], bl[2][1], bl[2][2], bl[2][3], bl[3][0], bl[3][1], bl[3][2], bl[3][3]};
+#ifdef NJF_ABLATE_CVT6
+    const u32x6 y6 = {lv[0], lv[1], lv[2], lv[3], lv[4], lv[5]};
+#else
     const u32x6 y6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, lv), __uint_as_float(sb_l << 23));
+#endif
     const i32x8 bl6 = {(int)y6[0], (int)y6[1], (int)y6[2], (int)y6[3], (int)y6[4], (int)y6[5], 0, 0};
     __builtin_amdgcn_sched_barrier(0);
-    out[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_2, bh6, out[2], 2, 2, 2, (int)s_w1, 0, (int)sb_h);
-    out[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl6_3, bh6, out[3], 2, 2, 3, (int)s_w1, 0, (int)sb_h);
+    NJF_MFMA6(out[2], wl6_2, bh6, 2, s_w1, sb_h);
+    NJF_MFMA6(out[3], wl6_3, bh6, 3, s_w1, sb_h);
     i32x8 wh6_2 = f6frag(4), wh6_3 = f6frag(6);
     __builtin_amdgcn_sched_barrier(0);
-    out[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_0, bl6, out[0], 2, 2, 0, (int)s_w0, 0, (int)sb_l);
-    out[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_1, bl6, out[1], 2, 2, 1, (int)s_w0, 0, (int)sb_l);
-    out[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_2, bl6, out[2], 2, 2, 2, (int)s_w0, 0, (int)sb_l);
-    out[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh6_3, bl6, out[3], 2, 2, 3, (int)s_w0, 0, (int)sb_l);
+    NJF_MFMA6(out[0], wh6_0, bl6, 0, s_w0, sb_l);
+    NJF_MFMA6(out[1], wh6_1, bl6, 1, s_w0, sb_l);
+    NJF_MFMA6(out[2], wh6_2, bl6, 2, s_w0, sb_l);
+    NJF_MFMA6(out[3], wh6_3, bl6, 3, s_w0, sb_l);
+#undef NJF_MFMA6
     __builtin_amdgcn_sched_barrier(0);  // the matrix work of a chunk stays in front of the next chunk's barrier
   } else {
     // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
@@ -442,8 +495,21 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 }
 
 // acc[m][r] (+)= bias[16*MB*hh + 16*m + r]   (bias in LDS, logical order)
+// As ONE exact-fp32 MFMA per output block: acc[m] = B_m (x) e + acc[m], with the bias column as the A operand of a
+// 32x32x2 product (k = 0: the 32 biases of the block's rows, k = 1: multiplied by zero) against B = 1 for k = 0.  The
+// product bias x 1.0 is exact and is added to the accumulator with one rounding, i.e. the result is bit-identical to
+// the 16 v_mov / v_add per block it replaces (64 VALU instructions + 16 ds_read_b128 per 128-wide layer became
+// 4 ds_read_b32 + 4 MFMAs; the render kernel was issue-bound on exactly that kind of work: -0.5 ms of 6.9, measured
+// by ablation in profiles/r02_ablate.txt).  Row i of block m holds logical feature 16*MB*hh' + 16*m + 4*(i>>3) + (i&3)
+// with hh' = (i>>2)&1 (the accumulator layout of the 32x32 MFMAs: lane half hh owns rows 8*(r>>2) + 4*hh + (r&3)).
 template <int MB, bool ASSIGN>
 __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, f32x16 (&acc)[MB]) {
+#ifdef NJF_ABLATE_BIAS  // experiment builds only
+  if (ASSIGN)
+    for (int m = 0; m < MB; ++m) acc[m] = (f32x16)(0.f);
+  return;
+#endif
+#ifdef NJF_BIAS_VALU  // the round-1 form, kept for A/B builds
   const float* b = bl + 16 * MB * hh;
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
@@ -457,6 +523,17 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
       }
     }
   }
+#else
+  const int i = threadIdx.x & 31;
+  const float one = hh == 0 ? 1.f : 0.f;
+  const float* b = bl + 16 * MB * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    const float a = b[16 * m];
+    if (ASSIGN) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, (f32x16)(0.f), 0, 0, 0);
+    else acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, acc[m], 0, 0, 0);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -475,6 +552,8 @@ struct PointGeom {
   float xc, yc, zc;
   const CamCtx* cam;  // intrinsics (wave-uniform in the ray kernels: SGPRs)
   int hf, wf, stride;
+  unsigned gofs;      // float index of the point's batch element in the hoisted map (`gz` of the gathers is the map itself:
+                      // the lanes of a quad fetch each other's texels, and a tile of njf_points_forward may mix batch elements)
 };
 struct Footprint {
   int t00, t01, t10, t11;  // texel offsets (floats) into the feature map of this batch element
@@ -510,7 +589,8 @@ __device__ __forceinline__ float dot3(const float* r, float x, float y, float z)
 }
 
 __device__ __forceinline__ void point_geometry(const CamCtx& c, float px, float py, float pz, int hf, int wf,
-                                               int stride, PointGeom& g) {
+                                               int stride, unsigned gofs, PointGeom& g) {
+  g.gofs = gofs;
   g.xc = dot4_h(c.m + 0, px, py, pz);
   g.yc = dot4_h(c.m + 4, px, py, pz);
   g.zc = dot4_h(c.m + 8, px, py, pz);
@@ -553,19 +633,94 @@ __device__ __forceinline__ void point_footprint(const PointGeom& g, Footprint& f
   f.w11 = fy * fx;
 }
 
-// h += bilerp(G)[32*MB channels starting at `gz`].  Within a block of 32*MB channels the map stores logical
-// feature f = 16*MB*hh + 16*m + 4*q + e at position 32*m + 8*q + 4*hh + e (njf_hoist_position), so the two
-// lanes that own a point read ADJACENT 16-byte pieces in the same instruction: 32 distinct cache lines per
-// wave-instruction instead of 64 (the gather is TA tag-rate bound, not bandwidth bound).
+// h += bilerp(G)[32*MB channels starting at `gz`]: the pixel-aligned sampling of the hoisted map
+// (model_components/pixel_aligned_features.py:29-33 on G = lin_z(features)).
+//
+// The "quad" form (F16F6 networks).
+// Loads.  The 16*MB floats lane (j, hh) accumulates per texel are CONTIGUOUS in the map (njf_hoist_position, layout 1: logical
+// feature f = 16*MB*hh + 16*m + (4*e + i) sits at 16*MB*hh + 16*m + 4*i + e), and they are fetched by the lane's QUAD:
+// in load (slot s, segment m) the four lanes 4p..4p+3 read the four 16-byte pieces i = 0..3 of segment m of the texel of
+// lane 4p+s -- 64 contiguous bytes per quad.  The texture addresser coalesces adjacent lanes, not the lane pairs 32
+// apart that own a point: measured with ray-like texel coherence (tools/probes/probe_gather.hip), a 64-lane dwordx4
+// load costs 45 clocks CU-wide when every lane reads its own point's piece, 28 in this form; the gather phase of the
+// fused kernels is bound by exactly that rate (four waves of a workgroup reach it together, tools/stamps.py).
+//
+// Accumulation.  The loaded pieces sit in the wrong lanes (lane 4p+i holds piece i of lane 4p+s's texel); the matrix
+// core both moves and accumulates them: v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products, one per quad) with
+// A = the loaded dword, B = w_t * [lane % 4 == s], C = D = four accumulator registers gives lane n = s of the quad
+// D[i] += piece_i * w_t(own) for i = 0..3 and adds exact zeros in the other three lanes.  That replaces the 64*MB
+// v_fmac per gather of the round-1 form (the kernels are VALU-issue bound between the gathers) by 64*MB MFMAs of
+// 8 cycles on the otherwise idle fp32 matrix pipe.  The product-sum of the MFMA is not bit-identical to v_fmac (about
+// one value in five differs in the last bit); texel order t = 0..3 is kept.
+//
+// Pipelining.  A batch = (texel t, slot s): MB loads, 4*MB MFMAs.  DEPTH batches of loads are in flight (the registers
+// `net` vacates at this point of the block); sched_barrier pins the issue order, otherwise the scheduler hoists all 16*MB
+// loads (-> scratch) or serialises them.
+template <int S>
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S | (S << 2) | (S << 4) | (S << 6), 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned quad_bcast_n(unsigned v, int s) {  // s is a compile-time constant after unrolling
+  return s == 0 ? quad_bcast<0>(v) : (s == 1 ? quad_bcast<1>(v) : (s == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+}
+
 template <int MB>
-__device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int hh,
-                                                   f32x16 (&h)[MB]) {
+__device__ __forceinline__ void add_hoisted_latent_quad(const float* __restrict__ gz, const PointGeom& g, int lane,
+                                                        f32x16 (&h)[MB]) {
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
   return;
 #endif
   Footprint f;
   point_footprint(g, f);
-  const float* p[4] = {gz + f.t00 + 4 * hh, gz + f.t01 + 4 * hh, gz + f.t10 + 4 * hh, gz + f.t11 + 4 * hh};
+  const int c = lane & 3;
+  const unsigned lane_off = 16 * MB * (lane >> 5) + 4 * c;
+  // float index of this lane's four texels in the map (gofs: its batch element); a quad exchanges them by DPP
+  const unsigned gofs = g.gofs;
+  const unsigned own[4] = {gofs + (unsigned)f.t00, gofs + (unsigned)f.t01, gofs + (unsigned)f.t10, gofs + (unsigned)f.t11};
+  const float w[4] = {f.w00, f.w01, f.w10, f.w11};
+  constexpr int DEPTH = 4;
+  f32x4 x[DEPTH][MB];
+  auto issue = [&](int b) {
+    const float* src = gz + (size_t)(quad_bcast_n(own[b >> 2], b & 3) + lane_off);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) x[b % DEPTH][m] = *(const f32x4*)(src + 16 * m);
+  };
+#pragma unroll
+  for (int b = 0; b < DEPTH; ++b) issue(b);
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const float wb = c == (b & 3) ? w[b >> 2] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f32x4 d = {h[m][4 * e], h[m][4 * e + 1], h[m][4 * e + 2], h[m][4 * e + 3]};
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(x[b % DEPTH][m][e], wb, d, 0, 0, 0);
+        h[m][4 * e] = d[0];
+        h[m][4 * e + 1] = d[1];
+        h[m][4 * e + 2] = d[2];
+        h[m][4 * e + 3] = d[3];
+      }
+    if (b + DEPTH < 16) issue(b + DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+
+// The "half" form (every precision but F16F6): each lane fetches its own point's pieces and folds them with v_fmac.
+// Within a block of 32*MB channels the map stores logical feature f = 16*MB*hh + 16*m + 4*q + e at position
+// 32*m + 8*q + 4*hh + e (njf_hoist_position, layout 0), so the two lanes that own a point read ADJACENT 16-byte
+// pieces in the same instruction.
+template <int MB>
+__device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict__ gz, const PointGeom& g, int hh,
+                                                        f32x16 (&h)[MB]) {
+#ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
+  return;
+#endif
+  Footprint f;
+  point_footprint(g, f);
+  const float* gb = gz + (size_t)g.gofs + 4 * hh;
+  const float* p[4] = {gb + f.t00, gb + f.t01, gb + f.t10, gb + f.t11};
   const float w[4] = {f.w00, f.w01, f.w10, f.w11};
   // The gather is latency-bound: with NJF_GATHER_BATCH texels per batch, 4*MB*BATCH float4 loads are in flight
   // together (the registers `net` vacates at this point of the block), then folded into h.  The asm fence makes
@@ -611,6 +766,23 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 #pragma unroll
     for (int m = 0; m < MB; ++m) asm volatile("" : "+v"(h[m]) : : "memory");
   }
+}
+
+// Which form a network uses follows its MFMA precision (and so does the layout its lin_z columns are packed in,
+// njf_hoist_layout): the quad/MFMA form where the matrix pipe has headroom -- the fp6-corrected networks, measured
+// -3.8 % on the C2 final pass -- and the half/VALU form where it is the busier pipe (F16X2: the proposal pass measured
+// +5 % with the quad form; F32: the matrix pipe is the bound).
+template <int MB, int PREC>
+__device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int lane,
+                                                   f32x16 (&h)[MB]) {
+#if defined(NJF_GATHER_ALWAYS_HALF)  // A/B builds only (tools/ablate.sh)
+  add_hoisted_latent_half<MB>(gz, g, lane >> 5, h);
+#elif defined(NJF_GATHER_ALWAYS_QUAD)
+  add_hoisted_latent_quad<MB>(gz, g, lane, h);
+#else
+  if constexpr (PREC == PREC_F16F6) add_hoisted_latent_quad<MB>(gz, g, lane, h);
+  else add_hoisted_latent_half<MB>(gz, g, lane >> 5, h);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -738,7 +910,11 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
   for (int blk = 0; blk < 5; ++blk) {
-    if (blk < 3) add_hoisted_latent<4>(gz + blk * 128, g, hh, h);
+    if (blk < 3) {
+      NJF_STAMP(st, 4);  // gather begins (the stamp's own lgkmcnt(0) also ends the previous chunk's MFMA issue)
+      add_hoisted_latent<4, PREC>(gz + blk * 128, g, lane, h);
+      NJF_STAMP(st, 5);  // gather folded into h
+    }
     if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
     const float* bl = bias + blk * 256;
     bias_init<4, true>(bl, hh, net);
@@ -865,7 +1041,7 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
   x[1] = (f32x16)(0.f);
   const float* wl = stream_step(st, wave, lane);
   mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, pe, x);  // query MLP, PE part (bias in slot 63)
-  add_hoisted_latent<2>(gq, g, hh, x);            // query MLP, feature part (hoisted)
+  add_hoisted_latent<2, PREC>(gq, g, lane, x);    // query MLP, feature part (hoisted)
   for (int l = 0; l < 3; ++l) {
     const float* bl = bias + 256 * l;
     norm64(x, n);

@@ -220,33 +220,49 @@ __global__ void fill_kernel(float* p, int n, float v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
-// position of logical feature f inside its 32*MB-channel block of the hoisted map (see add_hoisted_latent)
-__host__ __device__ inline int njf_hoist_position(int f, int mb_count) {
+// position of logical feature f inside its 32*MB-channel block of the hoisted map.  Two layouts, one per gather form of
+// add_hoisted_latent (njf_device.h); a network's layout follows its MFMA precision:
+//   0 "half" (F32, F16X2): the two lanes that own a point read adjacent 16-byte pieces
+//   1 "quad" (F16F6): the 16*MB floats of a lane are contiguous, accumulator register 4*e + i <-> piece i, dword e
+#if defined(NJF_GATHER_ALWAYS_HALF)  // A/B builds only (tools/ablate.sh)
+__host__ __device__ inline int njf_hoist_layout(int) { return 0; }
+#elif defined(NJF_GATHER_ALWAYS_QUAD)
+__host__ __device__ inline int njf_hoist_layout(int) { return 1; }
+#else
+__host__ __device__ inline int njf_hoist_layout(int precision) { return precision == NJF_PRECISION_F16F6 ? 1 : 0; }
+#endif
+__host__ __device__ inline int njf_hoist_position(int f, int mb_count, int layout) {
   const int hh = f / (16 * mb_count), r = f % (16 * mb_count);
-  const int m = r >> 4, q = (r >> 2) & 3, e = r & 3;
-  return 32 * m + 8 * q + 4 * hh + e;
+  const int m = r >> 4;
+  if (layout == 0) {
+    const int q = (r >> 2) & 3, e = r & 3;
+    return 32 * m + 8 * q + 4 * hh + e;
+  }
+  const int e = (r >> 2) & 3, i = r & 3;
+  return 16 * mb_count * hh + 16 * m + 4 * i + e;
 }
 
 // the same function for callers that write hoisted channels themselves (per-image biases, folded projections)
-extern "C" int njf_hoisted_channel(int feature, int block_channels) {
+extern "C" int njf_hoisted_channel(int feature, int block_channels, int precision) {
   if (block_channels < 32 || (block_channels & 31) || feature < 0 || feature >= block_channels) return NJF_E_SHAPE;
-  return njf_hoist_position(feature, block_channels / 32);
+  if (!valid_base_precision(precision)) return NJF_E_MODE;
+  return njf_hoist_position(feature, block_channels / 32, njf_hoist_layout(precision));
 }
 
 // lin_z.{0,1,2}.weight [128,512] -> wz[k * ld + 128*i + pos(f)]  (k-major: coalesced B operand of the projection)
 __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
-                                 const float* b2, float* wz, int ld, float* bz) {
+                                 const float* b2, float* wz, int ld, float* bz, int layout) {
   const int n = 3 * 128 * 512;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int c = i % 384, k = i / 384;
     const int l = c >> 7, f = c & 127;
     const float* w = l == 0 ? w0 : (l == 1 ? w1 : w2);
-    wz[(size_t)k * ld + 128 * l + njf_hoist_position(f, 4)] = w[f * 512 + k];
+    wz[(size_t)k * ld + 128 * l + njf_hoist_position(f, 4, layout)] = w[f * 512 + k];
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < 384; c += blockDim.x) {
       const int l = c >> 7, f = c & 127;
-      bz[128 * l + njf_hoist_position(f, 4)] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f];
+      bz[128 * l + njf_hoist_position(f, 4, layout)] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f];
     }
 }
 
@@ -290,7 +306,7 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
     for (int i = 0; i < 3; ++i)
       if (!src->lin_z_w[i] || !src->lin_z_b[i]) return NJF_E_NULL;
     pack_linz_kernel<<<256, 256, 0, s>>>(src->lin_z_w[0], src->lin_z_w[1], src->lin_z_w[2], src->lin_z_b[0],
-                                         src->lin_z_b[1], src->lin_z_b[2], wz_out, wz_ld, bz_out);
+                                         src->lin_z_b[1], src->lin_z_b[2], wz_out, wz_ld, bz_out, njf_hoist_layout(P));
   }
   return launch_status();
 }
@@ -941,7 +957,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     const float se = start + end;
     const float px = ox + (dx * se) / 2.0f, py = oy + (dy * se) / 2.0f, pz = oz + (dz * se) / 2.0f;
     PointGeom g;
-    point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
+    point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, 0u, g);
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     f32x16 out[1];
@@ -1107,6 +1123,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   const int tiles = (S + 31) >> 5;
   WeightStream st;
   stream_begin(st, a.w_all, NJF_RESNET_CHUNKS + 1 + J_CHUNKS, tiles, wave, lane);
+#ifdef NJF_STAMPS
+  const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
+  if (stamping) st.stamp_i = 0;
+  NJF_STAMP(st, 9);
+#endif
 
   CamCtx cam;
   load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
@@ -1139,8 +1160,9 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     {
       SamplePlace sp;
       place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
-      point_geometry(cam, sp.px, sp.py, sp.pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, g);
+      point_geometry(cam, sp.px, sp.py, sp.pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, 0u, g);
     }
+    NJF_STAMP(st, 10);  // tile begins
     ActDump dump{nullptr, nullptr, 0};
     ColorDump cdump{nullptr, nullptr, 0};
     if (DUMP != 0 && store) {
@@ -1172,6 +1194,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
       if (a.out.density) a.out.density[si] = sigma;
     }
     // ---- colour head
+    NJF_STAMP(st, 11);  // density net + weights done
     {
       float rgb[3];
       color_stage<PREC, DUMP>(st, geo, dx, dy, dz, wave, lane, rgb, cdump);
@@ -1186,6 +1209,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
       }
     }
     // ---- Jacobian head -> scene flow
+    NJF_STAMP(st, 12);  // colour head done
     float flow[3] = {0.f, 0.f, 0.f};
     if (WITH_J) {
       f32x16 jac[1];
@@ -1218,6 +1242,13 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     }
   }
 
+#ifdef NJF_STAMPS
+  NJF_STAMP(st, 13);  // tiles done
+  if (stamping) {
+    for (int i = lane; i < NJF_STAMP_SLOTS; i += 64)
+      njf_stamp_out[i] = i < st.stamp_i ? __float_as_uint(njf_lds[LDS_FLOATS_RENDER + i]) : 0u;
+  }
+#endif
   // reduce over the ray's samples (32 lanes of a half; both halves hold identical per-sample data)
   acc_w = half_sum(acc_w);
   acc_wt = half_sum(acc_wt);
@@ -1331,13 +1362,14 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   load_ctx(a.cams.ctxt_w2c, a.cams.ctxt_k, b, cam);
   const float px = a.xyz[3 * (size_t)pc], py = a.xyz[3 * (size_t)pc + 1], pz = a.xyz[3 * (size_t)pc + 2];
   PointGeom g;
-  point_geometry(cam, px, py, pz, a.gmap.height, a.gmap.width, a.gmap.stride, g);
-  const size_t gbase = (size_t)b * a.gmap.height * a.gmap.width * a.gmap.stride;
+  // the batch element's offset travels with the point (PointGeom::gofs): the gathers take the map itself as base
+  const unsigned gbase = (unsigned)b * (unsigned)(a.gmap.height * a.gmap.width) * (unsigned)a.gmap.stride;
+  point_geometry(cam, px, py, pz, a.gmap.height, a.gmap.width, a.gmap.stride, gbase, g);
   const float* bias = njf_lds + LDS_BIAS;
   if (MODE == 0) {
     f32x16 pe[2], out[1];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    resnet_tile<PREC>(st, bias, a.gmap.data + gbase + a.goff_d, g, pe, wave, lane, out);
+    resnet_tile<PREC>(st, bias, a.gmap.data + a.goff_d, g, pe, wave, lane, out);
     if (ok && hh == 0 && a.density) a.density[p] = expf(out[0][0] - 1.0f);
   } else {
     float dx = 0.f, dy = 0.f, dz = 1.f;
@@ -1352,7 +1384,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
     const ActDump nodump{nullptr, nullptr, 0};
     // stage by stage, each result stored before the next network starts (nothing but the point itself stays live)
     f32x16 geo[1];
-    const float sigma = density_stage<PREC, 0>(st, a.gmap.data + gbase + a.goff_d, g, wave, lane, geo, nodump);
+    const float sigma = density_stage<PREC, 0>(st, a.gmap.data + a.goff_d, g, wave, lane, geo, nodump);
     if (ok && hh == 0) {
       if (a.density) a.density[p] = sigma;
       if (a.geo) {
@@ -1373,7 +1405,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
       f32x16 jac[1];
       float flow[3];
       // NOTE: `action` is per lane here (tiles may straddle batch elements)
-      jacobian_stage<JK, PRECJ, 0>(st, a.gmap.data + gbase + a.goff_j, g, action, A, wave, lane, jac, flow, nodump);
+      jacobian_stage<JK, PRECJ, 0>(st, a.gmap.data + a.goff_j, g, action, A, wave, lane, jac, flow, nodump);
       if (ok) {
         if (hh == 0 && a.flow) {
           a.flow[3 * (size_t)p] = flow[0];
@@ -1948,6 +1980,14 @@ static void lds_attribute_remember(const void* fn) {
   }
 }
 
+#ifdef NJF_STAMPS
+extern "C" int njf_debug_read_stamps(unsigned* host_out, int n) {
+  if (n > NJF_STAMP_SLOTS) n = NJF_STAMP_SLOTS;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(njf_stamp_out), (size_t)n * sizeof(unsigned));
+}
+#endif
+
 template <typename K, typename A>
 static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, int lds_floats = LDS_FLOATS_RENDER) {
   static_assert(sizeof(A) <= 4096, "kernel args too large");
@@ -1955,7 +1995,11 @@ static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, 
 #ifdef NJF_ABLATE_ONE_WG_PER_CU  // experiment builds only: pad LDS so a single 4-wave workgroup owns the CU
   const size_t lds = 100 * 1024;
 #else
+#ifdef NJF_STAMPS
+  const size_t lds = (size_t)(lds_floats + NJF_STAMP_SLOTS) * sizeof(float);
+#else
   const size_t lds = (size_t)lds_floats * sizeof(float);
+#endif
 #endif
   if (!lds_attribute_known((const void*)kernel)) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2121,6 +2165,8 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   if (!valid_precision(precision)) return NJF_E_MODE;
   int rc;
   if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
+  // a point carries the float index of its batch element in 32 bits (PointGeom::gofs): maps up to 16 GiB
+  if ((long long)cams->batch * gmap->height * gmap->width * gmap->stride > 0xffffffffLL) return NJF_E_SHAPE;
   PointsArgs a;
   a.xyz = xyz;
   a.dirs = dirs;

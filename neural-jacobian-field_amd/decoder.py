@@ -455,7 +455,7 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
         enc_dim = self.flow_head.d_latent - self.action_dim
         w_a = torch.stack([lin.weight[:, enc_dim:] for lin in self.flow_head.lin_z])       # [3,128,A]
         delta = torch.einsum("lfa,ba->blf", w_a, action.to(w_a.dtype))                       # [B,3,128] logical order
-        pos = hip.hoisted_channel_order(128, delta.device)                                   # njf_hoisted_channel
+        pos = hip.hoisted_channel_order(128, delta.device, self.j_precision)                 # njf_hoisted_channel
         permuted = torch.empty_like(delta)
         permuted[:, :, pos] = delta
         gmap = base.clone()
@@ -550,7 +550,7 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
         qw = self.jacobian_query_mlp.weight  # [64, 63 + 512], input = cat[xyz_features, pixel_aligned_features] (:421-427)
         hip.pack_linear(qw[:, :63].contiguous(), self.jacobian_query_mlp.bias, 1, half(0), precision=self.j_precision)
         # hoisted query channels use the same in-block order as lin_z (csrc: njf_hoist_position, MB=2)
-        pos = hip.hoisted_channel_order(64, qw.device)
+        pos = hip.hoisted_channel_order(64, qw.device, self.j_precision)
         wz[:, hip.ZDIM + pos] = qw[:, 63:].t()
         bz[hip.ZDIM:] = 0.0
         z = self.jacobian_index_embedding[0].double()  # [A, 64]

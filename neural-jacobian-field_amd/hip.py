@@ -111,7 +111,7 @@ _SIGNATURES = {
     "njf_project_features_ld": ([_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_project_pyramid": ([C.POINTER(PyramidLevel), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp],
                             C.c_int),
-    "njf_hoisted_channel": ([C.c_int, C.c_int], C.c_int),
+    "njf_hoisted_channel": ([C.c_int, C.c_int, C.c_int], C.c_int),
     "njf_upsample_concat": ([C.POINTER(PyramidLevel), C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_solve_action": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp], C.c_int),
     "njf_invert_4x4": ([_vp, C.c_int, _vp, _vp], C.c_int),
@@ -365,13 +365,15 @@ def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tenso
 _hoist_order_cache: Dict[tuple, torch.Tensor] = {}
 
 
-def hoisted_channel_order(block_channels: int, device) -> torch.Tensor:
-    """pos[f] = position of logical feature f inside a block of ``block_channels`` hoisted-map channels
-    (njf_hoisted_channel: the single definition of that order), as an index tensor on ``device``."""
-    key = (block_channels, str(device))
+def hoisted_channel_order(block_channels: int, device, precision: str) -> torch.Tensor:
+    """pos[f] = position of logical feature f inside a block of ``block_channels`` hoisted-map channels of a network
+    packed for MFMA ``precision`` (njf_hoisted_channel: the single definition of that order), as an index tensor on
+    ``device``."""
+    key = (block_channels, str(device), precision)
     if key not in _hoist_order_cache:
         lib = load_library()
-        pos = [lib.njf_hoisted_channel(f, block_channels) for f in range(block_channels)]
+        code = PRECISIONS[precision]
+        pos = [lib.njf_hoisted_channel(f, block_channels, code) for f in range(block_channels)]
         if min(pos) < 0:
             _check(min(pos))
         _hoist_order_cache[key] = torch.tensor(pos, dtype=torch.long, device=device)

@@ -28,24 +28,36 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 13
+    assert lib.njf_abi_version() == 14
 
 
 def test_hoisted_channel_order(built):
     """njf_hoisted_channel (a host function: runs without a GPU) is the one definition of the hoisted map's in-block
-    channel order; it must be the permutation the kernels' gather assumes (csrc/njf_device.h: add_hoisted_latent reads
-    logical feature 16*MB*hh + 16*m + 4*q + e at 32*m + 8*q + 4*hh + e) for both block widths in use."""
+    channel order; it must be the permutation the kernels' gather assumes (csrc/njf_device.h) for both block widths in use
+    and both gather forms: F32 / F16X2 networks read logical feature 16*MB*hh + 16*m + 4*q + e at 32*m + 8*q + 4*hh + e
+    (add_hoisted_latent_half), F16F6 networks accumulator register 4*e + i of block m at 16*MB*hh + 16*m + 4*i + e
+    (add_hoisted_latent_quad: piece i, dword e of the lane's contiguous 16*MB floats)."""
     lib = ctypes.CDLL(built)
+    F32, F16X2, F16F6 = 0, 1, 2
     for width in (128, 64):
         mb = width // 32
-        pos = [lib.njf_hoisted_channel(f, width) for f in range(width)]
+        for prec in (F32, F16X2):
+            pos = [lib.njf_hoisted_channel(f, width, prec) for f in range(width)]
+            assert sorted(pos) == list(range(width))
+            for hh in range(2):
+                for m in range(mb):
+                    for q in range(4):
+                        for e in range(4):
+                            assert pos[16 * mb * hh + 16 * m + 4 * q + e] == 32 * m + 8 * q + 4 * hh + e
+        pos = [lib.njf_hoisted_channel(f, width, F16F6) for f in range(width)]
         assert sorted(pos) == list(range(width))
         for hh in range(2):
             for m in range(mb):
-                for q in range(4):
-                    for e in range(4):
-                        assert pos[16 * mb * hh + 16 * m + 4 * q + e] == 32 * m + 8 * q + 4 * hh + e
-    assert lib.njf_hoisted_channel(128, 128) < 0 and lib.njf_hoisted_channel(0, 100) < 0 and lib.njf_hoisted_channel(-1, 64) < 0
+                for e in range(4):
+                    for i in range(4):
+                        assert pos[16 * mb * hh + 16 * m + 4 * e + i] == 16 * mb * hh + 16 * m + 4 * i + e
+    assert lib.njf_hoisted_channel(128, 128, 0) < 0 and lib.njf_hoisted_channel(0, 100, 0) < 0 and lib.njf_hoisted_channel(-1, 64, 0) < 0
+    assert lib.njf_hoisted_channel(0, 128, 3) < 0 and lib.njf_hoisted_channel(0, 128, 0x21) < 0   # base precisions only
 
 
 def test_flow_mlp_action_fold_is_exact_algebra():
@@ -381,7 +393,7 @@ def test_header_is_plain_c(tmp_path, built):
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == len(names) and int(out[1]) == 13
+    assert int(out[0]) == len(names) and int(out[1]) == 14
 
 
 def test_static_isa_properties_of_the_fused_kernels():
