@@ -1029,7 +1029,12 @@ __device__ __forceinline__ void jacobian_stage(WeightStream& st, const float* __
   // the encoding is recomputed (~1 % of the head's time) rather than held in 32 VGPRs across density + colour
   asm volatile("" ::: "memory");
   f32x16 pe[2];
+  NJF_STAMP(st, 6);  // Jacobian stage begins
   positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+#ifdef NJF_STAMPS
+  asm volatile("" : "+v"(pe[0]), "+v"(pe[1]));
+#endif
+  NJF_STAMP(st, 7);  // encoding done
   if (JKIND == 1)
     resnet_tile<PREC, DUMP == 1>(st, bias, gz_j, g, pe, wave, lane, jac, dump);
   else {
@@ -1178,7 +1183,12 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     {
       SamplePlace sp;
       place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      NJF_STAMP(st, 14);  // density net returned
       w = tile_weights(sp.delta, sigma, valid, j, carry);
+#ifdef NJF_STAMPS
+      asm volatile("" : "+v"(w));
+#endif
+      NJF_STAMP(st, 15);  // weights done
       if (valid) {
         acc_w += w;
         acc_wt = fmaf(w, sp.tm, acc_wt);

@@ -11,6 +11,40 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
+def ulp_nudged(t):
+    """Every element moved by one unit in the last place (towards +inf): the smallest input change any fp32
+    implementation of the ray generation may produce."""
+    return torch.nextafter(t, torch.full_like(t, float("inf")))
+
+
+def noisy(t, scale=1e-5, seed=1234):
+    """t * (1 + scale * n), n ~ N(0,1) seeded: the size of the difference between two fp32 encoders (MIOpen's Winograd
+    convolutions vs ATen's CPU ones) -- the same 1e-5 the output floors of tests/golden/make_golden_r02.py use."""
+    g = torch.Generator().manual_seed(seed)
+    return t * (1.0 + scale * torch.randn(t.shape, generator=g))
+
+
+FLOOR_MODES = ("fp64", "rays", "features")
+
+
+def gradient_floor(run_oracle_backward, names):
+    """What fp32 arithmetic itself costs the ORACLE's gradients: its fp32 run against its own float64 run ("fp64": the
+    ds-nerf depth loss differentiates log(w + eps) of tiny weights, ~2e-3 on its own), and how far its fp32 gradients move
+    under input changes no fp32 implementation can avoid -- the rays moved by one ulp ("rays": the samplers' inverse-CDF
+    placement and the 2*pi*512-gain encoding amplify it) and the encoder's output / input moved by 1e-5 ("features").
+    `run_oracle_backward(mode)` returns {name: gradient}; the floor of a parameter is the largest of the three."""
+    base = run_oracle_backward(None)
+    moved = [run_oracle_backward(mode) for mode in FLOOR_MODES]
+    return {n: max(rel(m[n], base[n]) for m in moved) for n in names}, base
+
+
+def as_dtype(mode):
+    """Tensor converter of an oracle run: float64 for the "fp64" floor, identity otherwise."""
+    if mode == "fp64":
+        return lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+    return lambda t: t
+
+
 @pytest.fixture(scope="module")
 def setup():
     if not torch.cuda.is_available():
@@ -46,7 +80,7 @@ def setup():
     return dict(model=model, case=case, full=full, image=image, target=target, cam=cam, rin=rin, rob=rob, dev=dev, S=S)
 
 
-def test_action_mode_gradients_match_oracle_autograd(setup):
+def test_action_mode_gradients_match_oracle_autograd(setup, margins):
     import njf_oracle as orc
     import parity_harness as ph
     from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
@@ -57,27 +91,38 @@ def test_action_mode_gradients_match_oracle_autograd(setup):
     loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))
     loss.backward()
     # oracle: same weights, encoder features from the oracle's own encoder, autograd through everything
-    params = {k: v.clone() for k, v in s["full"].items()}
-    for k in params:
-        if k.startswith("decoder.jacobian_head."):
-            params[k].requires_grad_(True)
     c = case["cams"]
-    ref = orc.model_forward(params, input_image=s["image"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
-                            trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
-                            directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=case["action"],
-                            num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_mlp")
-    ref_loss = orc.flow_loss(ref.optical_flow, s["target"])
-    ref_loss.backward()
-    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3
+    losses = {}
+
+    with torch.no_grad():
+        feats = orc.encoder_features({k[len("encoder."):]: v for k, v in s["full"].items() if k.startswith("encoder.")}, s["image"])
+
+    def oracle_backward(mode):
+        cv = as_dtype(mode)
+        params = {k: cv(v.clone()) for k, v in s["full"].items()}
+        for k in params:
+            if k.startswith("decoder.jacobian_head."):
+                params[k].requires_grad_(True)
+        origins = ulp_nudged(case["origins"]) if mode == "rays" else case["origins"]
+        ref = orc.model_forward(params, features=cv(noisy(feats) if mode == "features" else feats),
+                                ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
+                                trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
+                                directions=cv(case["directions"]), z_near=cv(c["z_near"]), z_far=cv(c["z_far"]),
+                                action=cv(case["action"]),
+                                num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_mlp")
+        ref_loss = orc.flow_loss(ref.optical_flow, cv(s["target"]))
+        ref_loss.backward()
+        losses[mode] = ref_loss.detach().reshape(1)
+        return {n: params["decoder.jacobian_head." + n].grad for n in JACOBIAN_PARAM_ORDER}
+
+    floor, g_ref = gradient_floor(oracle_backward, JACOBIAN_PARAM_ORDER)
+    margins("train.action[jacobian_mlp]", "loss", loss.reshape(1), losses[None],
+            floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES))
     head = dict(model.decoder.jacobian_head.named_parameters())
-    worst = 0.0
     for name in JACOBIAN_PARAM_ORDER:
-        g_hip, g_ref = head[name].grad, params["decoder.jacobian_head." + name].grad
-        assert g_hip is not None and torch.isfinite(g_hip).all(), name
-        worst = max(worst, rel(g_hip, g_ref))
-    # bound: sample locations differ by ~1e-6 between the two implementations and feed a 2*pi*512-gain encoding
-    print("worst relative gradient error", worst)
-    assert worst < 5e-3, worst
+        assert head[name].grad is not None and torch.isfinite(head[name].grad).all(), name
+        # bound: twice the oracle's own movement under one-ulp rays (sample locations feed a 2*pi*512-gain encoding)
+        margins("train.action[jacobian_mlp]", "grad " + name, head[name].grad, g_ref[name], floor=floor[name])
     # frozen parameters received no gradient
     assert all(p.grad is None for n, p in model.named_parameters() if "jacobian_head" not in n)
 
@@ -112,7 +157,7 @@ def test_flow_backward_outside_action_mode_is_refused_loudly(setup):
         model.zero_grad(set_to_none=True)
 
 
-def test_perception_mode_gradients_match_oracle_autograd(setup):
+def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
     """Reference perception mode (model_wrapper.py:117-146): every parameter trains; the losses read rgb, depth and
     the per-level weights.  HIP forward with activation dumps + GEMM backward, against autograd through the CPU oracle
     (encoder included).  Deterministic (un-jittered) samples so both sides place the same points."""
@@ -157,22 +202,35 @@ def test_perception_mode_gradients_match_oracle_autograd(setup):
         for w_g, w_i in zip(tr.weights_list, inf.training_output.weights_list):
             assert rel(w_g, w_i) < 2e-3
 
-        params = {k: v.clone() for k, v in s["full"].items()}
-        for k, v in params.items():
-            if v.is_floating_point() and "running_" not in k:
-                v.requires_grad_(True)
         c = case["cams"]
-        ref = orc.model_forward(params, input_image=s["image"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
-                                trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
-                                directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=case["action"],
-                                num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_mlp")
-        ref_loss = loss_fn(ref.rgb, ref.depth, ref.weights_list, [(x.starts, x.ends) for x in ref.samples_list], lambda t: t)
-        ref_loss.backward()
-        assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3, (loss.item(), ref_loss.item())
+        losses = {}
+        names = [n for n, _ in model.named_parameters()]
 
-        worst = {}
+        def oracle_backward(mode):
+            cv = as_dtype(mode)
+            params = {k: cv(v.clone()) for k, v in s["full"].items()}
+            for k, v in params.items():
+                if v.is_floating_point() and "running_" not in k:
+                    v.requires_grad_(True)
+            origins = ulp_nudged(case["origins"]) if mode == "rays" else case["origins"]
+            image = noisy(s["image"]) if mode == "features" else s["image"]   # the encoder trains: its INPUT moves
+            ref = orc.model_forward(params, input_image=cv(image), ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
+                                    trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
+                                    directions=cv(case["directions"]), z_near=cv(c["z_near"]), z_far=cv(c["z_far"]),
+                                    action=cv(case["action"]),
+                                    num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_mlp")
+            ref_loss = loss_fn(ref.rgb, ref.depth, ref.weights_list, [(x.starts, x.ends) for x in ref.samples_list], cv)
+            ref_loss.backward()
+            losses[mode] = ref_loss.detach().reshape(1)
+            return {n: params[n].grad for n in names}
+
+        base = oracle_backward(None)
+        moved = [oracle_backward(mode) for mode in FLOOR_MODES]
+        margins("train.perception", "loss", loss.reshape(1), losses[None],
+                floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES))
+        groups = {}
         for name, p in model.named_parameters():
-            g_ref = params[name].grad
+            g_ref = base[name]
             if g_ref is None or name.startswith("decoder.jacobian_head."):
                 # not on the differentiated path: the Jacobian head (optical_flow is not in a perception loss), and
                 # ResNet-34's layer4 / fc, which EncoderResnet (num_layers=4) never evaluates
@@ -180,10 +238,24 @@ def test_perception_mode_gradients_match_oracle_autograd(setup):
                 continue
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
             group = name.split(".")[0] + "." + name.split(".")[1]
-            worst[group] = max(worst.get(group, 0.0), rel(p.grad, g_ref))
-        print("worst relative gradient error per group", worst)
-        # bound: sample locations differ by ~1e-6 between the implementations and feed a 2*pi*512-gain encoding
-        assert max(worst.values()) < 1e-2, worst
+            e, f = rel(p.grad, g_ref), max(rel(m[name], g_ref) for m in moved)
+            worst = groups.setdefault(group, {"err": 0.0, "floor": 0.0})
+            if e > worst["err"]:
+                worst.update(err=e, at=name)
+            if __import__("os").environ.get("NJF_TEST_VERBOSE"):
+                print(f"  {name:60s} err {e:.3e} floor {f:.3e}")
+            worst["floor"] = max(worst["floor"], f)
+        print("worst relative gradient error per group", groups)
+        # bound per parameter group: twice the oracle's own fp32 floor (its float64 run; one-ulp rays; a 1e-5 image
+        # perturbation); err = the group's worst parameter, floor = the group's largest floor
+        rows = []
+        for group, w in groups.items():
+            limit = max(1e-4, 2.0 * w["floor"])
+            rows.append({"key": "grad " + group, "err": float(f"{w['err']:.3e}"), "floor": float(f"{w['floor']:.3e}"),
+                         "floor_fp64": 0.0, "limit": float(f"{limit:.3e}"), "needs_floor": bool(w["err"] > 1e-4),
+                         "ok": bool(w["err"] <= limit)})
+        margins.record("train.perception", rows)
+        assert all(r["ok"] for r in rows), rows
     finally:
         for n, p in model.named_parameters():
             p.requires_grad = req[n]
@@ -268,7 +340,7 @@ def test_wrapper_training_step_perception_and_action(setup):
         model.eval()
 
 
-def test_transformer_action_mode_gradients_match_oracle_autograd(setup):
+def test_transformer_action_mode_gradients_match_oracle_autograd(setup, margins):
     """jacobian_transformer (the shipped Allegro decoder, model_allegro.yaml:26) in action mode: the kernel evaluates
     the folded head, the backward pass recomputes the un-folded head on the dumped encoding + footprint; gradients of
     every "jacobian*" parameter against autograd through the CPU oracle."""
@@ -295,21 +367,34 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup):
     loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))
     loss.backward()
 
-    params = {k: v.clone() for k, v in full.items()}
-    for k in trainable:
-        params[k].requires_grad_(True)
     c = case["cams"]
-    ref = orc.model_forward(params, input_image=s["image"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
-                            trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
-                            directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=action,
-                            num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_transformer")
-    ref_loss = orc.flow_loss(ref.optical_flow, s["target"])
-    ref_loss.backward()
-    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3
+    losses = {}
+
+    with torch.no_grad():
+        feats = orc.encoder_features({k[len("encoder."):]: v for k, v in full.items() if k.startswith("encoder.")}, s["image"])
+
+    def oracle_backward(mode):
+        cv = as_dtype(mode)
+        params = {k: cv(v.clone()) for k, v in full.items()}
+        for k in trainable:
+            params[k].requires_grad_(True)
+        origins = ulp_nudged(case["origins"]) if mode == "rays" else case["origins"]
+        ref = orc.model_forward(params, features=cv(noisy(feats) if mode == "features" else feats),
+                                ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
+                                trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
+                                directions=cv(case["directions"]), z_near=cv(c["z_near"]), z_far=cv(c["z_far"]), action=cv(action),
+                                num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_transformer")
+        ref_loss = orc.flow_loss(ref.optical_flow, cv(s["target"]))
+        ref_loss.backward()
+        losses[mode] = ref_loss.detach().reshape(1)
+        return {k: params[k].grad for k in trainable}
+
+    floor, g_ref = gradient_floor(oracle_backward, trainable)
+    margins("train.action[jacobian_transformer]", "loss", loss.reshape(1), losses[None],
+            floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES))
     named = dict(model.named_parameters())
-    worst = max(rel(named[k].grad, params[k].grad) for k in trainable)
-    print("worst relative gradient error (transformer head)", worst)
-    assert worst < 5e-3, worst
+    for k in trainable:
+        margins("train.action[jacobian_transformer]", "grad " + k, named[k].grad, g_ref[k], floor=floor[k])
     assert all(p.grad is None for n, p in named.items() if n not in trainable)
 
 
