@@ -38,7 +38,9 @@ DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16f6")
 def proposal_precision_for(precision: str) -> str:
     """The proposal networks' precision that goes with a decoder precision: the same, except that "f16f6" keeps sample
     PLACEMENT on "f16x2" (an error of 1e-5 in the proposal weights moves samples enough to show up as 3e-4 in depth / flow
-    through the positional encoding's 2*pi*512 gain; inside the final pass the same error stays 1e-5)."""
+    through the positional encoding's 2*pi*512 gain; inside the final pass the same error stays 1e-5).  Re-measured in
+    round 2 with the proposal pass forced to "f16f6": depth 3.0e-4 against a bound of 1.0e-4, optical flow 7.8e-4 against
+    3.6e-4 (parity cases 1 and 4) for a proposal pass of 3.16 instead of 3.80 ms -- not adopted."""
     return "f16x2" if precision == "f16f6" else precision
 
 
