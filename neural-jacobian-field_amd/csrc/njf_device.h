@@ -495,13 +495,13 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 }
 
 // acc[m][r] (+)= bias[16*MB*hh + 16*m + r]   (bias in LDS, logical order)
-// As ONE exact-fp32 MFMA per output block: acc[m] = B_m (x) e + acc[m], with the bias column as the A operand of a
-// 32x32x2 product (k = 0: the 32 biases of the block's rows, k = 1: multiplied by zero) against B = 1 for k = 0.  The
-// product bias x 1.0 is exact and is added to the accumulator with one rounding, i.e. the result is bit-identical to
-// the 16 v_mov / v_add per block it replaces (64 VALU instructions + 16 ds_read_b128 per 128-wide layer became
-// 4 ds_read_b32 + 4 MFMAs; the render kernel was issue-bound on exactly that kind of work: -0.5 ms of 6.9, measured
-// by ablation in profiles/r02_ablate.txt).  Row i of block m holds logical feature 16*MB*hh' + 16*m + 4*(i>>3) + (i&3)
-// with hh' = (i>>2)&1 (the accumulator layout of the 32x32 MFMAs: lane half hh owns rows 8*(r>>2) + 4*hh + (r&3)).
+// ASSIGN (the accumulator starts at the bias): 16-byte LDS reads straight into the accumulator registers, no VALU work.
+// Accumulate (h += b1 of a block's second layer): ONE exact-fp32 MFMA per output block, acc[m] += B_m (x) e, with the
+// bias column as the A operand of a 32x32x2 product (k = 0: the 32 biases of the block's rows, k = 1: multiplied by zero)
+// against B = 1 for k = 0.  bias x 1.0 is exact and is added with one rounding: bit-identical to the 16 v_add per block it
+// replaces, on the matrix pipe instead of the VALU (the chunk phases of the fused kernels are issue-bound on VALU work;
+// A/B in profiles/r02_ab_variants.txt).  Row i of block m holds logical feature 16*MB*hh' + 16*m + 4*(i>>3) + (i&3) with
+// hh' = (i>>2)&1 (the accumulator layout of the 32x32 MFMAs: lane half hh owns rows 8*(r>>2) + 4*hh + (r&3)).
 template <int MB, bool ASSIGN>
 __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, f32x16 (&acc)[MB]) {
 #ifdef NJF_ABLATE_BIAS  // experiment builds only
@@ -509,31 +509,38 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
     for (int m = 0; m < MB; ++m) acc[m] = (f32x16)(0.f);
   return;
 #endif
-#ifdef NJF_BIAS_VALU  // the round-1 form, kept for A/B builds
-  const float* b = bl + 16 * MB * hh;
+#if defined(NJF_BIAS_MFMA_ALL)  // A/B builds only
+  constexpr bool VALU = false;
+#elif defined(NJF_BIAS_VALU)
+  constexpr bool VALU = true;
+#else
+  constexpr bool VALU = ASSIGN;
+#endif
+  if constexpr (VALU) {
+    const float* b = bl + 16 * MB * hh;
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
+    for (int m = 0; m < MB; ++m) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = *(const f32x4*)(b + 16 * m + 4 * q);
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *(const f32x4*)(b + 16 * m + 4 * q);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (ASSIGN) acc[m][4 * q + e] = v[e];
-        else acc[m][4 * q + e] += v[e];
+        for (int e = 0; e < 4; ++e) {
+          if (ASSIGN) acc[m][4 * q + e] = v[e];
+          else acc[m][4 * q + e] += v[e];
+        }
       }
     }
-  }
-#else
-  const int i = threadIdx.x & 31;
-  const float one = hh == 0 ? 1.f : 0.f;
-  const float* b = bl + 16 * MB * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+  } else {
+    const int i = threadIdx.x & 31;
+    const float one = hh == 0 ? 1.f : 0.f;
+    const float* b = bl + 16 * MB * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    const float a = b[16 * m];
-    if (ASSIGN) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, (f32x16)(0.f), 0, 0, 0);
-    else acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, acc[m], 0, 0, 0);
+    for (int m = 0; m < MB; ++m) {
+      const float a = b[16 * m];
+      if (ASSIGN) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, (f32x16)(0.f), 0, 0, 0);
+      else acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, acc[m], 0, 0, 0);
+    }
   }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
