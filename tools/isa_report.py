@@ -22,7 +22,7 @@ import __graft_entry__ as entry  # noqa: E402
 SRC = os.path.join(entry.CSRC, "njf_kernels.hip")
 FLAGS = [f for f in entry.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + sys.argv[1:]
 KERNELS = ["render_kernel", "proposal_kernel", "points_kernel", "project_kernel", "solve_action_kernel",
-           "scatter_footprint_kernel", "relu_backward_kernel", "upsample_concat_kernel"]
+           "scatter_footprint_kernel", "relu_backward_kernel", "upsample_concat_kernel", "resnetfc_backward_kernel"]
 
 
 def demangle(names):

@@ -69,9 +69,11 @@ for k in ("proposal", "render"):
     lines += [f"### {k}",
               f"* effective clock {clock/1e9:.2f} GHz; issued MFMA work {flop/1e12:.3f} TFLOP (incl. zero padding) "
               f"= {flop/dur[k]/1e12:.1f} TFLOP/s",
-              f"* MFMA pipe utilisation: {100*mfma_util_insts:.1f} % from SQ_INSTS_MFMA x {MFMA_CYCLES} cycles / (1024 SIMDs x "
-              f"kernel-trace duration x 2.4 GHz); {100*mfma_util:.1f} % from SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE/8) "
-              f"(the GRBM figure is taken in a slower counter-collection run, so this ratio and the 'effective clock' are indicative only)",
+              f"* MFMA pipe utilisation: {100*mfma_util:.1f} % from SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE/8) (the GRBM "
+              f"figure is taken in a slower counter-collection run, so this ratio and the 'effective clock' are indicative only); "
+              f"SQ_INSTS_MFMA x {MFMA_CYCLES} cycles / (1024 SIMDs x kernel-trace duration x 2.4 GHz) = {100*mfma_util_insts:.1f} % is "
+              f"an UPPER bound since round 2: the instruction count mixes {MFMA_CYCLES}-cycle products with the 8-cycle 4x4x1 "
+              f"MFMAs of the f16f6 gather (6 x 256 per 32-point tile) and the 64-cycle fp32 bias MFMAs",
               f"* wave time: issue-stall {100*mean[(k,'SQ_WAIT_INST_ANY')]/wc:.0f} %, waitcnt/barrier "
               f"{100*mean[(k,'SQ_WAIT_ANY')]/wc:.0f} %, issuing {100*mean[(k,'SQ_ACTIVE_INST_ANY')]/wc:.0f} % "
               f"(VALU {100*mean.get((k,'SQ_ACTIVE_INST_VALU'),0)/wc:.0f} %, LDS {100*mean.get((k,'SQ_ACTIVE_INST_LDS'),0)/wc:.0f} %, "
