@@ -58,21 +58,36 @@ k_pix = geometry.denormalize_intrinsics(d(cams["trgt_k_norm"]), W, H)
 ctxt_w2c, trgt_w2c = torch.linalg.inv(ctxt_c2w), torch.linalg.inv(trgt_c2w)
 dp = {k: d(v) for k, v in params.items()}
 results, ref = {}, None
+
+
+def kernel_ms(records, steps):
+    """Mean duration per step of the fused launches, from the per-launch HIP events hip.set_profile_sink collects."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in records:
+        key = {"njf_proposal_forward": "proposal_ms", "njf_render_forward": "render_ms"}.get(name)
+        if key:
+            out[key] = out.get(key, 0.0) + e0.elapsed_time(e1)
+    return {k: round(v / steps, 3) for k, v in out.items()}
+
+
 for prec in PRECS:
-    fr = FusedRenderer(dev, 1, A, precision=prec)
+    fr = FusedRenderer(dev, 1, A, precision=prec)   # sets the whole model (proposal pass included) to `prec`'s policy
     fr.load_weights(dp)
     gmap = fr.project(feats)
     steps = 3 if prec == "f32" else 8
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
-    for i in range(2 + steps):
-        res = fr.render(gmap, origins, directions, ctxt_c2w, ctxt_k, z_near, z_far, [S], S, trgt_c2w=trgt_c2w, trgt_k_pix=k_pix,
-                        action=action, ctxt_w2c=ctxt_w2c, trgt_w2c=trgt_w2c, _events=ev[i - 2] if i >= 2 else None)
-    torch.cuda.synchronize()
-    prop = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
-    rend = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    render = lambda: fr.render(gmap, origins, directions, ctxt_c2w, ctxt_k, z_near, z_far, [S], S, trgt_c2w=trgt_c2w,
+                               trgt_k_pix=k_pix, action=action, ctxt_w2c=ctxt_w2c, trgt_w2c=trgt_w2c)
+    for _ in range(2):
+        res = render()
+    launches = []
+    hip.set_profile_sink(launches)
+    for _ in range(steps):
+        res = render()
+    hip.set_profile_sink(None)
     if ref is None:
         ref = res
-    results[prec] = dict(proposal_ms=round(prop, 3), render_ms=round(rend, 3),
+    results[prec] = dict(**kernel_ms(launches, steps),
                          rgb_vs_f32=ph.rel_err(res.rgb, ref.rgb), depth_vs_f32=ph.rel_err(res.depth, ref.depth),
                          flow_vs_f32=ph.rel_err(res.optical_flow, ref.optical_flow))
     print("C2", prec, json.dumps(results[prec]))
