@@ -36,6 +36,25 @@ def test_fused_forward_matches_oracle(device, case_id, precision, margins):
     assert rep["ok"], {k: v for k, v in rep.items() if k != "rows"}
 
 
+RAGGED = [
+    dict(batch=3, height=16, width=20, rays=37, s_prop=40, s_final=48),                 # half-empty second tile, odd ray count
+    dict(batch=1, height=16, width=16, rays=5, s_prop=33, s_final=31),                  # one sample into a tile / one short of it
+    dict(batch=5, height=16, width=16, rays=1, s_prop=64, s_final=65, action_dim=3),    # one ray per image, 3 tiles, A = 3
+]
+
+
+@pytest.mark.parametrize("shape", range(len(RAGGED)))
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ragged_shapes_match_oracle(device, shape, precision, margins):
+    """Sample counts that do not fill the 32-point tiles, ray counts that do not fill the 4-wave workgroups, a batch of
+    single rays: the clamped lanes of a partial tile still take part in the quad gather and the scans (the bound's floors
+    come from the oracle's own float64 run here: these shapes are not in the reference-generated harness fixture)."""
+    import parity_harness as ph
+    rep = ph.run_parity_case(device=device, tol=TOL, precision=precision, **RAGGED[shape])
+    margins.record(f"parity[ragged{shape}:{precision}]", rep["rows"])
+    assert rep["ok"], {k: v for k, v in rep.items() if k != "rows"}
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_reference_initialisation_of_the_jacobian_head(device, precision, margins):
     """The reference initialises every Linear of the Jacobian head with N(0, 1e-4) weights AND biases
