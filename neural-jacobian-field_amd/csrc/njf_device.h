@@ -94,11 +94,16 @@ struct WeightStream {
 // bits of s_memtime) words, logged to a spare LDS area and copied out by the render kernel when the wave retires.
 #ifdef NJF_STAMPS
 #define NJF_STAMP_SLOTS 1024
+#ifdef NJF_STAMPS_PROPOSAL   // log a wave of the proposal kernel (its LDS use ends higher than the render kernel's)
+#define NJF_STAMP_BASE LDS_FLOATS_PROPOSAL
+#else
+#define NJF_STAMP_BASE LDS_FLOATS_RENDER
+#endif
 __device__ unsigned njf_stamp_out[NJF_STAMP_SLOTS];
 #define NJF_STAMP(st, tag)                                                                                   \
   do {                                                                                                       \
     if ((st).stamp_i >= 0 && (st).stamp_i < NJF_STAMP_SLOTS) {                                               \
-      njf_lds[LDS_FLOATS_RENDER + (st).stamp_i] =                                                            \
+      njf_lds[NJF_STAMP_BASE + (st).stamp_i] =                                                               \
           __uint_as_float(((unsigned)(tag) << 24) | ((unsigned)__builtin_readcyclecounter() & 0xffffffu));   \
       (st).stamp_i += 1;                                                                                     \
     }                                                                                                        \

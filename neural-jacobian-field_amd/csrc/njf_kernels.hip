@@ -933,6 +933,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
   const int tiles = (a.s_in + 31) >> 5;
   WeightStream st;
   stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane);
+#ifdef NJF_STAMPS_PROPOSAL
+  const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
+  if (stamping) st.stamp_i = 0;
+  NJF_STAMP(st, 9);
+#endif
 
   CamCtx cam;
   load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
@@ -958,6 +963,9 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     const float px = ox + (dx * se) / 2.0f, py = oy + (dy * se) / 2.0f, pz = oz + (dz * se) / 2.0f;
     PointGeom g;
     point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, 0u, g);
+#ifdef NJF_STAMPS_PROPOSAL
+    NJF_STAMP(st, 10);
+#endif
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     f32x16 out[1];
@@ -966,6 +974,9 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
       dump = point_dump(a.dump, (size_t)ray * a.s_in + s, (size_t)a.rc.total_rays * a.s_in, hh, g,
                         b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
     resnet_tile<PREC, DUMP>(st, bias, gz, g, pe, wave, lane, out, dump);
+#ifdef NJF_STAMPS_PROPOSAL
+    NJF_STAMP(st, 14);
+#endif
     const float pre = __shfl(out[0][0], j, 64);
     const float sigma = expf(pre - 1.0f);
     const float w = tile_weights(end - start, sigma, valid, j, carry);
@@ -979,9 +990,19 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
       }
     }
   }
+#ifdef NJF_STAMPS_PROPOSAL
+  NJF_STAMP(st, 13);
+#endif
   __syncthreads();
   const float* u = a.u + (a.u_per_ray ? (size_t)rayc * (a.s_out + 1) : 0);
   pdf_resample_ray(sc, bins, a.s_in, u, a.s_out, a.bins_out + (size_t)rayc * (a.s_out + 1), lane, ray_ok);
+#ifdef NJF_STAMPS_PROPOSAL
+  NJF_STAMP(st, 15);
+  if (stamping) {
+    for (int i = lane; i < NJF_STAMP_SLOTS; i += 64)
+      njf_stamp_out[i] = i < st.stamp_i ? __float_as_uint(njf_lds[NJF_STAMP_BASE + i]) : 0u;
+  }
+#endif
 }
 
 // =============================================================================================
@@ -1129,7 +1150,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   WeightStream st;
   stream_begin(st, a.w_all, NJF_RESNET_CHUNKS + 1 + J_CHUNKS, tiles, wave, lane);
 #ifdef NJF_STAMPS
+#ifdef NJF_STAMPS_PROPOSAL
+  const bool stamping = false;  // that build logs a wave of the proposal kernel instead
+#else
   const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
+#endif
   if (stamping) st.stamp_i = 0;
   NJF_STAMP(st, 9);
 #endif
@@ -1256,7 +1281,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   NJF_STAMP(st, 13);  // tiles done
   if (stamping) {
     for (int i = lane; i < NJF_STAMP_SLOTS; i += 64)
-      njf_stamp_out[i] = i < st.stamp_i ? __float_as_uint(njf_lds[LDS_FLOATS_RENDER + i]) : 0u;
+      njf_stamp_out[i] = i < st.stamp_i ? __float_as_uint(njf_lds[NJF_STAMP_BASE + i]) : 0u;
   }
 #endif
   // reduce over the ray's samples (32 lanes of a half; both halves hold identical per-sample data)

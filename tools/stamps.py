@@ -33,7 +33,7 @@ for tag, x in ev:
         base += 1 << 24
     prev = x
     t.append(base + x)
-names = {6: "jac<", 7: "pe>", 14: "sigma", 15: "weights", 1: "issued", 2: "drained", 3: "barrier", 4: "gather<", 5: "gather>", 9: "begin", 10: "tile", 11: "density.", 12: "colour.", 13: "end"}
+names = {6: "jac<", 7: "pe>", 14: "sigma", 15: "weights|pdf>", 1: "issued", 2: "drained", 3: "barrier", 4: "gather<", 5: "gather>", 9: "begin", 10: "tile", 11: "density.", 12: "colour.", 13: "end"}
 span = collections.defaultdict(int)
 count = collections.defaultdict(int)
 for i in range(1, len(ev)):
