@@ -1028,6 +1028,11 @@ template <int PREC, int DUMP>
 __device__ __forceinline__ void color_stage(WeightStream& st, const f32x16 (&geo)[1], float dirx, float diry, float dirz,
                                             int wave, int lane, float (&rgb)[3], ColorDump cdump) {
   const int j = lane & 31, hh = lane >> 5;
+  // The harmonics depend on the ray only, so the compiler computes them once in front of the tile loop -- and, with every
+  // register taken by the networks, spills all 16 and reloads them here one by one behind s_waitcnt vmcnt(0) (which also
+  // waits for the weight DMA in flight): 16 serialised memory round trips per tile for ~30 VALU instructions of work.
+  // Opaque copies of the direction make it a per-tile recomputation.
+  asm volatile("" : "+v"(dirx), "+v"(diry), "+v"(dirz));
   float sh[16];
   sh4(dirx, diry, dirz, sh);
   f32x16 cin[1], crgb[1];
@@ -1048,10 +1053,13 @@ __device__ __forceinline__ void jacobian_stage(WeightStream& st, const float* __
   const int hh = lane >> 5;
   const float* bias = njf_lds + LDS_BIAS + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS;
   // the encoding is recomputed (~1 % of the head's time) rather than held in 32 VGPRs across density + colour
-  asm volatile("" ::: "memory");
+  // ... and REALLY recomputed: without the opaque copies the compiler keeps the density stage's 25 encoding values alive
+  // through scratch and reloads them inside the lin_in chunk, each reload behind its own s_waitcnt vmcnt(0)
+  float xc = g.xc, yc = g.yc, zc = g.zc;
+  asm volatile("" : "+v"(xc), "+v"(yc), "+v"(zc) : : "memory");
   f32x16 pe[2];
   NJF_STAMP(st, 6);  // Jacobian stage begins
-  positional_encoding(g.xc, g.yc, g.zc, hh, pe);
+  positional_encoding(xc, yc, zc, hh, pe);
 #ifdef NJF_STAMPS
   asm volatile("" : "+v"(pe[0]), "+v"(pe[1]));
 #endif
