@@ -1120,9 +1120,11 @@ struct RenderArgs {
 struct SamplePlace {
   float delta, tm, px, py, pz;
 };
-__device__ __forceinline__ void place_sample(const float* __restrict__ bins, int sc_i, float near, float far, float ox,
+// `b0`, `b1`: the sample's two bin edges, loaded once per tile and kept in two registers; the five derived values are
+// recomputed where they are needed (opaque copies: otherwise the compiler keeps all five alive across the networks)
+__device__ __forceinline__ void place_sample(float b0, float b1, float near, float far, float ox,
                                              float oy, float oz, float dx, float dy, float dz, SamplePlace& sp) {
-  const float b0 = bins[sc_i], b1 = bins[sc_i + 1];
+  asm volatile("" : "+v"(b0), "+v"(b1));
   const float start = b0 * far + (1.0f - b0) * near;
   const float end = b1 * far + (1.0f - b1) * near;
   const float se = start + end;
@@ -1194,10 +1196,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     const int sc_i = min(s, S - 1);
     const size_t si = (size_t)ray * S + s;
     const bool store = valid && ray_ok;
+    const float bin0 = bins[sc_i], bin1 = bins[sc_i + 1];
     PointGeom g;
     {
       SamplePlace sp;
-      place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      place_sample(bin0, bin1, near, far, ox, oy, oz, dx, dy, dz, sp);
       point_geometry(cam, sp.px, sp.py, sp.pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, 0u, g);
     }
     NJF_STAMP(st, 10);  // tile begins
@@ -1215,7 +1218,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     float w;
     {
       SamplePlace sp;
-      place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      place_sample(bin0, bin1, near, far, ox, oy, oz, dx, dy, dz, sp);
       NJF_STAMP(st, 14);  // density net returned
       w = tile_weights(sp.delta, sigma, valid, j, carry);
 #ifdef NJF_STAMPS
@@ -1278,7 +1281,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     }
     if (valid) {
       SamplePlace sp;
-      place_sample(bins, sc_i, near, far, ox, oy, oz, dx, dy, dz, sp);
+      place_sample(bin0, bin1, near, far, ox, oy, oz, dx, dy, dz, sp);
       acc_pw[0] = fmaf(w, sp.px + flow[0], acc_pw[0]);
       acc_pw[1] = fmaf(w, sp.py + flow[1], acc_pw[1]);
       acc_pw[2] = fmaf(w, sp.pz + flow[2], acc_pw[2]);
