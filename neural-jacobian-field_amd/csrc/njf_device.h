@@ -734,49 +734,48 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
   const float* gb = gz + (size_t)g.gofs + 4 * hh;
   const float* p[4] = {gb + f.t00, gb + f.t01, gb + f.t10, gb + f.t11};
   const float w[4] = {f.w00, f.w01, f.w10, f.w11};
-  // The gather is latency-bound: with NJF_GATHER_BATCH texels per batch, 4*MB*BATCH float4 loads are in flight
-  // together (the registers `net` vacates at this point of the block), then folded into h.  The asm fence makes
-  // the fmas retire into h before the next batch's loads are issued (otherwise the scheduler either hoists all
-  // 16*MB loads -> 256 VGPRs -> scratch, or serialises them 4 at a time -> 16 L2 round trips per gather).
-#ifndef NJF_GATHER_BATCH
-#define NJF_GATHER_BATCH 1
-#endif
+  // A rolling pipeline like the quad form's: a batch = (texel t, block m) = 4 loads of 16 bytes; DEPTH batches are in
+  // flight (the 64 registers `net` vacates at this point of the block), and every consumed batch is refilled at once, so
+  // the addresser sees a continuous stream (the round-1 form issued a texel's 4*MB loads, waited for all of them, folded
+  // them, and only then issued the next texel's; measured equal in round 2 -- this form's gather is bound by the addresser's
+  // request rate, not by the exposed round trips -- and kept as the one structure both forms share).  sched_barrier pins
+  // the issue order (otherwise the scheduler hoists all 16*MB loads -> scratch).
+  // Accumulation order per element stays t = 0..3: bit-identical results.
+  constexpr int DEPTH = 4, NB = 4 * MB;
+  f32x4 v[DEPTH][4];
+  auto issue = [&](int b) {
+    const float* src = p[b / MB] + 32 * (b % MB);
 #pragma unroll
-  for (int t0 = 0; t0 < 4; t0 += NJF_GATHER_BATCH) {
-    f32x4 v[NJF_GATHER_BATCH][MB][4];
+    for (int q = 0; q < 4; ++q) v[b % DEPTH][q] = *(const f32x4*)(src + 8 * q);
+  };
 #pragma unroll
-    for (int t = 0; t < NJF_GATHER_BATCH; ++t)
+  for (int b = 0; b < DEPTH; ++b) issue(b);
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
+  for (int b = 0; b < NB; ++b) {
+    const int t = b / MB, m = b % MB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[t][m][q] = *(const f32x4*)(p[t0 + t] + 32 * m + 8 * q);
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int t = 0; t < NJF_GATHER_BATCH; ++t)
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // Texels 1..3: one v_fmac per value, written as asm so that the SLP vectoriser cannot pair them into
-            // v_pk_fma_f32 -- the packed form needs every bilinear weight as a {w, w} register pair, which the
-            // allocator materialises per use site and spills (252 -> 70 spilled VGPRs in the render kernel, 156 -> 11
-            // in the proposal kernel; 10 % of the frame time).  Texel 0 stays a compiler-visible fmaf: h was just
-            // written by MFMAs, and the MFMA-write -> VALU-read wait states are only inserted for instructions the
-            // hazard recogniser can see, never for inline asm.  Every register is therefore first read by a visible
-            // instruction, and its asm updates depend on that result.  (A cheaper "touch one register per
-            // accumulator block" was tried and is WRONG: the scheduler moves the other registers' asm above the
-            // touch -- caught by the transformer-head golden tests.)
-            if (t0 + t == 0) {
-              h[m][4 * q + e] = fmaf(v[t][m][q][e], w[0], h[m][4 * q + e]);
-            } else {
-              float acc = h[m][4 * q + e];
-              asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v[t][m][q][e]), "v"(w[t0 + t]));
-              h[m][4 * q + e] = acc;
-            }
-          }
-#pragma unroll
-    for (int m = 0; m < MB; ++m) asm volatile("" : "+v"(h[m]) : : "memory");
+      for (int e = 0; e < 4; ++e) {
+        // Texels 1..3: one v_fmac per value, written as asm so that the SLP vectoriser cannot pair them into
+        // v_pk_fma_f32 -- the packed form needs every bilinear weight as a {w, w} register pair, which the
+        // allocator materialises per use site and spills.  Texel 0 stays a compiler-visible fmaf: h was just
+        // written by MFMAs, and the MFMA-write -> VALU-read wait states are only inserted for instructions the
+        // hazard recogniser can see, never for inline asm.  Every register is therefore first read by a visible
+        // instruction, and its asm updates depend on that result.  (A cheaper "touch one register per
+        // accumulator block" was tried and is WRONG: the scheduler moves the other registers' asm above the
+        // touch -- caught by the transformer-head golden tests.)
+        if (t == 0) {
+          h[m][4 * q + e] = fmaf(v[b % DEPTH][q][e], w[0], h[m][4 * q + e]);
+        } else {
+          float acc = h[m][4 * q + e];
+          asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v[b % DEPTH][q][e]), "v"(w[t]));
+          h[m][4 * q + e] = acc;
+        }
+      }
+    asm volatile("" : "+v"(h[m]) : : "memory");  // the fmas retire into h before the batch's registers are reloaded
+    if (b + DEPTH < NB) issue(b + DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
