@@ -315,7 +315,10 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
     auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + i * 1024); };                  // hi fp16 fragment (t, m): i = 4t + m
     auto f6frag = [&](int idx) {                                                           // fp6 fragment idx = 2m + w
       const i32x4 a4 = *(NJF_LDS(i32x4))(p16 + F6_P1 + idx * 1024);
-      const i32x2 b2 = *(NJF_LDS(i32x2))(p8 + F6_P2 + idx * 512);
+      // volatile: keeps the load-store optimiser from fusing the 8-byte tails of two fragments into one ds_read2st64_b64,
+      // whose four consecutive result registers then have to be moved next to each fragment's first 16 bytes (16 v_mov
+      // per chunk in a stream that is VALU-issue bound)
+      const i32x2 b2 = *(volatile NJF_LDS(i32x2))(p8 + F6_P2 + idx * 512);
       return i32x8{a4[0], a4[1], a4[2], a4[3], b2[0], b2[1], 0, 0};
     };
 #endif
