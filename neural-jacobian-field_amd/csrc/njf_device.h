@@ -510,7 +510,7 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
 // replaces, on the matrix pipe instead of the VALU (the chunk phases of the fused kernels are issue-bound on VALU work;
 // A/B in profiles/r02_ab_variants.txt).  Row i of block m holds logical feature 16*MB*hh' + 16*m + 4*(i>>3) + (i&3) with
 // hh' = (i>>2)&1 (the accumulator layout of the 32x32 MFMAs: lane half hh owns rows 8*(r>>2) + 4*hh + (r&3)).
-template <int MB, bool ASSIGN>
+template <int MB, bool ASSIGN, int PREC = PREC_F16F6>
 __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, f32x16 (&acc)[MB]) {
 #ifdef NJF_ABLATE_BIAS  // experiment builds only
   if (ASSIGN)
@@ -522,7 +522,9 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
 #elif defined(NJF_BIAS_VALU)
   constexpr bool VALU = true;
 #else
-  constexpr bool VALU = ASSIGN;
+  // the MFMA form only where the matrix pipe has the headroom (the fp6-corrected chunks); the f16x2 chunks are bound by
+  // their 48 matrix instructions (proposal pass: -0.5...1 % with v_add, profiles/r02_ab_variants.txt)
+  constexpr bool VALU = ASSIGN || PREC != PREC_F16F6;
 #endif
   if constexpr (VALU) {
     const float* b = bl + 16 * MB * hh;
@@ -931,7 +933,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     }
     if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
     const float* bl = bias + blk * 256;
-    bias_init<4, true>(bl, hh, net);
+    bias_init<4, true, PREC>(bl, hh, net);
     {
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, h, net);
@@ -941,7 +943,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
       mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, h, net);
     }
     if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
-    bias_init<4, false>(bl + 128, hh, h);
+    bias_init<4, false, PREC>(bl + 128, hh, h);
     {
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, net, h);
@@ -952,7 +954,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     }
   }
   if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h);
-  bias_init<1, true>(bias + 1280, hh, out);
+  bias_init<1, true, PREC>(bias + 1280, hh, out);
   {
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 1, 4, 0, true, 4>(st, wl, lane, h, out);
@@ -992,9 +994,9 @@ __device__ __forceinline__ void color_tile(WeightStream& st, const float* __rest
   a[0] = (f32x16)(0.f);
   a[1] = (f32x16)(0.f);
   mma_chunk<PREC, 2, 1, 0, false, 1>(st, wl, lane, cin, a);
-  bias_init<2, true>(bias, hh, b);
+  bias_init<2, true, PREC>(bias, hh, b);
   mma_chunk<PREC, 2, 2, 0, true, 2>(st, wl + 2048, lane, a, b);
-  bias_init<1, true>(bias + 64, hh, rgb);
+  bias_init<1, true, PREC>(bias + 64, hh, rgb);
   mma_chunk<PREC, 1, 2, 0, true, 2>(st, wl + 6144, lane, b, rgb);
   if (DUMP && dump.in != nullptr) {
 #pragma unroll
@@ -1059,7 +1061,7 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
   for (int l = 0; l < 3; ++l) {
     const float* bl = bias + 256 * l;
     norm64(x, n);
-    bias_init<2, true>(bl, hh, t);
+    bias_init<2, true, PREC>(bl, hh, t);
     mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, n, t);  // dots[head*8 + key]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -1080,10 +1082,10 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
       }
     }
     wl = stream_step(st, wave, lane);
-    bias_init<2, false>(bl + 64, hh, x);
+    bias_init<2, false, PREC>(bl + 64, hh, x);
     mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, t, x);  // x += to_out(attn @ V)
     norm64(x, n);
-    bias_init<2, true>(bl + 128, hh, t);
+    bias_init<2, true, PREC>(bl + 128, hh, t);
     mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, n, t);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -1093,10 +1095,10 @@ __device__ __forceinline__ void transformer_tile(WeightStream& st, const float* 
         t[m][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (nn.GELU default)
       }
     wl = stream_step(st, wave, lane);
-    bias_init<2, false>(bl + 192, hh, x);
+    bias_init<2, false, PREC>(bl + 192, hh, x);
     mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, t, x);  // x += FF
   }
-  bias_init<1, true>(bias + 768, hh, out);
+  bias_init<1, true, PREC>(bias + 768, hh, out);
   mma_chunk<PREC, 1, 2, 0, false, 2>(st, wl + 4096, lane, x, out);
 }
 
