@@ -398,72 +398,99 @@ __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo
   }
 }
 
-// channel tiles per wave: 2 keeps accumulators + the double-buffered raw operands inside 256 VGPRs at two waves per
-// SIMD (measured on C2: NT=2 0.119 ms, NT=3 0.30 ms, NT=4 0.79 ms with spills; the fp32-MFMA kernel 0.29 ms)
-#ifndef NJF_PROJ_NT
-#define NJF_PROJ_NT 2
-#endif
+// Workgroup tile 128 texels x 128 channels, K swept 16 at a time.  Per step every thread fetches 8 k-values of ONE texel
+// (A) and of ONE channel (B) from global memory -- both coalesced across the threads -- splits them ONCE into fp16 hi/lo and
+// writes them to LDS as ready MFMA fragments ([hi|lo][32-row block][lane][8 x f16]: conflict-free 16-byte writes and
+// reads); each of the four waves then computes a 64 x 64 sub-tile from 8 fragment reads and 12 MFMAs.  Double-buffered:
+// the next step's global loads are in flight during the MFMAs, one barrier per step.  (The round-1 form had every wave
+// fetch and split its own operands straight from global memory: 32 load instructions per 12 MFMAs, the feature plane
+// re-read once per 64 output channels -- 13 % matrix-pipe efficiency; products and their order are unchanged, results are
+// bit-identical.)
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+// KS = k-values per step: 16 is shipped (C2, both maps of a frame: 0.127 -> 0.102 ms against the round-1 form; a 32-wide
+// step, twice the LDS and half the barriers, measured 0.117 ms).
+template <int KS>
 __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __restrict__ feats, const float* __restrict__ wz,
                                                             const float* __restrict__ bz, int hw, int n, int ld, int K,
                                                             float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NS = KS / 16;               // 16-wide sub-steps per step
+  __shared__ u32x4p s_a[2][NS][2][4][64];   // [stage][sub-step][hi|lo][32-texel block][lane]
+  __shared__ u32x4p s_b[2][NS][2][4][64];   // [stage][sub-step][hi|lo][32-channel block][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, kh = lane >> 5;
   const int b = blockIdx.z;
-  const int p0 = (blockIdx.x * 4 + wave) * 64;
-  const int n0 = blockIdx.y * (32 * NJF_PROJ_NT);
-  if (p0 >= hw) return;
-  const float* fa[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) fa[a] = feats + (size_t)b * K * hw + min(p0 + 32 * a + j, hw - 1);
-  int nn[NJF_PROJ_NT];
-#pragma unroll
-  for (int t = 0; t < NJF_PROJ_NT; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
-  f32x16 acc[2][NJF_PROJ_NT];
+  const int p0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  // loader role: row `lr` of the tile (a texel for A, a channel for B), k-group `lk` (8 consecutive k of a sub-step's 16)
+  const int lr = tid & 127, lk = tid >> 7;
+  const float* fa = feats + (size_t)b * K * hw + min(p0 + lr, hw - 1);
+  const float* fb = wz + min(n0 + lr, n - 1);
+  const int blk = lr >> 5, slot = lk * 32 + (lr & 31);
+  // compute role: wave (wm, wn) owns texel blocks 2*wm, 2*wm+1 and channel blocks 2*wn, 2*wn+1
+  const int wm = wave & 1, wn = wave >> 1;
+  f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int t = 0; t < NJF_PROJ_NT; ++t) acc[a][t] = (f32x16)(0.f);
-  // raw fp32 operands of K-step t+1 are requested before the split + MFMAs of step t (register double buffer): the
-  // operands come straight from global memory / L2, so one K-step of latency must be in flight at all times
-  float xa[2][8], xb[NJF_PROJ_NT][8];
+    for (int t = 0; t < 2; ++t) acc[a][t] = (f32x16)(0.f);
+  float xa[NS][8], xb[NS][8];
   auto fetch = [&](int k0) {
-    const int kb = k0 + 8 * kh;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int u = 0; u < NS; ++u) {
+      const int kb = k0 + 16 * u + 8 * lk;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xa[a][i] = fa[a][(size_t)(kb + i) * hw];
+      for (int i = 0; i < 8; ++i) xa[u][i] = fa[(size_t)(kb + i) * hw];
 #pragma unroll
-    for (int t = 0; t < NJF_PROJ_NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xb[t][i] = wz[(size_t)(kb + i) * ld + nn[t]];
+      for (int i = 0; i < 8; ++i) xb[u][i] = fb[(size_t)(kb + i) * ld];
+    }
   };
   fetch(0);
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    f16x8 ah[2], al[2], bh[NJF_PROJ_NT], bl[NJF_PROJ_NT];
+  int st = 0;
+  for (int k0 = 0; k0 < K; k0 += KS, st ^= 1) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) split8(xa[a], ah[a], al[a]);
+    for (int u = 0; u < NS; ++u) {
+      f16x8 h, l;
+      split8(xa[u], h, l);
+      s_a[st][u][0][blk][slot] = __builtin_bit_cast(u32x4p, h);
+      s_a[st][u][1][blk][slot] = __builtin_bit_cast(u32x4p, l);
+      split8(xb[u], h, l);
+      s_b[st][u][0][blk][slot] = __builtin_bit_cast(u32x4p, h);
+      s_b[st][u][1][blk][slot] = __builtin_bit_cast(u32x4p, l);
+    }
+    __syncthreads();  // stage `st` complete; every wave has finished reading the other stage (it did so before this barrier)
+    if (k0 + KS < K) fetch(k0 + KS);
 #pragma unroll
-    for (int t = 0; t < NJF_PROJ_NT; ++t) split8(xb[t], bh[t], bl[t]);
-    if (k0 + 16 < K) fetch(k0 + 16);
-#pragma unroll
-    for (int t = 0; t < NJF_PROJ_NT; ++t)
+    for (int u = 0; u < NS; ++u) {
+      f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[t], acc[a][t], 0, 0, 0);
-        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[t], acc[a][t], 0, 0, 0);
-        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[t], acc[a][t], 0, 0, 0);
+        ah[a] = __builtin_bit_cast(f16x8, s_a[st][u][0][2 * wm + a][lane]);
+        al[a] = __builtin_bit_cast(f16x8, s_a[st][u][1][2 * wm + a][lane]);
       }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bh[t] = __builtin_bit_cast(f16x8, s_b[st][u][0][2 * wn + t][lane]);
+        bl[t] = __builtin_bit_cast(f16x8, s_b[st][u][1][2 * wn + t][lane]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[t], acc[a][t], 0, 0, 0);
+          acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[t], acc[a][t], 0, 0, 0);
+          acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[t], acc[a][t], 0, 0, 0);
+        }
+    }
   }
 #pragma unroll
-  for (int t = 0; t < NJF_PROJ_NT; ++t) {
-    const int c = n0 + 32 * t + j;
+  for (int t = 0; t < 2; ++t) {
+    const int c = n0 + 64 * wn + 32 * t + j;
     if (c >= n) continue;
     const float bias = bz ? bz[c] : 0.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = p0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = p0 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row < hw) out[((size_t)b * hw + row) * n + c] = acc[a][t][r] + bias;
       }
   }
@@ -472,8 +499,8 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
 static void launch_project(const float* feats, int K, const float* wz, int ld, const float* bz, int batch, int hw, int n,
                            float* out, int precision, hipStream_t s) {
   if (precision != NJF_PRECISION_F32) {  // F16X2 and F16F6: both operands split on the fly
-    dim3 grid((hw + 255) / 256, (n + 32 * NJF_PROJ_NT - 1) / (32 * NJF_PROJ_NT), batch);
-    project_kernel_f16x2<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+    dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
+    project_kernel_f16x2<16><<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
   } else {
     dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
     project_kernel<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
