@@ -176,6 +176,7 @@ def _note_device(t, name: str) -> None:
     if dev is None:
         _call.device = new
     elif dev != new:
+        _call.device = None   # the half-assembled call is abandoned: its device must not leak into the next entry point
         raise ValueError(f"njf_hip: {name} lives on {new} but other arguments of this call live on {dev}; all tensors "
                          "of one call must be on the same GPU")
 
@@ -201,12 +202,16 @@ class _RecordScope:
 def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
     if t is None:
         return None
+    problem = None
     if not t.is_cuda:
-        raise ValueError(f"njf_hip: {name} must live on the GPU (got {t.device}); there is no CPU path")
-    if t.dtype != torch.float32:
-        raise ValueError(f"njf_hip: {name} must be float32 (got {t.dtype})")
-    if not t.is_contiguous():
-        raise ValueError(f"njf_hip: {name} must be contiguous")
+        problem = f"njf_hip: {name} must live on the GPU (got {t.device}); there is no CPU path"
+    elif t.dtype != torch.float32:
+        problem = f"njf_hip: {name} must be float32 (got {t.dtype})"
+    elif not t.is_contiguous():
+        problem = f"njf_hip: {name} must be contiguous"
+    if problem is not None:
+        _call.device = None   # abandon the half-assembled call (a stale device used to leak into the next one)
+        raise ValueError(problem)
     _note_device(t, name)
     return t.data_ptr()
 
@@ -408,6 +413,7 @@ def generate_rays(coords, height, width, k_inv, c2w, origins, directions, z) -> 
 
 def _int_ptr(t: torch.Tensor) -> int:
     if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        _call.device = None
         raise ValueError("njf_hip: foot_idx must be a contiguous int32 device tensor")
     _note_device(t, "foot_idx")
     return t.data_ptr()

@@ -47,7 +47,10 @@ def global_depth_clip(depth: torch.Tensor, step_minmax: torch.Tensor) -> torch.T
     """render_depth's clip bounds are min/max over the WHOLE [B,R,S] step tensor (model.py:277); under ray
     sharding they need an all-reduce of two scalars -- ONE collective: MAX over (-min, max)."""
     flat = step_minmax.reshape(-1, 2)
-    buf = torch.cat([-flat[:, 0], flat[:, 1]]).reshape(2, -1).amax(dim=1)   # (-min, max) in one reduction
+    if flat.shape[0] == 0:   # a rank without rays (more ranks than rays): neutral element of the MAX all-reduce
+        buf = torch.full((2,), float("-inf"), dtype=step_minmax.dtype, device=step_minmax.device)
+    else:
+        buf = torch.cat([-flat[:, 0], flat[:, 1]]).reshape(2, -1).amax(dim=1)   # (-min, max) in one reduction
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
     return torch.clamp(depth, min=-buf[0], max=buf[1])
@@ -120,10 +123,13 @@ def allreduce_gradients(parameters, average: bool = True) -> None:
         return
     dev, dt = params[0].device, torch.float32
     pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in params]
-    flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=dev, dtype=dt)
+    pattern = tuple(0.0 if p.grad is None else 1.0 for p in params)
+    flags = _device_constant(pattern, dev)   # uploaded once per pattern: no per-step host-to-device copy
     flat = torch.cat(pieces + [flags])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    seen = flat[-len(params):].tolist()
+    # the flags are only READ (a host synchronisation) when this rank is missing a gradient some other rank may have;
+    # with every local gradient present -- every step of the reference's two training modes -- nothing is read back
+    seen = flat[-len(params):].tolist() if 0.0 in pattern else pattern
     if average:
         flat /= dist.get_world_size()
     off = 0

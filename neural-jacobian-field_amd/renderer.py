@@ -86,12 +86,6 @@ class FusedRenderer:
             raise KeyError(f"FusedRenderer.load_weights: missing {missing[:4]}{'...' if len(missing) > 4 else ''}")
         self.model.load_state_dict({k: params[k] for k in own}, strict=True)
 
-    # ------------------------------------------------------------------ per image
-    def project(self, features: torch.Tensor) -> torch.Tensor:
-        """Kept for call compatibility: the hoisted maps are produced (and cached per feature tensor) inside the render
-        call, by the networks that consume them; this returns the feature map itself."""
-        return features.contiguous()
-
     # ------------------------------------------------------------------ per ray batch
     def render(self, features: torch.Tensor, origins: torch.Tensor, directions: torch.Tensor, ctxt_c2w: torch.Tensor,
                ctxt_k_norm: torch.Tensor, z_near: torch.Tensor, z_far: torch.Tensor,

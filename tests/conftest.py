@@ -31,6 +31,7 @@ def pytest_collection_modifyitems(config, items):
 # {case, key, err, floor, limit} and asserts err <= max(tol, 2 x floor).  The floor is the REFERENCE's own fp32-vs-fp64
 # difference for that quantity (tests/golden/*_f64.npz, harness_reference.npz).  The table is written at session end.
 _MARGIN_ROWS = []
+SELF_NOISE_CEILING = 5e-3   # no parity limit is looser than this, whatever the reference's self-noise
 
 
 def _rel(a, b):
@@ -41,21 +42,31 @@ def _rel(a, b):
 
 @pytest.fixture(scope="session")
 def margins():
-    def check(case, key, got, ref32, ref64=None, tol=1e-4, floor=None, self_noise=()):
-        """assert rel(got, ref32) <= max(tol, 2 * floor).  floor = the largest of rel(ref32, ref64) (the reference's fp32 run
-        against its float64 run) and the `self_noise` figures: how far the reference's OWN fp32 output moves when its
-        inputs move by what no fp32 implementation can avoid (one ulp on the rays; 1e-5 on the encoder features)."""
+    def check(case, key, got, ref32, ref64=None, tol=1e-4, floor=None, self_noise=(), floor_fp64=None):
+        """assert rel(got, ref32) <= max(tol, 2 * floor_fp64), floor_fp64 = rel(ref32, ref64): the reference's fp32 run
+        against its float64 run (or the explicit ``floor_fp64`` / ``floor``).  Only where that fails are the `self_noise`
+        figures consulted -- how far the reference's OWN fp32 output moves when its inputs move by what no fp32
+        implementation can avoid (one ulp on the rays; a perturbation of the encoder features no larger than the measured
+        MIOpen-vs-ATen difference) -- and the row is marked ``self_noise_floor_used``; the limit is capped at
+        SELF_NOISE_CEILING.  ``floor`` together with ``floor_fp64``: floor = the largest of all floors of that quantity,
+        floor_fp64 = its fp64 part (gradient tests)."""
         err = _rel(got, ref32)
         if floor is None:
             floor = _rel(ref32, ref64) if ref64 is not None else 0.0
-        floor64 = floor
-        for f in self_noise:
-            floor = max(floor, float(f))
-        limit = max(tol, 2.0 * floor)
-        _MARGIN_ROWS.append({"case": case, "key": key, "err": float(f"{err:.3e}"), "floor": float(f"{floor:.3e}"),
+        floor64 = floor if floor_fp64 is None else float(floor_fp64)
+        limit = max(tol, 2.0 * floor64)
+        used_self_noise = False
+        noise = max([float(f) for f in self_noise] + ([floor] if floor_fp64 is not None else []), default=0.0)
+        if not err <= limit and noise > floor64:
+            # self-noise floors (one-ulp rays, perturbed encoder) are consulted ONLY where twice the fp64 floor fails, and
+            # the row says so; no limit may exceed SELF_NOISE_CEILING however noisy the reference is
+            limit = min(max(tol, 2.0 * noise), SELF_NOISE_CEILING)
+            used_self_noise = True
+        _MARGIN_ROWS.append({"case": case, "key": key, "err": float(f"{err:.3e}"),
+                             "floor": float(f"{(noise if used_self_noise else floor64):.3e}"),
                              "floor_fp64": float(f"{floor64:.3e}"), "limit": float(f"{limit:.3e}"), "needs_floor": bool(err > tol),
-                             "ok": bool(err <= limit)})
-        assert err <= limit, {"case": case, "key": key, "err": err, "floor": floor, "limit": limit}
+                             "self_noise_floor_used": used_self_noise, "ok": bool(err <= limit)})
+        assert err <= limit, {"case": case, "key": key, "err": err, "floor_fp64": floor64, "self_noise": noise, "limit": limit}
         return err
 
     def record(case, rows):
@@ -71,13 +82,19 @@ def pytest_sessionfinish(session, exitstatus):
         return
     import json
 
-    out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.path.join(ROOT, "profiles")
-    path = os.environ.get("NJF_MARGINS_OUT", os.path.join(out_dir, "r02_parity_margins.json"))
-    summary = {"rule": "err <= max(1e-4, 2 x floor); err, floor = max|a-b| / max|b| (norm-wise); floor = the reference's own "
-                       "fp32-vs-fp64 difference for that quantity (floor_fp64) or, for outputs downstream of sample placement / "
-                       "the encoder, the larger of it and the movement of the reference's fp32 output under a one-ulp "
-                       "perturbation of the rays / a 1e-5 perturbation of the encoder features (tests/golden/make_golden_r02.py)",
+    # scratch by default (a partial run -- `pytest -k`, one file -- must never replace the committed table); the committed
+    # profiles/r03_parity_margins.json is written only when NJF_MARGINS_OUT names it (tools/measure_r03.sh: full suite)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.environ.get("NJF_MARGINS_OUT", os.path.join(out_dir, "parity_margins_last_run.json"))
+    summary = {"rule": "err <= max(1e-4, 2 x floor_fp64); err, floor = max|a-b| / max|b| (norm-wise); floor_fp64 = the reference's "
+                       "own fp32-vs-fp64 difference for that quantity.  Rows with self_noise_floor_used = true failed that bound "
+                       "and are held to 2 x the reference's measured self-noise instead (movement of its fp32 output under a "
+                       "one-ulp perturbation of the rays / the encoder-feature perturbation of tests/golden/make_golden_r02.py), "
+                       "capped at 5e-3",
+               "collected_tests": getattr(session, "testscollected", None), "exit_status": int(exitstatus),
                "rows": len(_MARGIN_ROWS), "rows_over_1e-4": sum(r["needs_floor"] for r in _MARGIN_ROWS),
+               "rows_on_self_noise_floor": sum(bool(r.get("self_noise_floor_used")) for r in _MARGIN_ROWS),
                "failed": sum(not r["ok"] for r in _MARGIN_ROWS), "table": _MARGIN_ROWS}
     with open(path, "w") as f:
         json.dump(summary, f, indent=0)

@@ -11,31 +11,39 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-def ulp_nudged(t):
-    """Every element moved by one unit in the last place (towards +inf): the smallest input change any fp32
+def ulp_nudged(t, direction=1.0):
+    """Every element moved by one unit in the last place (towards +inf, or -inf): the smallest input change any fp32
     implementation of the ray generation may produce."""
-    return torch.nextafter(t, torch.full_like(t, float("inf")))
+    return torch.nextafter(t, torch.full_like(t, direction * float("inf")))
 
 
-def noisy(t, scale=1e-5, seed=1234):
-    """t * (1 + scale * n), n ~ N(0,1) seeded: the size of the difference between two fp32 encoders (MIOpen's Winograd
-    convolutions vs ATen's CPU ones) -- the same 1e-5 the output floors of tests/golden/make_golden_r02.py use."""
+def noisy(t, scale=1e-6, seed=1234):
+    """t * (1 + scale * n), n ~ N(0,1) seeded: the size of the difference between two fp32 encoders.  MIOpen's convolutions
+    against ATen's CPU ones measure 6.6e-7 norm-wise on the reference's fixture (row model_mlp.encoder / features of the
+    margins table; that test holds it below 1e-5), so 1e-6 element-wise -- round 2 assumed 1e-5."""
     g = torch.Generator().manual_seed(seed)
     return t * (1.0 + scale * torch.randn(t.shape, generator=g))
 
 
-FLOOR_MODES = ("fp64", "rays", "features")
+FLOOR_MODES = ("fp64", "rays", "rays-", "features")
+
+
+def moved_origins(origins, mode):
+    return ulp_nudged(origins, -1.0 if mode == "rays-" else 1.0) if mode in ("rays", "rays-") else origins
 
 
 def gradient_floor(run_oracle_backward, names):
     """What fp32 arithmetic itself costs the ORACLE's gradients: its fp32 run against its own float64 run ("fp64": the
     ds-nerf depth loss differentiates log(w + eps) of tiny weights, ~2e-3 on its own), and how far its fp32 gradients move
-    under input changes no fp32 implementation can avoid -- the rays moved by one ulp ("rays": the samplers' inverse-CDF
-    placement and the 2*pi*512-gain encoding amplify it) and the encoder's output / input moved by 1e-5 ("features").
-    `run_oracle_backward(mode)` returns {name: gradient}; the floor of a parameter is the largest of the three."""
+    under input changes no fp32 implementation can avoid -- the rays moved by one ulp either way ("rays", "rays-": the
+    samplers' inverse-CDF placement and the 2*pi*512-gain encoding amplify it) and the encoder's output / input moved by
+    1e-6 ("features").  `run_oracle_backward(mode)` returns {name: gradient}.  Returns, PER PARAMETER, the fp64 floor and
+    the largest of all floors (the `margins` rule consults the latter only where twice the former fails), and the base run."""
     base = run_oracle_backward(None)
-    moved = [run_oracle_backward(mode) for mode in FLOOR_MODES]
-    return {n: max(rel(m[n], base[n]) for m in moved) for n in names}, base
+    moved = {mode: run_oracle_backward(mode) for mode in FLOOR_MODES}
+    floor64 = {n: rel(moved["fp64"][n], base[n]) for n in names}
+    floor_all = {n: max(rel(m[n], base[n]) for m in moved.values()) for n in names}
+    return floor64, floor_all, base
 
 
 def as_dtype(mode):
@@ -103,7 +111,7 @@ def test_action_mode_gradients_match_oracle_autograd(setup, margins):
         for k in params:
             if k.startswith("decoder.jacobian_head."):
                 params[k].requires_grad_(True)
-        origins = ulp_nudged(case["origins"]) if mode == "rays" else case["origins"]
+        origins = moved_origins(case["origins"], mode)
         ref = orc.model_forward(params, features=cv(noisy(feats) if mode == "features" else feats),
                                 ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
                                 trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
@@ -115,14 +123,15 @@ def test_action_mode_gradients_match_oracle_autograd(setup, margins):
         losses[mode] = ref_loss.detach().reshape(1)
         return {n: params["decoder.jacobian_head." + n].grad for n in JACOBIAN_PARAM_ORDER}
 
-    floor, g_ref = gradient_floor(oracle_backward, JACOBIAN_PARAM_ORDER)
+    floor64, floor, g_ref = gradient_floor(oracle_backward, JACOBIAN_PARAM_ORDER)
     margins("train.action[jacobian_mlp]", "loss", loss.reshape(1), losses[None],
-            floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES))
+            floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES), floor_fp64=rel(losses["fp64"], losses[None]))
     head = dict(model.decoder.jacobian_head.named_parameters())
     for name in JACOBIAN_PARAM_ORDER:
         assert head[name].grad is not None and torch.isfinite(head[name].grad).all(), name
         # bound: twice the oracle's own movement under one-ulp rays (sample locations feed a 2*pi*512-gain encoding)
-        margins("train.action[jacobian_mlp]", "grad " + name, head[name].grad, g_ref[name], floor=floor[name])
+        margins("train.action[jacobian_mlp]", "grad " + name, head[name].grad, g_ref[name], floor=floor[name],
+                floor_fp64=floor64[name])
     # frozen parameters received no gradient
     assert all(p.grad is None for n, p in model.named_parameters() if "jacobian_head" not in n)
 
@@ -212,7 +221,7 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
             for k, v in params.items():
                 if v.is_floating_point() and "running_" not in k:
                     v.requires_grad_(True)
-            origins = ulp_nudged(case["origins"]) if mode == "rays" else case["origins"]
+            origins = moved_origins(case["origins"], mode)
             image = noisy(s["image"]) if mode == "features" else s["image"]   # the encoder trains: its INPUT moves
             ref = orc.model_forward(params, input_image=cv(image), ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
                                     trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
@@ -225,10 +234,13 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
             return {n: params[n].grad for n in names}
 
         base = oracle_backward(None)
-        moved = [oracle_backward(mode) for mode in FLOOR_MODES]
+        moved = {mode: oracle_backward(mode) for mode in FLOOR_MODES}
         margins("train.perception", "loss", loss.reshape(1), losses[None],
-                floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES))
-        groups = {}
+                floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES), floor_fp64=rel(losses["fp64"], losses[None]))
+        # EVERY parameter is held to ITS OWN floors (a group's largest floor used to excuse the group's worst
+        # parameter): twice the oracle's fp32-vs-fp64 difference of that gradient, and only where that fails twice its
+        # largest movement under one-ulp rays / the 1e-6 image perturbation (row marked; limit capped by `margins`)
+        failures = []
         for name, p in model.named_parameters():
             g_ref = base[name]
             if g_ref is None or name.startswith("decoder.jacobian_head."):
@@ -237,25 +249,13 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
                 assert p.grad is None and (g_ref is None or g_ref.abs().max() == 0), name
                 continue
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
-            group = name.split(".")[0] + "." + name.split(".")[1]
-            e, f = rel(p.grad, g_ref), max(rel(m[name], g_ref) for m in moved)
-            worst = groups.setdefault(group, {"err": 0.0, "floor": 0.0})
-            if e > worst["err"]:
-                worst.update(err=e, at=name)
-            if __import__("os").environ.get("NJF_TEST_VERBOSE"):
-                print(f"  {name:60s} err {e:.3e} floor {f:.3e}")
-            worst["floor"] = max(worst["floor"], f)
-        print("worst relative gradient error per group", groups)
-        # bound per parameter group: twice the oracle's own fp32 floor (its float64 run; one-ulp rays; a 1e-5 image
-        # perturbation); err = the group's worst parameter, floor = the group's largest floor
-        rows = []
-        for group, w in groups.items():
-            limit = max(1e-4, 2.0 * w["floor"])
-            rows.append({"key": "grad " + group, "err": float(f"{w['err']:.3e}"), "floor": float(f"{w['floor']:.3e}"),
-                         "floor_fp64": 0.0, "limit": float(f"{limit:.3e}"), "needs_floor": bool(w["err"] > 1e-4),
-                         "ok": bool(w["err"] <= limit)})
-        margins.record("train.perception", rows)
-        assert all(r["ok"] for r in rows), rows
+            f64 = rel(moved["fp64"][name], g_ref)
+            f_all = max(rel(m[name], g_ref) for m in moved.values())
+            try:
+                margins("train.perception", "grad " + name, p.grad, g_ref, floor=f_all, floor_fp64=f64)
+            except AssertionError as e:
+                failures.append(str(e))
+        assert not failures, failures
     finally:
         for n, p in model.named_parameters():
             p.requires_grad = req[n]
@@ -378,7 +378,7 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup, margins)
         params = {k: cv(v.clone()) for k, v in full.items()}
         for k in trainable:
             params[k].requires_grad_(True)
-        origins = ulp_nudged(case["origins"]) if mode == "rays" else case["origins"]
+        origins = moved_origins(case["origins"], mode)
         ref = orc.model_forward(params, features=cv(noisy(feats) if mode == "features" else feats),
                                 ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
                                 trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
@@ -389,12 +389,12 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup, margins)
         losses[mode] = ref_loss.detach().reshape(1)
         return {k: params[k].grad for k in trainable}
 
-    floor, g_ref = gradient_floor(oracle_backward, trainable)
+    floor64, floor, g_ref = gradient_floor(oracle_backward, trainable)
     margins("train.action[jacobian_transformer]", "loss", loss.reshape(1), losses[None],
-            floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES))
+            floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES), floor_fp64=rel(losses["fp64"], losses[None]))
     named = dict(model.named_parameters())
     for k in trainable:
-        margins("train.action[jacobian_transformer]", "grad " + k, named[k].grad, g_ref[k], floor=floor[k])
+        margins("train.action[jacobian_transformer]", "grad " + k, named[k].grad, g_ref[k], floor=floor[k], floor_fp64=floor64[k])
     assert all(p.grad is None for n, p in named.items() if n not in trainable)
 
 

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-3 measurement sweep (GPU box, one gpurun call, from the repo root): full GPU suite with the margins table, bench
+# line, HBM table of the streaming kernels (HIP events + rocprofv3 averages), other configs, scaling dry run.
+# Outputs land in gpurun_out/measure_r03/; the ones that are evidence are copied to profiles/r03_* by hand.
+cd "$(dirname "$0")/.."
+O=gpurun_out/measure_r03; mkdir -p $O
+export NJF_MARGINS_OUT=$PWD/$O/r03_parity_margins.json
+STEP=${1:-all}
+if [ "$STEP" = all ] || [ "$STEP" = tests ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest_gpu.txt
+fi
+if [ "$STEP" = all ] || [ "$STEP" = bench ]; then
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 1500 $O/bench.json
+fi
+if [ "$STEP" = all ] || [ "$STEP" = stream ]; then
+  timeout 300 python tools/stream_kernels.py --json $O/stream_hip_events.json > $O/stream_hip_events.txt 2>&1; cat $O/stream_hip_events.txt | tail -9
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/stream_trace -- python $OLDPWD/tools/stream_kernels.py --launches 20 > $OLDPWD/$O/stream_trace.log 2>&1)
+  ST=$(find $O/stream_trace -name '*kernel_stats.csv' | head -1)
+  [ -n "$ST" ] && cp $ST $O/stream_kernel_stats.csv && python tools/stream_kernels.py --stats $O/stream_kernel_stats.csv --json $O/stream_rocprof.json | tee $O/stream_rocprof.txt
+fi
+if [ "$STEP" = all ] || [ "$STEP" = configs ]; then
+  for a in "--batch 4 --samples 128" "--height 512 --width 512" "--samples 256" "--samples 32"; do
+    echo "ARGS $a"; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-precisions $a 2>/dev/null | tail -1
+  done > $O/configs.txt
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-precisions --force-dist 2>/dev/null | tail -1 > $O/force_dist.json
+  for n in 2 4 8; do
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-precisions --simulate-world $n 2>/dev/null | tail -1
+  done > $O/simulate_world.txt
+  tail -c 400 $O/simulate_world.txt
+fi

@@ -74,7 +74,7 @@ def kernel_ms(records, steps):
 for prec in PRECS:
     fr = FusedRenderer(dev, 1, A, precision=prec)   # sets the whole model (proposal pass included) to `prec`'s policy
     fr.load_weights(dp)
-    gmap = fr.project(feats)
+    gmap = feats.contiguous()
     steps = 3 if prec == "f32" else 8
     render = lambda: fr.render(gmap, origins, directions, ctxt_c2w, ctxt_k, z_near, z_far, [S], S, trgt_c2w=trgt_c2w,
                                trgt_k_pix=k_pix, action=action, ctxt_w2c=ctxt_w2c, trgt_w2c=trgt_w2c)

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""HBM roofline of the streaming kernels (VERDICT r02 "missing" #4 / "next" #8).
+
+Runs every HBM-bound kernel of the path at the size it has on a C2 frame / the reference training batch, and prints one
+table row per kernel: ALGORITHMIC bytes per launch (the minimum an implementation must move: every input read once,
+every output written once), mean launch duration, bytes / time, fraction of the 8 TB/s HBM3E peak
+(/opt/skills/guides/MI355X_MICROARCH.md).
+
+  python tools/stream_kernels.py                               durations from HIP events on the launch stream
+  rocprofv3 --kernel-trace --stats ... -- python tools/stream_kernels.py --launches 20
+  python tools/stream_kernels.py --stats <kernel_stats.csv>    the same table with rocprofv3's average durations
+
+The GPU is needed for the first two forms; the third only formats (the byte counts are computed from the shapes).
+"""
+import argparse
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12
+H = W = 256
+HF = WF = 128
+S = 64
+TRAIN_POINTS = 7 * 256 * 64          # reference batch shape: 7 scenes x 256 rays x 64 samples
+PYRAMID = ((64, 128, 128), (64, 64, 64), (128, 32, 32), (256, 16, 16))   # ResNet-34 latents of a 256 x 256 image
+
+
+def workloads():
+    """name -> (rocprofv3 kernel-name prefix, algorithmic bytes per launch, what is counted)."""
+    rays = H * W
+    n_dec, n_all = 768, 1152
+    lower = sum(h * w for _, h, w in PYRAMID[1:])
+    return {
+        "raygen": ("raygen_kernel", rays * (8 + 28), f"{rays} rays: pixel coordinate 8 B in, origin + direction + z 28 B out"),
+        "alpha_weights": ("alpha_weights_kernel", rays * S * 12, f"[{rays},{S}] deltas + densities in, weights out (4 B each)"),
+        "pdf": ("pdf_kernel", rays * (S + (S + 1) + (S + 1)) * 4, f"[{rays},{S}] weights + [{rays},{S + 1}] bins in, [{rays},{S + 1}] bins out"),
+        "upsample_add": ("upsample_add_kernel", (2 * HF * WF + lower) * n_dec * 4,
+                         f"hoisted map [{HF},{WF},{n_dec}] read + written, projected coarser levels ({lower} texels x {n_dec}) read once"),
+        "upsample_concat": ("upsample_concat_kernel", (sum(c * h * w for c, h, w in PYRAMID) + HF * WF * 512) * 4,
+                            f"four NCHW latents in, [{HF * WF},512] channels-last matrix out"),
+        "scatter_footprint": ("scatter_footprint_kernel", (3 * TRAIN_POINTS * 128 + TRAIN_POINTS * 8 + 2 * HF * WF * 384) * 4,
+                              f"3 x [{TRAIN_POINTS},128] gradients + footprints (32 B/point) in, [{HF * WF},384] accumulated (read + write)"),
+        "project_f16x2": ("project_kernel_f16x2", (512 * HF * WF + 512 * n_all + HF * WF * n_all) * 4,
+                          f"[512,{HF},{WF}] features + [512,{n_all}] weights in, [{HF},{WF},{n_all}] hoisted maps out (19.3 GFLOP: also "
+                          "priced against the f16 MFMA peak in DESIGN.md)"),
+    }
+
+
+def run(launches: int):
+    import torch
+    import __graft_entry__ as entry
+    entry.build()
+    from neural_jacobian_field_amd import geometry, hip
+    from neural_jacobian_field_amd.renderer import pdf_u_eval
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)
+    rays = H * W
+    calls = {}
+    # raygen
+    coords, _ = geometry.get_pixel_coordinates(H, W, dev)
+    coords = coords.reshape(1, rays, 2).contiguous()
+    k_inv = torch.linalg.inv(torch.tensor([[[0.8, 0, 0.5], [0, 0.8, 0.5], [0, 0, 1.0]]])).to(dev).contiguous()
+    c2w = torch.eye(4, device=dev)[None].contiguous()
+    o, d, z = (torch.empty(1, rays, 3, device=dev), torch.empty(1, rays, 3, device=dev), torch.empty(1, rays, 1, device=dev))
+    calls["raygen"] = lambda: hip.generate_rays(coords, H, W, k_inv, c2w, o, d, z)
+    # alpha weights, pdf
+    deltas, dens, wts = rnd(rays, S).abs().contiguous(), rnd(rays, S).abs().contiguous(), torch.empty(rays, S, device=dev)
+    calls["alpha_weights"] = lambda: hip.alpha_weights(deltas, dens, wts)
+    bins_in = torch.sort(torch.rand(rays, S + 1, generator=g), dim=-1).values.to(dev).contiguous()
+    w_in = torch.rand(rays, S, generator=g).to(dev).contiguous()
+    bins_out = torch.empty(rays, S + 1, device=dev)
+    u = pdf_u_eval(S, dev)
+    calls["pdf"] = lambda: hip.pdf_resample(w_in, bins_in, u, S, 1.0, bins_out)
+    # feature-pyramid producer and the encoder tail
+    levels = [rnd(1, c, h, w).contiguous() for c, h, w in PYRAMID]
+    wz, bz = (rnd(512, 768) * 0.05).contiguous(), rnd(768).contiguous()
+    gmap = torch.empty(1, HF, WF, 768, device=dev)
+    calls["upsample_add"] = lambda: hip.project_pyramid(levels, wz, bz, gmap, precision="f16x2")
+    calls["upsample_concat"] = lambda: hip.upsample_concat(levels)
+    # scatter of the lin_z latent gradients (three slices of one net, reference training batch)
+    grads = rnd(6, TRAIN_POINTS, 128)
+    tex = torch.randint(0, HF * WF - WF - 2, (TRAIN_POINTS // S, 1), generator=g).repeat_interleave(S, 0)
+    tex = tex + torch.arange(TRAIN_POINTS).remainder(S)[:, None] // 8          # neighbouring samples share texels
+    foot_idx = torch.cat([tex, tex + 1, tex + WF, tex + WF + 1], 1).to(torch.int32).to(dev).contiguous()
+    foot_w = torch.rand(TRAIN_POINTS, 4, generator=g).to(dev).contiguous()
+    acc = torch.zeros(HF * WF, 384, device=dev)
+    calls["scatter_footprint"] = lambda: hip.scatter_footprint(grads[0:6:2], foot_idx, foot_w, acc, run_length=S)
+    # per-image projection of the concatenated map (all three networks' lin_z blocks)
+    feats, wz3, bz3 = rnd(1, 512, HF, WF).contiguous(), (rnd(512, 1152) * 0.05).contiguous(), rnd(1152).contiguous()
+    g3 = torch.empty(1, HF, WF, 1152, device=dev)
+    calls["project_f16x2"] = lambda: hip.project_features(feats, wz3, bz3, g3, precision="f16x2")
+
+    measured = {}
+    for name, fn in calls.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        rec = []
+        hip.set_profile_sink(rec)
+        for _ in range(launches):
+            fn()
+        torch.cuda.synchronize()
+        hip.set_profile_sink(None)
+        # project_pyramid = 4 projection launches + upsample_add inside one entry point: the per-kernel figure comes from
+        # rocprofv3 (--stats); the HIP-event figure of that row is the whole entry point and says so
+        measured[name] = sum(e0.elapsed_time(e1) for _, e0, e1 in rec) / len(rec) * 1e-3
+    return measured
+
+
+def table(durations, source):
+    rows = []
+    for name, (kernel, nbytes, what) in workloads().items():
+        t = durations.get(name)
+        row = {"kernel": kernel, "algorithmic_bytes": nbytes, "counted": what, "seconds": t, "source": source}
+        if t:
+            row["GB_per_s"] = round(nbytes / t / 1e9, 1)
+            row["frac_of_8TBps"] = round(nbytes / t / HBM_PEAK, 4)
+            row["microseconds"] = round(t * 1e6, 2)
+        rows.append(row)
+    return rows
+
+
+def from_stats(path):
+    """rocprofv3 --stats kernel_stats.csv -> {workload: average seconds}."""
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            nm = r.get("Name") or r.get("KernelName") or ""
+            avg = float(r.get("AverageNs") or r.get("Average") or 0.0) * 1e-9
+            for name, (kernel, _, _) in workloads().items():
+                if nm.startswith(kernel) or (" " + kernel) in nm or ("::" + kernel) in nm:
+                    # several instantiations of one kernel (project_kernel_f16x2<KS>): keep the one with most calls
+                    calls = int(r.get("Calls") or 0)
+                    if name not in out or calls > out[name][1]:
+                        out[name] = (avg, calls)
+    return {k: v[0] for k, v in out.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--stats", help="rocprofv3 kernel_stats.csv of a run of this script")
+    ap.add_argument("--json", help="write the rows here")
+    a = ap.parse_args()
+    if a.stats:
+        rows = table(from_stats(a.stats), f"rocprofv3 --kernel-trace --stats average ({os.path.basename(a.stats)})")
+    else:
+        rows = table(run(a.launches), "HIP events around the C-ABI entry point (upsample_add row: the whole njf_project_pyramid "
+                                      "entry point, 4 projections + the add)")
+    print(f"{'kernel':28s} {'alg. MB':>9s} {'us':>9s} {'GB/s':>9s} {'of 8 TB/s':>10s}")
+    for r in rows:
+        if r.get("seconds"):
+            print(f"{r['kernel']:28s} {r['algorithmic_bytes'] / 1e6:9.2f} {r['microseconds']:9.2f} {r['GB_per_s']:9.1f} {r['frac_of_8TBps']:10.3f}")
+        else:
+            print(f"{r['kernel']:28s} {r['algorithmic_bytes'] / 1e6:9.2f} {'-':>9s}")
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump({"hbm_peak_bytes_per_s": HBM_PEAK, "rows": rows}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
