@@ -74,6 +74,11 @@ def parse():
                     help="rays per CPU-baseline pass (one patch_render chunk), taken at a constant stride over the frame")
     ap.add_argument("--cpu-passes", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank")
+    ap.add_argument("--graph", action="store_true",
+                    help="strong scaling: replay each rank's compute (Model.forward + partial reduction) as ONE HIP graph; the "
+                         "per-kernel HIP-event timings then come from an eager pass after the timed loop")
+    ap.add_argument("--legacy-step", action="store_true",
+                    help="the round-2 step (ATen depth clip / loss sums / concatenation, three collectives) for A/B")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--batch", type=int, default=1)
@@ -240,8 +245,23 @@ def main():
     rin = RenderingInput(o_loc, d_loc, z_near, z_far)
     rob = RobotInput(action)
 
+    # strong scaling (and N = 1): parallel.ShardedFrameStep -- Model.forward on the shard with the frame-level reductions
+    # (depth-clip bounds, loss sums) folded into the render kernel's epilogue, ONE all_gather of [pixels | 4 scalars] per
+    # step, one assemble launch (global depth clip + losses).  Weak scaling / --legacy-step: the round-2 step.
+    use_frame_step = strong and not args.legacy_step
+    frame_steps = {}
+    if use_frame_step:
+        for prec, m in models.items():
+            fs = parallel.ShardedFrameStep(m, BB, HH * WW, device, world_size=shard_world, rank=shard_rank,
+                                           collective=not sim_world)
+            fs.set_targets(rgb_loc, flow_loc)
+            frame_steps[prec] = fs
+
     def step(model):
         model.reset_image_cache()  # a new image every step: the per-image projection stays inside the timed region
+        if use_frame_step:
+            frame, scalars, out = frame_steps[model.decoder.precision](cam, rin, rob)
+            return out, scalars, frame
         out = model.forward(cam, rin, rob).standard_output
         # photometric + flow loss (model_wrapper.py:117-163): local sums, ONE all-reduce over the ranks
         losses = parallel.sharded_losses(out.rgb, rgb_loc, out.optical_flow, flow_loc)
@@ -253,11 +273,18 @@ def main():
     model = models[precision]
     for _ in range(args.warmup):
         step(model)
+    graphed = bool(args.graph and use_frame_step)
+    if graphed:   # record the rank-local compute once; the graph replays the per-image projection, so no cache reset
+        frame_steps[precision].capture(cam, rin, rob)
+        model.reset_image_cache = lambda: model
+        for _ in range(2):
+            step(model)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     launches = []
-    hip.set_profile_sink(launches)   # per-launch HIP events on the launch stream (roofline.achieved)
+    if not graphed:
+        hip.set_profile_sink(launches)   # per-launch HIP events on the launch stream (roofline.achieved)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(model)
@@ -266,6 +293,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     hip.set_profile_sink(None)
+    timing_note = "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"
+    if graphed:   # events cannot be read back from inside a replayed graph: an eager pass of the same step, not part of `value`
+        del model.reset_image_cache
+        frame_steps[precision]._graph = None
+        hip.set_profile_sink(launches)
+        for _ in range(args.steps):
+            step(model)
+        torch.cuda.synchronize()
+        hip.set_profile_sink(None)
+        timing_note = ("mean njf_render_forward launch duration over an EAGER pass of the same steps right after the timed "
+                       "(graph-replayed) loop, HIP events on the launch stream")
+    launches_per_step = len(launches) / max(args.steps, 1)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -333,12 +372,18 @@ def main():
                        "parallelism": f"dp{world} ({'one frame, rays sharded' if strong else 'one frame per rank'}, replicated weights "
                                       "and feature map)"},
             "kernel_ms": {k: round(v, 3) for k, v in k_ms.items()},
+            "step": {"form": ("ShardedFrameStep: Model.forward (per-image projection x2, njf_proposal_forward, njf_render_forward "
+                              "with the frame reductions in its epilogue) + njf_reduce_frame_partials + "
+                              + ("ONE all_gather of [pixels | 4 scalars] + " if world > 1 else "")
+                              + "njf_assemble_frame (global depth clip, rgb / flow loss)") if use_frame_step else
+                             "round-2 step: Model.forward + ATen depth clip, loss sums, concatenation (three collectives at N > 1)",
+                     "c_abi_launches_per_step": round(launches_per_step, 2), "hip_graph": graphed},
             "roofline": {"kernel": f"render_kernel<jacobian_mlp, {precision}> (density+colour+Jacobian MLPs + compositing)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_flop_per_launch": render_flop,
                          "mfma_issue_factor": ISSUE_FACTOR[precision],
-                         "timing": "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"},
+                         "timing": timing_note},
         }
         if sim_world:
             out["simulated"] = f"rank 0's shard of a {sim_world}-way strong split rendered on ONE GPU, no collectives: value counts only these rays"

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 14
+#define NJF_ABI_VERSION 15
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -242,6 +242,14 @@ typedef struct NjfRenderOutputs {
   float* den_act;         /* [11, P, 128] activations of the density ResnetFC */
   float* col_in;          /* [P, 32] colour-head input [geo 15 | 1 | sh 16] (action_decoder_jacobian.py:315-322) */
   float* col_act;         /* [2, P, 64] ReLU'd outputs of the colour head's first and second layer */
+  /* frame-level reductions folded into the kernel's epilogue (ABI v15; all may be NULL).  frame_partials
+   * [ceil(B*R / 4), 4]: per workgroup of four rays (min_t, max_t, sum (rgb - trgt_rgb)^2, sum (flow - trgt_flow)^2) --
+   * the bounds of render_depth's tensor-global clip (model.py:277) and the numerators of the photometric / flow mse
+   * (model_wrapper.py:117-163) of this launch's rays, reduced in a fixed order (bit-reproducible); the sums are 0 where
+   * the target pointer is NULL.  njf_reduce_frame_partials folds the rows into one 4-vector. */
+  float* frame_partials;
+  const float* trgt_rgb;  /* [B*R,3] target colours of the rays, or NULL */
+  const float* trgt_flow; /* [B*R,2] target optical flow of the rays, or NULL */
 } NjfRenderOutputs;
 
 /* bins [B*R, S+1] are spacing-domain bin edges in [0,1] (output of njf_proposal_forward or a
@@ -253,6 +261,22 @@ int njf_render_forward(const float* origins, const float* directions, int rays_p
                        const float* w_color, const float* b_color,
                        const float* w_jacobian, const float* b_jacobian,
                        const float* bins, int samples, const NjfRenderOutputs* out, int precision, void* stream);
+
+/* ---- frame-level reductions of a (ray-sharded) render: model.py:277, model_wrapper.py:117-163 ------------------------------ */
+/* partials [groups,4] (NjfRenderOutputs.frame_partials) -> out4 = (min, max, sum, sum) over the rows, one workgroup, fixed
+ * summation order.  This is the 16-byte record a rank contributes to the one collective of a ray-sharded step. */
+int njf_reduce_frame_partials(const float* partials, int groups, float* out4, void* stream);
+/* Assemble the frame of a ray-sharded step from the all-gathered per-rank packets.  packets [world, packet_floats]; the
+ * packet of rank k holds rgb [B,n_k,3] | depth [B,n_k] | flow [B,n_k,2] of its contiguous ray shard (n_k = R/world rays
+ * per batch element, the first R % world ranks one more: parallel.shard_bounds) at float offsets 0, 3*B*cap, 4*B*cap with
+ * cap = ceil(R / world), and its njf_reduce_frame_partials record in the last four floats.  Writes frame [B,R,6]
+ * (rgb | depth | flow per ray) with depth clipped to the GLOBAL [min, max] (render_depth's clip, model.py:277, which the
+ * sharded render defers to this point) and scalars6 = (global min, global max, S_rgb = global sum (rgb - trgt)^2, S_flow =
+ * global sum (flow - trgt)^2, S_rgb * rgb_scale, S_flow * flow_scale), ranks folded in rank order: with rgb_scale =
+ * 1 / (3 B R) and flow_scale = 0.01 / (2 B R) the last two are the frame's rgb loss and flow loss
+ * (model_wrapper.py:119-121,148-160). */
+int njf_assemble_frame(const float* packets, int world, int packet_floats, int batch, int rays_per_batch, float rgb_scale,
+                       float flow_scale, float* frame, float* scalars6, void* stream);
 
 /* ---- point-list evaluation (arbitrary xyz): density_decoder.py:45-71, model.py:416-456 ----- */
 /* xyz [B,N,3] world-space points, dirs [B,N,3] or NULL.  mode 0: proposal net -> density [B*N].

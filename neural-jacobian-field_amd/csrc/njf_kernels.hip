@@ -1344,6 +1344,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
       }
     }
   }
+  float flow2d[2] = {0.f, 0.f};
   if (ray_ok && lane == 0) {
     if (a.out.rgb) {
       a.out.rgb[3 * (size_t)ray] = acc_rgb[0];
@@ -1380,10 +1381,156 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
         uv[v][0] = u0 / (u2 + 1e-9f);
         uv[v][1] = u1 / (u2 + 1e-9f);
       }
-      a.out.flow[2 * (size_t)ray] = uv[1][0] - uv[0][0];
-      a.out.flow[2 * (size_t)ray + 1] = uv[1][1] - uv[0][1];
+      flow2d[0] = uv[1][0] - uv[0][0];
+      flow2d[1] = uv[1][1] - uv[0][1];
+      a.out.flow[2 * (size_t)ray] = flow2d[0];
+      a.out.flow[2 * (size_t)ray + 1] = flow2d[1];
     }
   }
+  if (a.out.frame_partials) {
+    // frame-level reductions of this workgroup's four rays (include/njf_hip.h: NjfRenderOutputs.frame_partials), in a fixed
+    // order
+    float se_rgb = 0.f, se_flow = 0.f;
+    if (ray_ok && lane == 0) {
+      if (a.out.trgt_rgb && a.out.rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d = acc_rgb[c] - a.out.trgt_rgb[3 * (size_t)ray + c];
+          se_rgb = fmaf(d, d, se_rgb);
+        }
+      }
+      if (a.out.trgt_flow && a.out.flow && a.rc.cams.trgt_w2c && a.rc.cams.trgt_k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float d = flow2d[c] - a.out.trgt_flow[2 * (size_t)ray + c];
+          se_flow = fmaf(d, d, se_flow);
+        }
+      }
+    }
+    __syncthreads();  // every wave has consumed its last weight chunk: the weight buffers are free
+    if (lane == 0) {
+      njf_lds[4 * wave + 0] = ray_ok ? tmin : 3.0e38f;
+      njf_lds[4 * wave + 1] = ray_ok ? tmax : -3.0e38f;
+      njf_lds[4 * wave + 2] = se_rgb;
+      njf_lds[4 * wave + 3] = se_flow;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float mn = njf_lds[0], mx = njf_lds[1], s0 = njf_lds[2], s1 = njf_lds[3];
+#pragma unroll
+      for (int w = 1; w < NJF_WAVES; ++w) {
+        mn = fminf(mn, njf_lds[4 * w]);
+        mx = fmaxf(mx, njf_lds[4 * w + 1]);
+        s0 += njf_lds[4 * w + 2];
+        s1 += njf_lds[4 * w + 3];
+      }
+      float* dst = a.out.frame_partials + 4 * (size_t)wg;
+      dst[0] = mn;
+      dst[1] = mx;
+      dst[2] = s0;
+      dst[3] = s1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame-level reductions of a (ray-sharded) render: fold the per-workgroup partials of the render kernel's epilogue, and
+// assemble the frame from the all-gathered per-rank packets (include/njf_hip.h).  Fixed orders: bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reduce_frame_partials_kernel(const float* __restrict__ partials, int groups,
+                                                                    float* __restrict__ out4) {
+  __shared__ float red[4][256];
+  float mn = 3.0e38f, mx = -3.0e38f, s0 = 0.f, s1 = 0.f;
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    const f32x4 v = *(const f32x4*)(partials + 4 * (size_t)g);
+    mn = fminf(mn, v[0]);
+    mx = fmaxf(mx, v[1]);
+    s0 += v[2];
+    s1 += v[3];
+  }
+  red[0][threadIdx.x] = mn;
+  red[1][threadIdx.x] = mx;
+  red[2][threadIdx.x] = s0;
+  red[3][threadIdx.x] = s1;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] = fminf(red[0][threadIdx.x], red[0][threadIdx.x + o]);
+      red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + o]);
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+      red[3][threadIdx.x] += red[3][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out4[threadIdx.x] = red[threadIdx.x][0];
+}
+
+extern "C" int njf_reduce_frame_partials(const float* partials, int groups, float* out4, void* stream) {
+  if (!partials || !out4) return NJF_E_NULL;
+  if (groups < 1) return NJF_E_SHAPE;
+  reduce_frame_partials_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials, groups, out4);
+  return launch_status();
+}
+
+__global__ void __launch_bounds__(256) assemble_frame_kernel(const float* __restrict__ packets, int world, int packet_floats,
+                                                             int batch, int rays, int cap, float rgb_scale, float flow_scale,
+                                                             float* __restrict__ frame, float* __restrict__ scalars6) {
+  // global bounds / sums from the trailing record of every packet, ranks in order (every workgroup recomputes them:
+  // world <= a few dozen, and it saves a launch)
+  float mn = 3.0e38f, mx = -3.0e38f, s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < world; ++k) {
+    const float* rec = packets + (size_t)k * packet_floats + (packet_floats - 4);
+    mn = fminf(mn, rec[0]);
+    mx = fmaxf(mx, rec[1]);
+    s0 += rec[2];
+    s1 += rec[3];
+  }
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    scalars6[0] = mn;
+    scalars6[1] = mx;
+    scalars6[2] = s0;
+    scalars6[3] = s1;
+    scalars6[4] = s0 * rgb_scale;    // e.g. 1 / (B*R*3): the photometric mse of the whole frame (model_wrapper.py:119-121)
+    scalars6[5] = s1 * flow_scale;   // e.g. 0.01 / (B*R*2): flow_loss (model_wrapper.py:148-160)
+  }
+  if (i >= (long long)batch * rays) return;
+  const int b = (int)(i / rays), r = (int)(i % rays);
+  // parallel.shard_bounds: the first `rem` ranks own q + 1 rays, the others q
+  const int q = rays / world, rem = rays % world;
+  int k, local;
+  if (r < rem * (q + 1)) {
+    k = r / (q + 1);
+    local = r - k * (q + 1);
+  } else {
+    k = rem + (r - rem * (q + 1)) / max(q, 1);
+    local = r - rem * (q + 1) - (k - rem) * q;
+  }
+  const int n_k = q + (k < rem ? 1 : 0);
+  const float* pk = packets + (size_t)k * packet_floats;
+  const float* rgb = pk + ((size_t)b * n_k + local) * 3;
+  const float* dep = pk + (size_t)3 * batch * cap + (size_t)b * n_k + local;
+  const float* flw = pk + (size_t)4 * batch * cap + ((size_t)b * n_k + local) * 2;
+  float* dst = frame + (size_t)i * 6;
+  dst[0] = rgb[0];
+  dst[1] = rgb[1];
+  dst[2] = rgb[2];
+  dst[3] = fminf(fmaxf(dep[0], mn), mx);   // torch.clip(depth, steps.min(), steps.max()) with the GLOBAL bounds
+  dst[4] = flw[0];
+  dst[5] = flw[1];
+}
+
+extern "C" int njf_assemble_frame(const float* packets, int world, int packet_floats, int batch, int rays_per_batch,
+                                  float rgb_scale, float flow_scale, float* frame, float* scalars6, void* stream) {
+  if (!packets || !frame || !scalars6) return NJF_E_NULL;
+  if (world < 1 || batch < 1 || rays_per_batch < 1) return NJF_E_SHAPE;
+  const int cap = (rays_per_batch + world - 1) / world;
+  if (packet_floats < 6 * batch * cap + 4) return NJF_E_SHAPE;
+  const long long total = (long long)batch * rays_per_batch;
+  assemble_frame_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(packets, world, packet_floats, batch,
+                                                                                          rays_per_batch, cap, rgb_scale, flow_scale,
+                                                                                          frame, scalars6);
+  return launch_status();
 }
 
 // =============================================================================================

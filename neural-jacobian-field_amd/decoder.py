@@ -135,12 +135,21 @@ class _HoistCache:
         return self.gmap
 
 
+_ZEROS: Dict[tuple, torch.Tensor] = {}
+
+
 def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trgt_w2c=None, trgt_k=None, action_dim=None,
              action=None):
     """``action``: what the kernel contracts the head's output with (default: the robot action itself)."""
     b = enc.extrinsics.shape[0]
     dev = enc.extrinsics.device
-    zeros = torch.zeros(b, dtype=torch.float32, device=dev)
+    zeros = None
+    if z_near is None or z_far is None:
+        zeros = _ZEROS.get((b, str(dev)))
+        if zeros is None:   # a constant: filled once per (batch, device), not per call
+            zeros = torch.zeros(b, dtype=torch.float32, device=dev)
+            if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):   # (a fill captured into a graph has not run yet)
+                _ZEROS[(b, str(dev))] = zeros
     if action is None:
         action = enc.action
     w2c = hip.inverse(enc.extrinsics) if enc.extrinsics_inv is None else enc.extrinsics_inv

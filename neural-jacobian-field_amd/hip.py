@@ -89,7 +89,7 @@ class RenderOutputs(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "rgb", "depth", "step_minmax", "flow", "pos", "pos_warped", "action_features",
         "weights", "density", "color", "sample_flow", "jacobian", "jac_act", "jac_pe", "foot_idx", "foot_w",
-        "den_act", "col_in", "col_act")]
+        "den_act", "col_in", "col_act", "frame_partials", "trgt_rgb", "trgt_flow")]
 
 
 class PyramidLevel(C.Structure):
@@ -129,6 +129,8 @@ _SIGNATURES = {
     "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
+    "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
+    "njf_assemble_frame": ([_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
 }
@@ -558,6 +560,28 @@ def relu_backward(upstream: torch.Tensor, act: torch.Tensor, residual: Optional[
     _launch("njf_relu_backward", load_library().njf_relu_backward, _ptr(upstream, "upstream"), _ptr(act, "act"), _ptr(residual, "residual"), points,
                                             channels, RELU_BACKWARD_ROWS, _ptr(out, "out"), _ptr(partial, "partial"))
     return out, (partial.sum(0) if want_colsum else None)
+
+
+def frame_partial_groups(total_rays: int) -> int:
+    """Rows of NjfRenderOutputs.frame_partials for a launch of ``total_rays`` rays (one per workgroup of four rays)."""
+    return (total_rays + 3) // 4
+
+
+def reduce_frame_partials(partials: torch.Tensor, out4: torch.Tensor) -> None:
+    """partials [groups,4] -> out4 [4] = (min_t, max_t, sum (rgb - trgt)^2, sum (flow - trgt)^2), fixed order."""
+    _launch("njf_reduce_frame_partials", load_library().njf_reduce_frame_partials, _ptr(partials, "partials"),
+            partials.shape[0], _ptr(out4, "out4"))
+
+
+def assemble_frame(packets: torch.Tensor, batch: int, rays_per_batch: int, frame: torch.Tensor, scalars6: torch.Tensor,
+                   rgb_scale: float = 0.0, flow_scale: float = 0.0) -> None:
+    """packets [world, packet_floats] (all-gathered, include/njf_hip.h: njf_assemble_frame) -> frame [B,R,6] with the
+    depth clipped to the global bounds, scalars6 = (min, max, S_rgb, S_flow, S_rgb * rgb_scale, S_flow * flow_scale)."""
+    world, packet_floats = packets.shape
+    if tuple(frame.shape) != (batch, rays_per_batch, 6) or scalars6.numel() != 6:
+        raise ValueError("njf_hip: assemble_frame shape mismatch")
+    _launch("njf_assemble_frame", load_library().njf_assemble_frame, _ptr(packets, "packets"), world, packet_floats, batch,
+            rays_per_batch, float(rgb_scale), float(flow_scale), _ptr(frame, "frame"), _ptr(scalars6, "scalars6"))
 
 
 def alpha_weights(deltas, densities, weights) -> None:

@@ -142,6 +142,11 @@ class Model(nn.Module):
         # the ones last checked (training) -- measures the largest matrix operand on the exact-fp32 path and moves the
         # model to "f32" with a warning if fp16 could overflow.  `auto_range_check = False` turns it off
         # (calibrate_precision stays available as the explicit form).
+        # Ray-sharded steps (parallel.ShardedFrameStep) hand the forward pass its output buffers -- views of the packet the
+        # rank contributes to the step's one collective -- and the loss targets; the render kernel then also writes the
+        # per-workgroup partials of the frame-level reductions and the depth clip is deferred to njf_assemble_frame.
+        self.frame_io: Optional[Dict[str, torch.Tensor]] = None
+        self._inverse_cache: Dict[str, tuple] = {}
         self.auto_range_check = True
         self.range_check_interval = 100
         self._range_checked = None      # weights signature of the last check
@@ -183,6 +188,17 @@ class Model(nn.Module):
             return   # a check synchronises with the host; it runs on the first eager forward instead
         self._range_pending, self._range_forwards, self._range_checked = False, 0, sig
         self.calibrate_precision(camera_input, rendering_input, robot_input)
+
+    def _inverse(self, name: str, m: torch.Tensor) -> torch.Tensor:
+        """hip.inverse(m), kept while ``m`` is the same tensor object at the same version (a camera rig that does not move
+        costs no launch per forward pass; the cache holds a reference to ``m``, so its address cannot be recycled)."""
+        hit = self._inverse_cache.get(name)
+        if hit is not None and hit[0] is m and hit[1] == m._version:
+            return hit[2]
+        inv = hip.inverse(m)
+        if not torch.cuda.is_current_stream_capturing():   # a graph-private tensor must not outlive its capture
+            self._inverse_cache[name] = (m, m._version, inv)
+        return inv
 
     def reset_image_cache(self) -> "Model":
         """Forget the hoisted feature maps.  They are cached per feature TENSOR (object + version counter), which is right
@@ -360,8 +376,8 @@ class Model(nn.Module):
         public entry point -- forward, encode_image, patch_render, the training paths, renderer.FusedRenderer -- ends here.
         ``want_sample_outputs`` adds per-sample colour and scene flow; ``final_bins`` ([B,R,S+1] spacing bins) skips the
         proposal levels and renders exactly those samples; ``ctxt_w2c`` / ``trgt_w2c`` are inverses the caller already has."""
-        if ctxt_w2c is None:  # one inverse per forward pass, shared by the proposal levels and the final pass
-            ctxt_w2c = hip.inverse(camera_input.ctxt_extrinsics)
+        if ctxt_w2c is None:  # one inverse per camera rig, shared by the proposal levels and the final pass
+            ctxt_w2c = self._inverse("ctxt", camera_input.ctxt_extrinsics)
         enc = PixelEncoding(features=features, extrinsics=camera_input.ctxt_extrinsics,
                             intrinsics=camera_input.ctxt_intrinsics, action=robot_input.robot_action, extrinsics_inv=ctxt_w2c)
         ray_bundle = self.compute_ray_bundle(rendering_input)
@@ -379,8 +395,16 @@ class Model(nn.Module):
         a3 = 3 * self.decoder.kernel_action_dim  # 3A for the Jacobian decoders, 3 for flow_mlp (the flow itself)
         dev = o.device
         f32 = dict(dtype=torch.float32, device=dev)
-        outs: Dict[str, torch.Tensor] = {"rgb": torch.empty(b, r, 3, **f32), "depth": torch.empty(b, r, 1, **f32),
-                                         "step_minmax": torch.empty(b, r, 2, **f32), "flow": torch.empty(b, r, 2, **f32)}
+        io = self.frame_io if not (dump_jacobian or dump_perception) else None
+        if io is not None:   # caller-owned pixel buffers + in-kernel frame reductions (parallel.ShardedFrameStep)
+            if tuple(io["rgb"].shape) != (b, r, 3):
+                raise ValueError(f"Model.frame_io was set up for {tuple(io['rgb'].shape[:2])} rays, this call renders {(b, r)}")
+            outs: Dict[str, torch.Tensor] = {k: io[k] for k in ("rgb", "depth", "flow", "frame_partials")}
+            outs.update({k: io[k] for k in ("trgt_rgb", "trgt_flow") if io.get(k) is not None})
+            clip_depth = False   # deferred: the global bounds exist only after the step's collective
+        else:
+            outs = {"rgb": torch.empty(b, r, 3, **f32), "depth": torch.empty(b, r, 1, **f32),
+                    "step_minmax": torch.empty(b, r, 2, **f32), "flow": torch.empty(b, r, 2, **f32)}
         if want_lists or want_vis or want_samples:
             outs["weights"] = torch.empty(b, r, s, **f32)
         if want_vis:
@@ -417,7 +441,7 @@ class Model(nn.Module):
         w, bd, bc, bj = self.decoder.packed()
         fmap = hip.make_feature_map(self.decoder.hoisted_map(features, enc.action))
         cams = _cameras(enc, True, rendering_input.z_near, rendering_input.z_far,
-                        (hip.inverse(camera_input.trgt_extrinsics) if trgt_w2c is None else trgt_w2c).contiguous(),
+                        (self._inverse("trgt", camera_input.trgt_extrinsics) if trgt_w2c is None else trgt_w2c).contiguous(),
                         camera_input.trgt_intrinsics.contiguous(), action=self.decoder.kernel_action(enc.action))
         hip.render_forward(o, d, cams, fmap, self.decoder.GOFF_DENSITY, self.decoder.GOFF_JACOBIAN, w, bd, bc, bj, bins, s,
                            {k: v for k, v in outs.items() if torch.is_tensor(v)},

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 14
+    assert lib.njf_abi_version() == 15
 
 
 def test_hoisted_channel_order(built):
@@ -241,6 +241,79 @@ def test_ray_sharding_world_size_2_gloo(tmp_path):
     assert all(open(os.path.join(tmp_path, f"ok{r}")).read() == "True" for r in range(2))
 
 
+class _FakeShardModel:
+    """Stands in for Model in the layout test of parallel.ShardedFrameStep: `forward` fills the buffers the step handed over
+    (frame_io) with this rank's slice of a known frame and with the per-group partials the render kernel's epilogue writes."""
+
+    def __init__(self, frame_rgb, frame_depth, frame_flow, tmin, tmax, lo, hi):
+        self.frame_io = None
+        self.args = (frame_rgb, frame_depth, frame_flow, tmin, tmax, lo, hi)
+
+    def forward(self, cam, rin, rob):
+        rgb, depth, flow, tmin, tmax, lo, hi = self.args
+        io = self.frame_io
+        io["rgb"].copy_(rgb[:, lo:hi])
+        io["depth"].copy_(depth[:, lo:hi])
+        io["flow"].copy_(flow[:, lo:hi])
+        b, n = rgb.shape[0], hi - lo
+        flat = lambda t: t[:, lo:hi].reshape(b * n, -1)
+        se_rgb = ((flat(rgb) - io["trgt_rgb"].reshape(b * n, 3)) ** 2).sum(-1)
+        se_flow = ((flat(flow) - io["trgt_flow"].reshape(b * n, 2)) ** 2).sum(-1)
+        groups = io["frame_partials"].shape[0]
+        pad = groups * 4 - b * n
+        grp = lambda v, fill: torch.cat([v, torch.full((pad,), fill)]).view(groups, 4)
+        io["frame_partials"][:, 0] = grp(flat(tmin)[:, 0], 3.0e38).min(-1).values
+        io["frame_partials"][:, 1] = grp(flat(tmax)[:, 0], -3.0e38).max(-1).values
+        io["frame_partials"][:, 2] = grp(se_rgb, 0.0).sum(-1)
+        io["frame_partials"][:, 3] = grp(se_flow, 0.0).sum(-1)
+        return "out"
+
+
+def _frame_step_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import frame_reference as fr
+    from neural_jacobian_field_amd import parallel as par
+    g = torch.Generator().manual_seed(1)
+    B, R = 2, 101                                    # ragged: 51 + 50 rays
+    rgb, trg = torch.rand(B, R, 3, generator=g), torch.rand(B, R, 3, generator=g)
+    flow, tflow = torch.randn(B, R, 2, generator=g), torch.randn(B, R, 2, generator=g)
+    depth = torch.rand(B, R, 1, generator=g) * 12
+    tmin, tmax = torch.rand(B, R, 1, generator=g) + 0.5, torch.rand(B, R, 1, generator=g) + 9
+    lo, hi = par.shard_bounds(R, world, rank)
+    step = par.ShardedFrameStep(_FakeShardModel(rgb, depth, flow, tmin, tmax, lo, hi), B, R, "cpu",
+                                reduce_fn=fr.reduce_frame_partials, assemble_fn=fr.assemble_frame)
+    assert (step.lo, step.hi) == (lo, hi) and step.world == world
+    step.set_targets(trg[:, lo:hi], tflow[:, lo:hi])
+    frame, scalars, out = step(None, None, None)
+    ref_depth = torch.clip(depth, tmin.min(), tmax.max())
+    ok = (out == "out" and torch.equal(frame[..., 0:3], rgb) and torch.equal(frame[..., 3:4], ref_depth)
+          and torch.equal(frame[..., 4:6], flow)
+          and abs(scalars[4] - torch.nn.functional.mse_loss(rgb, trg)) < 1e-6
+          and abs(scalars[5] - 0.01 * torch.nn.functional.mse_loss(flow, tflow)) < 1e-6
+          and scalars[0] == tmin.min() and scalars[1] == tmax.max())
+    # a second step reuses every buffer (nothing is reallocated) and reproduces the first
+    ptr = step.frame.data_ptr()
+    frame2, scalars2, _ = step(None, None, None)
+    ok = ok and frame2.data_ptr() == ptr and torch.equal(frame2, frame) and torch.equal(scalars2, scalars)
+    open(os.path.join(tmp, f"fs{rank}"), "w").write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_frame_step_world_size_2_gloo(tmp_path):
+    """parallel.ShardedFrameStep over 2 gloo ranks (ragged shards): ONE all_gather of [pixels | 4 scalars] + the assemble
+    step reproduce the unsharded frame, the tensor-global depth clip and the two losses.  The two HIP kernels are replaced
+    by their tensor-op restatements (oracle/frame_reference.py); tests/test_properties_gpu.py checks the kernels against the
+    same restatements on the GPU."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_frame_step_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(open(os.path.join(tmp_path, f"fs{r}")).read() == "True" for r in range(2))
+
+
 def _synthetic_linearization(device="cpu"):
     from neural_jacobian_field_amd.inverse_dynamics import FlowLinearization
     gen = torch.Generator().manual_seed(3)
@@ -393,7 +466,7 @@ def test_header_is_plain_c(tmp_path, built):
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == len(names) and int(out[1]) == 14
+    assert int(out[0]) == len(names) and int(out[1]) == 15
 
 
 def test_static_isa_properties_of_the_fused_kernels():

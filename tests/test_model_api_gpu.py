@@ -126,7 +126,9 @@ def test_plain_checkpoint_load_never_renders_finite_but_wrong_pixels(model_and_g
     plain = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
     plain.load_state_dict(sd)                                   # the snippet of INTEGRATION.md section A ends here
     assert plain.decoder.precision == "f16f6"                   # the package default, fp16-carried
-    with warnings.catch_warnings(record=True) as caught:
+    # (every model below renders from the reference's encoder output: MIOpen's convolutions are not bit-reproducible from
+    # run to run, and the comparison is bit for bit)
+    with warnings.catch_warnings(record=True) as caught, _from_reference_features(plain, g):
         warnings.simplefilter("always")
         out = plain.forward(cam, rin, rob).standard_output
     assert any("fp16's range" in str(w.message) for w in caught), [str(w.message) for w in caught]
@@ -135,14 +137,16 @@ def test_plain_checkpoint_load_never_renders_finite_but_wrong_pixels(model_and_g
     by_hand.auto_range_check = False
     by_hand.load_state_dict(sd)
     by_hand.set_precision("f32")
-    ref = by_hand.forward(cam, rin, rob).standard_output
+    with _from_reference_features(by_hand, g):
+        ref = by_hand.forward(cam, rin, rob).standard_output
     for a, b in ((out.rgb, ref.rgb), (out.depth, ref.depth), (out.optical_flow, ref.optical_flow)):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     # the guard is what made the difference: with it switched off the same checkpoint renders something else in f16f6
     unguarded = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
     unguarded.auto_range_check = False
     unguarded.load_state_dict(sd)
-    bad = unguarded.forward(cam, rin, rob).standard_output
+    with _from_reference_features(unguarded, g):
+        bad = unguarded.forward(cam, rin, rob).standard_output
     assert unguarded.decoder.precision == "f16f6"
     assert not torch.isfinite(bad.rgb).all() or rel(bad.rgb, ref.rgb) > 1e-3   # non-finite, or finite and WRONG
     # ... and a sane checkpoint is checked once, silently, and keeps the default precision
@@ -610,7 +614,9 @@ def test_plain_checkpoint_load_never_renders_finite_but_wrong_pixels(model_and_g
     plain = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
     plain.load_state_dict(sd)                                   # the snippet of INTEGRATION.md section A ends here
     assert plain.decoder.precision == "f16f6"                   # the package default, fp16-carried
-    with warnings.catch_warnings(record=True) as caught:
+    # (every model below renders from the reference's encoder output: MIOpen's convolutions are not bit-reproducible from
+    # run to run, and the comparison is bit for bit)
+    with warnings.catch_warnings(record=True) as caught, _from_reference_features(plain, g):
         warnings.simplefilter("always")
         out = plain.forward(cam, rin, rob).standard_output
     assert any("fp16's range" in str(w.message) for w in caught), [str(w.message) for w in caught]
@@ -619,14 +625,16 @@ def test_plain_checkpoint_load_never_renders_finite_but_wrong_pixels(model_and_g
     by_hand.auto_range_check = False
     by_hand.load_state_dict(sd)
     by_hand.set_precision("f32")
-    ref = by_hand.forward(cam, rin, rob).standard_output
+    with _from_reference_features(by_hand, g):
+        ref = by_hand.forward(cam, rin, rob).standard_output
     for a, b in ((out.rgb, ref.rgb), (out.depth, ref.depth), (out.optical_flow, ref.optical_flow)):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     # the guard is what made the difference: with it switched off the same checkpoint renders something else in f16f6
     unguarded = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
     unguarded.auto_range_check = False
     unguarded.load_state_dict(sd)
-    bad = unguarded.forward(cam, rin, rob).standard_output
+    with _from_reference_features(unguarded, g):
+        bad = unguarded.forward(cam, rin, rob).standard_output
     assert unguarded.decoder.precision == "f16f6"
     assert not torch.isfinite(bad.rgb).all() or rel(bad.rgb, ref.rgb) > 1e-3   # non-finite, or finite and WRONG
     # ... and a sane checkpoint is checked once, silently, and keeps the default precision

@@ -260,6 +260,72 @@ def test_binding_error_behaviour(dev):
         Model(model_cfg_from_dict({"action_dim": 11}))
 
 
+def test_sharded_frame_step_equals_the_unsharded_forward(dev):
+    """parallel.ShardedFrameStep (frame-level reductions in the render kernel's epilogue, njf_reduce_frame_partials,
+    njf_assemble_frame) on a ragged 3-way split rendered rank by rank on one GPU: the assembled frame equals the plain
+    Model.forward of the whole frame -- rgb and flow bit for bit, depth including the tensor-global clip (model.py:277) --
+    the two losses equal torch's mse on the full outputs, and both kernels equal their tensor-op restatements
+    (oracle/frame_reference.py) on the same packets."""
+    import frame_reference as fr
+    import parity_harness as ph
+    from neural_jacobian_field_amd import hip, parallel
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    B, H, W, S = 2, 24, 20, 48                                   # 480 rays per element: 160 + 160 + 160 would be even, so use 7 ranks
+    case = ph.make_case(B, H, W, None, 8, seed=2, identity_context=False)
+    cfg = model_cfg_from_dict({"action_dim": 8, "encoder": {"name": "precomputed"},
+                               "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                               "action_decoder": {"name": "jacobian_mlp"}})
+    model = Model(cfg).to(dev).eval().requires_grad_(False)
+    model.load_state_dict({k: v.to(dev) for k, v in case["params"].items()}, strict=True)
+    model.encoder.set_features(case["feats"].to(dev))
+    c = case["cams"]
+    d = lambda t: t.to(dev)
+    cam = CameraInput(None, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+    rob = RobotInput(d(case["action"]))
+    o, dr = d(case["origins"]), d(case["directions"])
+    R = o.shape[1]
+    full = model.forward(cam, RenderingInput(o, dr, d(c["z_near"]), d(c["z_far"])), rob).standard_output
+    g = torch.Generator().manual_seed(5)
+    trgt_rgb, trgt_flow = torch.rand(B, R, 3, generator=g).to(dev), torch.randn(B, R, 2, generator=g).to(dev)
+    world = 7
+    packets, steps = [], []
+    for k in range(world):
+        st = parallel.ShardedFrameStep(model, B, R, dev, world_size=world, rank=k, collective=False)
+        st.set_targets(trgt_rgb[:, st.lo:st.hi], trgt_flow[:, st.lo:st.hi])
+        out = st.local(cam, RenderingInput(o[:, st.lo:st.hi].contiguous(), dr[:, st.lo:st.hi].contiguous(), d(c["z_near"]),
+                                           d(c["z_far"])), rob)
+        assert out.standard_output.rgb.data_ptr() == st.rgb.data_ptr()       # written in place: no copy, no cat
+        rec = torch.empty(4, device=dev)
+        fr.reduce_frame_partials(st.partials, rec)                            # kernel vs restatement on the same partials
+        assert torch.equal(rec[:2], st.record[:2]) and ph.rel_err(rec[2:], st.record[2:]) < 1e-5
+        packets.append(st.packets[k].clone())
+        steps.append(st)
+    assert model.frame_io is None
+    pk = torch.stack(packets)
+    frame, scal = torch.empty(B, R, 6, device=dev), torch.empty(6, device=dev)
+    hip.assemble_frame(pk, B, R, frame, scal, steps[0].rgb_scale, steps[0].flow_scale)
+    frame_ref, scal_ref = torch.empty_like(frame), torch.empty_like(scal)
+    fr.assemble_frame(pk, B, R, frame_ref, scal_ref, steps[0].rgb_scale, steps[0].flow_scale)
+    assert torch.equal(frame, frame_ref) and torch.equal(scal[:2], scal_ref[:2]) and ph.rel_err(scal[2:], scal_ref[2:]) < 1e-5
+    assert torch.equal(frame[..., 0:3], full.rgb) and torch.equal(frame[..., 4:6], full.optical_flow)
+    assert torch.equal(frame[..., 3:4], full.depth)                           # same global clip bounds, same values
+    assert abs(scal[4].item() / torch.nn.functional.mse_loss(full.rgb, trgt_rgb).item() - 1) < 1e-5
+    assert abs(scal[5].item() / (0.01 * torch.nn.functional.mse_loss(full.optical_flow, trgt_flow).item()) - 1) < 1e-5
+    # the whole step on one rank (world 1), eager and as a replayed HIP graph, reproduces the frame bit for bit
+    one = parallel.ShardedFrameStep(model, B, R, dev, world_size=1, rank=0)
+    one.set_targets(trgt_rgb, trgt_flow)
+    rin = RenderingInput(o, dr, d(c["z_near"]), d(c["z_far"]))
+    f1, s1, _ = one(cam, rin, rob)
+    assert torch.equal(f1, frame) and ph.rel_err(s1[2:], scal[2:]) < 1e-5
+    f1 = f1.clone()
+    one.capture(cam, rin, rob)
+    one.frame.zero_()
+    f2, s2, _ = one()
+    torch.cuda.synchronize()
+    assert torch.equal(f2, f1) and torch.equal(s2, s1)
+
+
 # ---- BASELINE config 5 at its full size: 512 x 512 rays, F = [1,512,256,256], A = 6 --------------------------------------
 @pytest.fixture(scope="module")
 def full_frame_c5(dev):

@@ -28,3 +28,12 @@ if [ "$STEP" = all ] || [ "$STEP" = configs ]; then
   done > $O/simulate_world.txt
   tail -c 400 $O/simulate_world.txt
 fi
+if [ "$STEP" = scaling ]; then   # the N > 1 code on one GPU: RCCL with one rank, and rank 0's shard of an 8-way split, eager / graph / round-2 step
+  for extra in "" "--graph" "--legacy-step"; do
+    echo "FORCE-DIST $extra"; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-precisions --force-dist $extra 2>$O/fd.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_ms'], d.get('step',{}).get('c_abi_launches_per_step'))"
+    for n in 2 4 8; do
+      echo "SIM $n $extra"; python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-other-precisions --simulate-world $n $extra 2>>$O/fd.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['kernel_ms'])"
+    done
+  done > $O/scaling_dry.txt 2>&1
+  cat $O/scaling_dry.txt
+fi
