@@ -174,6 +174,12 @@ int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels, const flo
  * torch.cat) in one pass from the NCHW latents -- the matrix the lin_z weight gradients contract against on the training
  * path (the forward pass never forms it, see njf_project_pyramid).  C_l % 4 == 0. */
 int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels, int batch, float* out, void* stream);
+/* Adjoint of njf_upsample_concat (the encoder tail's backward pass: what autograd runs as slice +
+ * upsample_bilinear2d_backward for encoder_resnet.py:78-86).  grad [B*H_0*W_0, sum C_l] channels-last (the gradient
+ * w.r.t. the matrix njf_upsample_concat writes) -> levels[l].feats receives the gradient of latent l, [B,C_l,H_l,W_l]
+ * NCHW (the `feats` pointers of `levels` are the OUTPUTS here; geometry as for njf_upsample_concat).  Gather form, no
+ * atomics: bit-reproducible.  One launch per level. */
+int njf_upsample_concat_backward(const float* grad, const NjfPyramidLevel* levels, int num_levels, int batch, void* stream);
 
 /* Channel order of the hoisted map.  Inside every block of `block_channels` channels (128 for a ResnetFC's lin_z layer,
  * 64 for the transformer head's query projection) logical feature f of the layer is stored at position
@@ -295,6 +301,16 @@ int njf_alpha_weights(const float* deltas, const float* densities, int rays, int
 /* PDFSampler.generate_ray_samples (ray_samplers.py:351-451) on spacing bins. */
 int njf_pdf_resample(const float* weights, const float* bins_in, int bins_per_ray, int s_in, const float* u,
                      int u_per_ray, int s_out, float anneal, int rays, float* bins_out, void* stream);
+
+/* ---- training: backward of alpha compositing ------------------------------------------------------------------------------- */
+/* What autograd runs for RaySamples.get_weights (ray_samplers.py:77-101), render_rgb and the UN-clipped render_depth
+ * (model.py:257-279), as one launch: deltas, steps (sample mid-points), sigma [rays,S], color [rays,S,3] (or NULL) are the
+ * forward pass's per-sample fields; g_weights [rays,S], g_rgb [rays,3], g_depth [rays] (each may be NULL) the gradients
+ * w.r.t. the weights, the composited colour and the depth before render_depth's clip.  Writes g_sigma [rays,S] and (when not
+ * NULL) g_color [rays,S,3].  One wave per ray, fixed summation order (bit-reproducible). */
+int njf_composite_backward(const float* deltas, const float* steps, const float* sigma, const float* color,
+                           const float* g_weights, const float* g_rgb, const float* g_depth, int rays, int samples,
+                           float* g_sigma, float* g_color, void* stream);
 
 /* ---- training: backward of the pixel-aligned bilinear sampling -------------------------------- */
 /* Input gradient of F.grid_sample(bilinear, border, align_corners=True) as get_pixel_aligned_features uses it

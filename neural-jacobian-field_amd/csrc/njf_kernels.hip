@@ -698,6 +698,100 @@ extern "C" int njf_upsample_concat(const NjfPyramidLevel* levels, int num_levels
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adjoint of njf_upsample_concat for ONE level (the encoder tail's backward pass, encoder_resnet.py:78-86 differentiated:
+// what autograd runs as slice + upsample_bilinear2d_backward per latent): grad [B*H0*W0, n] channels-last -> the gradient
+// of the level's NCHW latent [B, C, h, w], channels c0 .. c0+C-1 of grad.  Gather form (no atomics, fixed summation
+// order: bit-reproducible): a latent texel collects w_y * w_x * grad over the fine texels whose bilinear footprint
+// contains it; the weights are recomputed with the forward pass's own formulas, so the kernel is the exact transpose of
+// upsample_concat_kernel for any size ratio (the window is the support widened by one texel; weights outside are zero).
+// One workgroup = 64 latent texels of one row x 64 channels: 16 lanes read 256 contiguous bytes of a fine texel's row,
+// the tile is transposed through LDS and written along x (NCHW).
+// ---------------------------------------------------------------------------------------------
+struct ConcatBwdArgs {
+  const float* grad;
+  int n, H, W;     // fine map: channels, height, width
+  int c0, C, h, w; // the level: first channel in grad, channels, height, width
+  float* dst;      // [B, C, h, w]
+};
+
+__device__ __forceinline__ float bilinear_tap_weight(int fine, int coarse, int n_coarse, float ratio) {
+  // weight of latent index `coarse` in the bilinear interpolation of fine index `fine` (align_corners=False)
+  const float s = fmaxf(((float)fine + 0.5f) * ratio - 0.5f, 0.f);
+  const int i0 = min((int)s, n_coarse - 1), i1 = min(i0 + 1, n_coarse - 1);
+  const float t = s - (float)i0;
+  return (i0 == coarse ? 1.0f - t : 0.f) + (i1 == coarse ? t : 0.f);
+}
+
+__global__ void __launch_bounds__(256) upsample_concat_backward_kernel(ConcatBwdArgs a) {
+  __shared__ float tile[64 * 65];
+  const int groups = (a.C + 63) >> 6;
+  const int xt = blockIdx.x / groups, cg = blockIdx.x - xt * groups;
+  const int yc = blockIdx.y, b = blockIdx.z;
+  const int q = threadIdx.x & 15, tr = threadIdx.x >> 4;
+  const int c = cg * 64 + 4 * q;
+  const float ry = (float)a.h / (float)a.H, rx = (float)a.w / (float)a.W;
+  const int y_lo = max(0, (int)floorf(((float)yc - 0.5f) / ry - 0.5f) - 1);
+  const int y_hi = min(a.H - 1, (int)ceilf(((float)yc + 1.5f) / ry - 0.5f) + 1);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int tx = 16 * pass + tr, xc = xt * 64 + tx;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (xc < a.w && c < a.C) {
+      const int x_lo = max(0, (int)floorf(((float)xc - 0.5f) / rx - 0.5f) - 1);
+      const int x_hi = min(a.W - 1, (int)ceilf(((float)xc + 1.5f) / rx - 0.5f) + 1);
+      for (int y = y_lo; y <= y_hi; ++y) {
+        const float wy = bilinear_tap_weight(y, yc, a.h, ry);
+        if (wy == 0.f) continue;
+        const float* row = a.grad + (((size_t)b * a.H + y) * a.W) * a.n + a.c0 + c;
+        for (int x = x_lo; x <= x_hi; ++x) {
+          const float wx = bilinear_tap_weight(x, xc, a.w, rx);
+          if (wx == 0.f) continue;
+          const f32x4 g = *(const f32x4*)(row + (size_t)x * a.n);
+          const float wgt = wy * wx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[tx * 65 + 4 * q + e] = acc[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = xt * 64 + lane;
+  if (x >= a.w) return;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int ch = cg * 64 + 16 * wave + g;
+    if (ch < a.C) a.dst[(((size_t)b * a.C + ch) * a.h + yc) * a.w + x] = tile[lane * 65 + 16 * wave + g];
+  }
+}
+
+extern "C" int njf_upsample_concat_backward(const float* grad, const NjfPyramidLevel* levels, int num_levels, int batch,
+                                            void* stream) {
+  if (!grad || !levels) return NJF_E_NULL;
+  if (num_levels < 1 || num_levels > 4 || batch < 1 || batch > 65535) return NJF_E_SHAPE;
+  int n = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!levels[l].feats) return NJF_E_NULL;
+    if (levels[l].channels < 4 || (levels[l].channels & 3) || levels[l].height < 1 || levels[l].width < 1 ||
+        levels[l].height > 65535)
+      return NJF_E_SHAPE;
+    n += levels[l].channels;
+  }
+  int c0 = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    ConcatBwdArgs a{grad, n, levels[0].height, levels[0].width, c0, levels[l].channels, levels[l].height, levels[l].width,
+                    const_cast<float*>(levels[l].feats)};  // the record's pointer is the OUTPUT of this entry point
+    const long long tiles = (long long)((a.w + 63) / 64) * ((a.C + 63) / 64);
+    if (tiles > 0x7fffffffLL) return NJF_E_SHAPE;
+    upsample_concat_backward_kernel<<<dim3((unsigned)tiles, a.h, batch), 256, 0, (hipStream_t)stream>>>(a);
+    c0 += levels[l].channels;
+  }
+  return launch_status();
+}
+
 // =============================================================================================
 // batched 4x4 inverse (camera matrices: torch.inverse in rendering/geometry.py:52,64)
 // =============================================================================================
@@ -2113,6 +2207,139 @@ extern "C" int njf_alpha_weights(const float* deltas, const float* densities, in
   if (!deltas || !densities || !weights) return NJF_E_NULL;
   if (rays < 1 || samples < 1) return NJF_E_SHAPE;
   alpha_weights_kernel<<<(rays + 3) / 4, 256, 0, (hipStream_t)stream>>>(deltas, densities, rays, samples, weights);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of alpha compositing (training, perception mode): what autograd runs for RaySamples.get_weights
+// (ray_samplers.py:77-101) + render_rgb + the un-clipped render_depth (model.py:257-279) -- where / mul / cumsum / cat /
+// exp / exp / sub / mul / sum ... ~25 launches per level -- as ONE launch.  With ds_s = delta_s sigma_s (0 where delta <= 0),
+// T_s = exp(-sum_{j<s} ds_j), w_s = (1 - exp(-ds_s)) T_s:
+//   G_s        = g_w[s] + g_rgb . c_s + g_depth (t_s - depth) / (sum w + 1e-10)      (total derivative w.r.t. w_s)
+//   dL/dds_k   = G_k T_{k+1} - sum_{s>k} G_s w_s                                      (dw_s/dds_s = T_{s+1}, dw_s/dds_k = -w_s)
+//   dL/dsigma_k = delta_k dL/dds_k,   dL/dc_k = w_k g_rgb
+// One wave per ray, lane = sample inside a tile of 64; a forward sweep over the tiles (prefix sums -> T, w, sum w, sum w t)
+// and a reverse sweep (suffix sums of G w), both with fixed orders: bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+struct CompositeBwdArgs {
+  const float* deltas;   // [rays, S]
+  const float* steps;    // [rays, S] sample mid-points t (only read with g_depth)
+  const float* sigma;    // [rays, S]
+  const float* color;    // [rays, S, 3] or NULL
+  const float* g_w;      // [rays, S] or NULL
+  const float* g_rgb;    // [rays, 3] or NULL
+  const float* g_depth;  // [rays] or NULL (gradient w.r.t. the UN-clipped depth)
+  int rays, samples;
+  float* g_sigma;        // [rays, S]
+  float* g_color;        // [rays, S, 3] or NULL
+};
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArgs a) {
+  const int ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (ray >= a.rays) return;
+  const int S = a.samples, tiles = (S + 63) >> 6;
+  const size_t base = (size_t)ray * S;
+  // forward sweep: sum w, sum w t (depth) -- and the optical depth in front of every tile is recomputed in the reverse sweep
+  float sum_w = 0.f, sum_wt = 0.f, carry = 0.f;
+  const bool need_depth = a.g_depth != nullptr;
+  if (need_depth) {
+    for (int t = 0; t < tiles; ++t) {
+      const int s = t * 64 + lane;
+      const bool valid = s < S;
+      const float delta = valid ? a.deltas[base + s] : 0.f;
+      const float ds = (valid && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
+      const float incl = wave_incl_scan(ds, lane);
+      const float w = (1.0f - expf(-ds)) * expf(-(carry + incl - ds));
+      carry += __shfl(incl, 63, 64);
+      sum_w += valid ? w : 0.f;
+      sum_wt += valid ? w * a.steps[base + s] : 0.f;
+    }
+    sum_w = wave_sum(sum_w);
+    sum_wt = wave_sum(sum_wt);
+  }
+  const float denom = sum_w + 1e-10f;
+  const float depth = sum_wt / denom;
+  const float gd = need_depth ? a.g_depth[ray] / denom : 0.f;
+  float gr[3] = {0.f, 0.f, 0.f};
+  if (a.g_rgb) {
+    gr[0] = a.g_rgb[3 * (size_t)ray];
+    gr[1] = a.g_rgb[3 * (size_t)ray + 1];
+    gr[2] = a.g_rgb[3 * (size_t)ray + 2];
+  }
+  // total optical depth of the ray (the reverse sweep walks the tiles from the far end)
+  float total = 0.f;
+  if (need_depth) total = carry;
+  else {
+    for (int t = 0; t < tiles; ++t) {
+      const int s = t * 64 + lane;
+      const float delta = s < S ? a.deltas[base + s] : 0.f;
+      total += (s < S && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
+    }
+    total = wave_sum(total);
+  }
+  float behind = 0.f;   // sum of G_s w_s over the tiles already visited (samples further along the ray)
+  float after = total;  // optical depth up to the END of the current tile
+  for (int t = tiles - 1; t >= 0; --t) {
+    const int s = t * 64 + lane;
+    const bool valid = s < S;
+    const float delta = valid ? a.deltas[base + s] : 0.f;
+    const float ds = (valid && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
+    const float incl = wave_incl_scan(ds, lane);
+    const float tile_total = __shfl(incl, 63, 64);
+    const float before = after - tile_total;           // optical depth in front of this tile
+    const float t_next = expf(-(before + incl));       // T_{s+1}
+    const float w = (1.0f - expf(-ds)) * expf(-(before + incl - ds));
+    float G = a.g_w ? (valid ? a.g_w[base + s] : 0.f) : 0.f;
+    float c[3] = {0.f, 0.f, 0.f};
+    if (a.color && valid) {
+      c[0] = a.color[3 * (base + s)];
+      c[1] = a.color[3 * (base + s) + 1];
+      c[2] = a.color[3 * (base + s) + 2];
+      G += gr[0] * c[0] + gr[1] * c[1] + gr[2] * c[2];
+    }
+    if (need_depth && valid) G += gd * (a.steps[base + s] - depth);
+    const float gw = valid ? G * w : 0.f;
+    // exclusive suffix sum inside the tile = tile sum - inclusive prefix sum
+    const float pre = wave_incl_scan(gw, lane);
+    const float tile_gw = __shfl(pre, 63, 64);
+    const float suffix = behind + (tile_gw - pre);
+    if (valid) {
+      a.g_sigma[base + s] = delta > 0.f ? delta * (G * t_next - suffix) : 0.f;
+      if (a.g_color) {
+        a.g_color[3 * (base + s)] = w * gr[0];
+        a.g_color[3 * (base + s) + 1] = w * gr[1];
+        a.g_color[3 * (base + s) + 2] = w * gr[2];
+      }
+    }
+    behind += tile_gw;
+    after = before;
+  }
+}
+
+extern "C" int njf_composite_backward(const float* deltas, const float* steps, const float* sigma, const float* color,
+                                      const float* g_weights, const float* g_rgb, const float* g_depth, int rays, int samples,
+                                      float* g_sigma, float* g_color, void* stream) {
+  if (!deltas || !sigma || !g_sigma) return NJF_E_NULL;
+  if (g_depth && !steps) return NJF_E_NULL;
+  if ((g_rgb || g_color) && !color) return NJF_E_NULL;
+  if (rays < 1 || samples < 1) return NJF_E_SHAPE;
+  CompositeBwdArgs a{deltas, steps, sigma, color, g_weights, g_rgb, g_depth, rays, samples, g_sigma, g_color};
+  composite_backward_kernel<<<(rays + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
   return launch_status();
 }
 

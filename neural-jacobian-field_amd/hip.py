@@ -115,6 +115,7 @@ _SIGNATURES = {
                             C.c_int),
     "njf_hoisted_channel": ([C.c_int, C.c_int, C.c_int], C.c_int),
     "njf_upsample_concat": ([C.POINTER(PyramidLevel), C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_upsample_concat_backward": ([_vp, C.POINTER(PyramidLevel), C.c_int, C.c_int, _vp], C.c_int),
     "njf_solve_action": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp], C.c_int),
     "njf_invert_4x4": ([_vp, C.c_int, _vp, _vp], C.c_int),
     "njf_generate_rays": ([_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
@@ -131,6 +132,7 @@ _SIGNATURES = {
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
     "njf_assemble_frame": ([_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp], C.c_int),
+    "njf_composite_backward": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_alpha_weights": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_pdf_resample": ([_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp], C.c_int),
 }
@@ -404,6 +406,21 @@ def upsample_concat(levels) -> torch.Tensor:
     return out
 
 
+def upsample_concat_backward(grad: torch.Tensor, shapes) -> list:
+    """Adjoint of ``upsample_concat``: grad [B*H_0*W_0, sum C_l] channels-last -> [gradient of latent l, NCHW] for the
+    latents of shapes ``shapes`` = [(B,C_l,H_l,W_l), ...] (njf_upsample_concat_backward)."""
+    b, _, h0, w0 = shapes[0]
+    n = sum(sh[1] for sh in shapes)
+    if tuple(grad.shape) != (b * h0 * w0, n):
+        raise ValueError("njf_hip: upsample_concat_backward shape mismatch")
+    outs = [torch.empty(tuple(sh), dtype=torch.float32, device=grad.device) for sh in shapes]
+    arr = (PyramidLevel * len(shapes))()
+    for i, (o, sh) in enumerate(zip(outs, shapes)):
+        arr[i] = PyramidLevel(_ptr(o, "latent gradient"), sh[1], sh[2], sh[3])
+    _launch("njf_upsample_concat_backward", load_library().njf_upsample_concat_backward, _ptr(grad, "grad"), arr, len(shapes), b)
+    return outs
+
+
 # --------------------------------------------------------------------------------------
 # ops
 # --------------------------------------------------------------------------------------
@@ -582,6 +599,19 @@ def assemble_frame(packets: torch.Tensor, batch: int, rays_per_batch: int, frame
         raise ValueError("njf_hip: assemble_frame shape mismatch")
     _launch("njf_assemble_frame", load_library().njf_assemble_frame, _ptr(packets, "packets"), world, packet_floats, batch,
             rays_per_batch, float(rgb_scale), float(flow_scale), _ptr(frame, "frame"), _ptr(scalars6, "scalars6"))
+
+
+def composite_backward(deltas, steps, sigma, color=None, g_weights=None, g_rgb=None, g_depth=None, want_color: bool = True):
+    """(g_sigma [rays,S], g_color [rays,S,3] | None) of alpha compositing (njf_composite_backward); per-sample inputs
+    [..., S] with any leading shape, contiguous fp32."""
+    samples = deltas.shape[-1]
+    rays = deltas.numel() // samples
+    g_sigma = torch.empty(rays, samples, dtype=torch.float32, device=deltas.device)
+    g_color = torch.empty(rays, samples, 3, dtype=torch.float32, device=deltas.device) if (color is not None and want_color) else None
+    _launch("njf_composite_backward", load_library().njf_composite_backward, _ptr(deltas, "deltas"), _ptr(steps, "steps"),
+            _ptr(sigma, "sigma"), _ptr(color, "color"), _ptr(g_weights, "g_weights"), _ptr(g_rgb, "g_rgb"),
+            _ptr(g_depth, "g_depth"), rays, samples, _ptr(g_sigma, "g_sigma"), _ptr(g_color, "g_color"))
+    return g_sigma, g_color
 
 
 def alpha_weights(deltas, densities, weights) -> None:

@@ -474,36 +474,43 @@ class Model(nn.Module):
         the encoder, the density and colour heads and the proposal nets; ``optical_flow`` is a value only -- the
         perception losses never read it -- and refuses back-propagation."""
         from . import training
-        features = self.encoder.forward(camera_input.input_image)
+        from .encoder import FeaturePyramid
+        # the encoder WITH its autograd graph; when it offers its un-concatenated latents the forward pass hoists from them
+        # and the encoder tail (up-sampling + concatenation) exists only in FieldFunction's backward pass, as two HIP kernels
+        fp = getattr(self.encoder, "forward_pyramid", None)
+        features = fp(camera_input.input_image) if fp is not None else self.encoder.forward(camera_input.input_image)
+        levels = list(features.levels) if isinstance(features, FeaturePyramid) else [features]
+        detached = FeaturePyramid([lv.detach() for lv in levels]) if len(levels) > 1 else levels[0].detach()
         box = {}
 
         def run():
             with torch.no_grad():
-                outs, bins, wl, bl, rb = self._fused_render(camera_input, rendering_input, robot_input, features.detach(),
+                outs, bins, wl, bl, rb = self._fused_render(camera_input, rendering_input, robot_input, detached,
                                                             want_lists=True, want_vis=compute_vis_features,
-                                                            want_samples=False, dump_perception=True)
-            box.update(outs=outs, bins=bins, bins_list=bl, ray_bundle=rb)
+                                                            want_samples=False, dump_perception=True, clip_depth=False)
+            box.update(outs=outs, bins=bins, bins_list=bl, weights_list=wl, ray_bundle=rb)
             return outs
 
         params = training.perception_params(self)
-        sigma, color, *sigma_prop = training.FieldFunction.apply(run, features, len(self.proposal_networks), *params)
+        sigma, color, *sigma_prop = training.FieldFunction.apply(run, len(levels), len(self.proposal_networks), *levels, *params)
         outs, ray_bundle = box["outs"], box["ray_bundle"]
-        # compositing of model.py:257-279 on the differentiable fields (O(B R S) elementwise work, left to autograd)
+        # compositing of model.py:257-279 on the differentiable fields: the values are the fused kernels' own (weights, rgb,
+        # un-clipped depth), the backward pass is one njf_composite_backward launch per level (training.CompositeFunction)
         smp = ray_bundle.samples_from_bins(box["bins"])
-        weights = self._weights_from_density(smp.deltas, sigma)
-        rgb = torch.sum(weights * color, dim=-2)
-        # render_depth (model.py:270-279) with its tensor-global clip routed through self.depth_clip, so that a ray shard
-        # clips with the all-reduced bounds exactly like the inference path (parallel.enable_ray_sharding)
         steps = (smp.starts + smp.ends) / 2
-        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
-        depth = self.depth_clip(depth, torch.cat([steps.amin(dim=-2), steps.amax(dim=-2)], dim=-1).detach())
+        weights, rgb, depth = training.CompositeFunction.apply(smp.deltas, steps, sigma, color, outs)
+        # render_depth's tensor-global clip (model.py:277) routed through self.depth_clip, so that a ray shard clips with the
+        # all-reduced bounds exactly like the inference path (parallel.enable_ray_sharding)
+        depth = self.depth_clip(depth, outs["step_minmax"])
         anchor = next(p for p in self.parameters() if p.requires_grad)
         flow = training.RefuseBackward.apply(outs["flow"], anchor, training.PERCEPTION_MESSAGE)
         out = ModelOutput(ModelStandardOutput(rgb=rgb, depth=depth, optical_flow=flow), None, None)
         samples_list = [ray_bundle.samples_from_bins(bn) for bn in box["bins_list"]]
         weights_list = []
-        for lvl_samples, dump, sg in zip(samples_list, outs["proposal_dumps"], sigma_prop):
-            weights_list.append(self._weights_from_density(lvl_samples.deltas, sg if dump["updated"] else sg.detach()))
+        for lvl_samples, dump, sg, w_fwd in zip(samples_list, outs["proposal_dumps"], sigma_prop, box["weights_list"]):
+            # the proposal nets receive gradient only on the steps the reference's `updated` schedule allows
+            weights_list.append(training.CompositeFunction.apply(lvl_samples.deltas, None, sg, None, {"weights": w_fwd})
+                                if dump["updated"] else w_fwd.detach().reshape(sg.shape))
         if self.training:
             out.training_output = ModelTrainingOutput(weights_list=weights_list + [weights],
                                                       ray_samples_list=samples_list + [smp])

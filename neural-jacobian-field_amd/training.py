@@ -262,12 +262,16 @@ class FieldFunction(torch.autograd.Function):
     dumps; the compositing between these fields and the losses is left to autograd (it is O(B R S) elementwise work)."""
 
     @staticmethod
-    def forward(ctx, run: Callable[[], Dict[str, torch.Tensor]], features: torch.Tensor, n_prop: int, *params):
+    def forward(ctx, run: Callable[[], Dict[str, torch.Tensor]], n_levels: int, n_prop: int, *tensors):
+        """``tensors`` = the encoder output -- ONE [B,512,Hf,Wf] feature tensor (n_levels = 1) or the encoder's un-concatenated
+        latents (n_levels = 4: the forward pass hoists from them, njf_project_pyramid; the 512-channel matrix and the
+        gradients of the latents are formed in the backward pass by njf_upsample_concat and its adjoint, round 3: this
+        replaces ATen's three upsample_bilinear2d forward + backward launches per step) -- followed by the parameters."""
         outs = run()
         ctx.outs = outs
-        ctx.features = features
+        ctx.n_levels = n_levels
         ctx.n_prop = n_prop
-        ctx.save_for_backward(*params)
+        ctx.save_for_backward(*tensors)
         ctx.set_materialize_grads(False)
         b, r, s = outs["weights"].shape
         # detached aliases: the returned tensors must not be the objects ``ctx.outs`` holds (reference cycle)
@@ -277,11 +281,12 @@ class FieldFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_sigma, g_color, *g_prop):
-        params = ctx.saved_tensors
+        levels, params = ctx.saved_tensors[:ctx.n_levels], ctx.saved_tensors[ctx.n_levels:]
         n = len(JACOBIAN_PARAM_ORDER)
-        outs, features = ctx.outs, ctx.features
+        outs = ctx.outs
+        features = levels[0] if ctx.n_levels == 1 else FeaturePyramid([lv.detach() for lv in levels])
         feats_flat = _flat_features(features).detach()
-        d_feats = torch.zeros_like(feats_flat) if ctx.needs_input_grad[1] else None
+        d_feats = torch.zeros_like(feats_flat) if any(ctx.needs_input_grad[3:3 + ctx.n_levels]) else None
         out_grads = [None] * len(params)
 
         clamp_exp = trunc_exp_backward_factor
@@ -315,11 +320,48 @@ class FieldFunction(torch.autograd.Function):
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[n + 6 + lvl * n + i] = grads[k]
         ctx.outs = None
-        g_features = None
+        g_levels = [None] * ctx.n_levels
         if d_feats is not None:
-            bsz, c, hf, wf = features.shape
-            g_features = d_feats.reshape(bsz, hf, wf, c).permute(0, 3, 1, 2)
-        return (None, g_features, None) + tuple(out_grads)
+            if ctx.n_levels == 1:
+                bsz, c, hf, wf = features.shape
+                g_levels = [d_feats.reshape(bsz, hf, wf, c).permute(0, 3, 1, 2)]
+            else:   # adjoint of the encoder tail: channels-last [T,512] -> one NCHW gradient per latent
+                g_levels = hip.upsample_concat_backward(d_feats, [tuple(lv.shape) for lv in levels])
+        return (None, None, None) + tuple(g_levels) + tuple(out_grads)
+
+
+class CompositeFunction(torch.autograd.Function):
+    """Alpha compositing of one sampling level as an autograd node (perception-mode training): weights = get_weights(sigma)
+    (ray_samplers.py:77-101), rgb = sum_s w c (model.py:257-270), depth = sum_s w t / (sum_s w + 1e-10) BEFORE the clip
+    (model.py:271-276).  The VALUES are the ones the fused forward kernels already composited (``values``: a dict holding
+    ``weights`` [B,R,S] and, for the final level, ``rgb`` [B,R,3] / ``depth`` [B,R,1]); the backward pass is one HIP launch,
+    njf_composite_backward -- autograd's ~25 element-wise / scan launches per level otherwise.  ``steps`` / ``color`` are
+    None for a proposal level (only its weights are read by the losses)."""
+
+    @staticmethod
+    def forward(ctx, deltas, steps, sigma, color, values):
+        ctx.save_for_backward(deltas, sigma, *([] if steps is None else [steps]), *([] if color is None else [color]))
+        ctx.has = (steps is not None, color is not None)
+        ctx.set_materialize_grads(False)
+        w = values["weights"].detach().reshape(sigma.shape)
+        if color is None:
+            return w
+        return w, values["rgb"].detach().view_as(values["rgb"]), values["depth"].detach().view_as(values["depth"])
+
+    @staticmethod
+    def backward(ctx, g_w, g_rgb=None, g_depth=None):
+        saved = list(ctx.saved_tensors)
+        deltas, sigma = saved[0], saved[1]
+        steps = saved[2] if ctx.has[0] else None
+        color = saved[-1] if ctx.has[1] else None
+        if g_w is None and g_rgb is None and g_depth is None:
+            return None, None, None, None, None
+        c = lambda t: None if t is None else t.contiguous()
+        want_color = color is not None and ctx.needs_input_grad[3]
+        g_sigma, g_color = hip.composite_backward(
+            c(deltas), c(steps), c(sigma), c(color), c(g_w), c(g_rgb), c(g_depth) if steps is not None else None,
+            want_color=want_color)
+        return None, None, g_sigma.reshape(sigma.shape), (g_color.reshape(color.shape) if g_color is not None else None), None
 
 
 def perception_params(model) -> List[torch.Tensor]:

@@ -190,6 +190,31 @@ def test_upsample_concat_equals_the_encoder_tail(dev):
     assert ((out - ref).abs().max() / ref.abs().max()).item() < 2e-6
 
 
+@pytest.mark.parametrize("sizes", [((64, 24, 40), (64, 12, 20), (128, 6, 10), (256, 3, 5)),      # the ResNet-34 ratios 1, 2, 4, 8
+                                   ((64, 24, 40), (64, 12, 20), (128, 6, 10), (256, 5, 7)),      # non-integer ratios
+                                   ((64, 17, 9), (64, 9, 5), (128, 5, 3), (256, 1, 1))])         # odd sizes, a 1 x 1 level
+def test_upsample_concat_backward_equals_autograd(dev, sizes):
+    """njf_upsample_concat_backward = the adjoint of the encoder tail (encoder_resnet.py:78-86): against autograd through
+    F.interpolate(bilinear, align_corners=False) + torch.cat (float64), for integer and non-integer size ratios; gather
+    form, so two launches agree bit for bit."""
+    import torch.nn.functional as F
+    from neural_jacobian_field_amd import hip
+    g = torch.Generator().manual_seed(sum(h * w for _, h, w in sizes))
+    b = 2
+    levels = [torch.randn(b, c, h, w, generator=g).to(dev).double().requires_grad_(True) for c, h, w in sizes]
+    h0, w0 = sizes[0][1:]
+    up = torch.cat([F.interpolate(lv, (h0, w0), mode="bilinear", align_corners=False) for lv in levels], dim=1)
+    grad = torch.randn(b * h0 * w0, 512, generator=g).to(dev)                       # channels-last, as the backward pass holds it
+    up.backward(grad.double().reshape(b, h0, w0, 512).permute(0, 3, 1, 2))
+    got = hip.upsample_concat_backward(grad, [tuple(lv.shape) for lv in levels])
+    again = hip.upsample_concat_backward(grad, [tuple(lv.shape) for lv in levels])
+    for lv, o, o2 in zip(levels, got, again):
+        assert o.shape == lv.shape and torch.equal(o, o2)
+        err = ((o.double() - lv.grad).abs().max() / lv.grad.abs().max()).item()
+        assert err < 2e-6, (tuple(lv.shape), err)
+    assert torch.equal(got[0], grad.reshape(b, h0, w0, 512)[..., :64].permute(0, 3, 1, 2))   # level 0 is a pure layout change
+
+
 @pytest.mark.parametrize("points,channels,texels", [(5000, 128, 331), (777, 64, 50), (3, 5, 2)])
 def test_footprint_scatter_equals_index_add(dev, points, channels, texels):
     """njf_scatter_footprint = the input gradient of the bilinear sampling: four weighted index_add_ calls in one launch

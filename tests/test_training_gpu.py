@@ -398,6 +398,58 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup, margins)
     assert all(p.grad is None for n, p in named.items() if n not in trainable)
 
 
+@pytest.mark.parametrize("rays,samples", [(37, 64), (5, 20), (9, 200), (1, 1)])
+def test_composite_backward_equals_autograd(rays, samples):
+    """njf_composite_backward (one launch) against autograd through the tensor-op form of RaySamples.get_weights +
+    render_rgb + the un-clipped render_depth (ray_samplers.py:77-101, model.py:257-279) in float64: gradients w.r.t. the
+    densities and the colours for any combination of upstream gradients (weights only = a proposal level; all three = the
+    final level), several 64-sample tiles, zero-length intervals, opaque rays."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import __graft_entry__ as g_
+    g_.build()
+    from neural_jacobian_field_amd import training
+    from neural_jacobian_field_amd.model import Model
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rays * 1000 + samples)
+    deltas = (torch.rand(2, rays, samples, 1, generator=g) * 0.3)
+    deltas[0, 0, samples // 2:] = 0.0                                        # zero-length intervals: no density there
+    sigma = torch.exp(torch.randn(2, rays, samples, 1, generator=g) * 1.5)
+    sigma[1, -1] *= 50.0                                                     # an opaque ray: weights vanish behind the surface
+    color = torch.rand(2, rays, samples, 3, generator=g)
+    steps = torch.sort(torch.rand(2, rays, samples, 1, generator=g) * 9 + 0.5, dim=-2).values
+    gw, grgb, gdep = (torch.randn(2, rays, samples, 1, generator=g), torch.randn(2, rays, 3, generator=g), torch.randn(2, rays, 1, generator=g))
+
+    def reference(use):
+        s64, c64 = sigma.double().requires_grad_(True), color.double().requires_grad_(True)
+        w = Model._weights_from_density(deltas.double(), s64)
+        loss = (w * gw.double()).sum() if use[0] else 0.0
+        if use[1]:
+            loss = loss + ((w * c64).sum(-2) * grgb.double()).sum()
+        if use[2]:
+            loss = loss + (((w * steps.double()).sum(-2) / (w.sum(-2) + 1e-10)) * gdep.double()).sum()
+        loss.backward()
+        return s64.grad, c64.grad, w.detach()
+
+    to = lambda t: t.to(dev).contiguous()
+    for use in ((True, False, False), (True, True, True), (False, True, False), (False, False, True)):
+        ref_s, ref_c, w64 = reference(use)
+        sg, cl = to(sigma).requires_grad_(True), to(color).requires_grad_(True)
+        values = {"weights": to(w64.float()[..., 0]), "rgb": to((w64 * color.double()).sum(-2).float()),
+                  "depth": to(((w64 * steps.double()).sum(-2) / (w64.sum(-2) + 1e-10)).float())}
+        if use == (True, False, False):                                      # the proposal-level form: weights only
+            w = training.CompositeFunction.apply(to(deltas), None, sg, None, values)
+            (w * to(gw)).sum().backward()
+        else:
+            w, rgb, dep = training.CompositeFunction.apply(to(deltas), to(steps), sg, cl, values)
+            loss = (w * to(gw)).sum() * float(use[0]) + (rgb * to(grgb)).sum() * float(use[1]) + (dep * to(gdep)).sum() * float(use[2])
+            loss.backward()
+        assert rel(sg.grad, ref_s) < 2e-5, (use, rel(sg.grad, ref_s))
+        if use[1]:
+            assert rel(cl.grad, ref_c) < 2e-6, (use, rel(cl.grad, ref_c))
+        assert (sg.grad[0, 0, samples // 2:] == 0).all()                     # no gradient through zero-length intervals
+
+
 def test_fused_backward_chain_equals_the_gemm_chain(setup):
     """njf_resnetfc_backward (one launch: 11 transposed-weight MFMA products, ReLU masks, residual adds, gradient resident
     in registers) against the layer-by-layer form -- library GEMMs + njf_relu_backward -- on random activations with

@@ -37,3 +37,7 @@ if [ "$STEP" = scaling ]; then   # the N > 1 code on one GPU: RCCL with one rank
   done > $O/scaling_dry.txt 2>&1
   cat $O/scaling_dry.txt
 fi
+if [ "$STEP" = train ]; then
+  NJF_PROFILE=1 python tools/bench_train.py action > $O/train_action.txt 2>&1; tail -22 $O/train_action.txt
+  NJF_PROFILE=1 python tools/bench_train.py perception > $O/train_perception.txt 2>&1; tail -22 $O/train_perception.txt
+fi
