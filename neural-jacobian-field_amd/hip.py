@@ -602,10 +602,15 @@ def assemble_frame(packets: torch.Tensor, batch: int, rays_per_batch: int, frame
 
 
 def composite_backward(deltas, steps, sigma, color=None, g_weights=None, g_rgb=None, g_depth=None, want_color: bool = True):
-    """(g_sigma [rays,S], g_color [rays,S,3] | None) of alpha compositing (njf_composite_backward); per-sample inputs
-    [..., S] with any leading shape, contiguous fp32."""
-    samples = deltas.shape[-1]
-    rays = deltas.numel() // samples
+    """(g_sigma [rays,S], g_color [rays,S,3] | None) of alpha compositing (njf_composite_backward): deltas / steps / sigma /
+    g_weights [rays,S], color [rays,S,3], g_rgb [rays,3], g_depth [rays], contiguous fp32."""
+    if deltas.dim() != 2:
+        raise ValueError("njf_hip: composite_backward takes [rays, samples] fields")
+    rays, samples = deltas.shape
+    for name, t, shape in (("steps", steps, (rays, samples)), ("sigma", sigma, (rays, samples)), ("g_weights", g_weights, (rays, samples)),
+                           ("color", color, (rays, samples, 3)), ("g_rgb", g_rgb, (rays, 3)), ("g_depth", g_depth, (rays,))):
+        if t is not None and tuple(t.shape) != shape:
+            raise ValueError(f"njf_hip: composite_backward: {name} has shape {tuple(t.shape)}, expected {shape}")
     g_sigma = torch.empty(rays, samples, dtype=torch.float32, device=deltas.device)
     g_color = torch.empty(rays, samples, 3, dtype=torch.float32, device=deltas.device) if (color is not None and want_color) else None
     _launch("njf_composite_backward", load_library().njf_composite_backward, _ptr(deltas, "deltas"), _ptr(steps, "steps"),

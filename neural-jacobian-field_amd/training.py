@@ -356,11 +356,14 @@ class CompositeFunction(torch.autograd.Function):
         color = saved[-1] if ctx.has[1] else None
         if g_w is None and g_rgb is None and g_depth is None:
             return None, None, None, None, None
-        c = lambda t: None if t is None else t.contiguous()
+        n_s = sigma.shape[-2]                                          # per-sample fields are [..., S, 1] / [..., S, 3]
+        per_sample = lambda t: None if t is None else t.reshape(-1, n_s).contiguous()
         want_color = color is not None and ctx.needs_input_grad[3]
         g_sigma, g_color = hip.composite_backward(
-            c(deltas), c(steps), c(sigma), c(color), c(g_w), c(g_rgb), c(g_depth) if steps is not None else None,
-            want_color=want_color)
+            per_sample(deltas), per_sample(steps), per_sample(sigma),
+            None if color is None else color.reshape(-1, n_s, 3).contiguous(), per_sample(g_w),
+            None if g_rgb is None else g_rgb.reshape(-1, 3).contiguous(),
+            None if (g_depth is None or steps is None) else g_depth.reshape(-1).contiguous(), want_color=want_color)
         return None, None, g_sigma.reshape(sigma.shape), (g_color.reshape(color.shape) if g_color is not None else None), None
 
 
