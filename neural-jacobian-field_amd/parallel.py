@@ -107,9 +107,11 @@ class ShardedFrameStep:
         # every rank's packet has the same length (cap rays per batch element; a shorter shard leaves its tail unused)
         # (``collective=False``: a dry run of one rank of a larger world on a single process -- no exchange, the other ranks'
         # packets stay zero; bench.py --simulate-world)
-        self.collective = collective
+        # The exchange runs whenever a process group of this world size is up -- also with ONE rank (bench.py --force-dist:
+        # the RCCL call path is exercised on a single GPU) -- and is skipped without a group (single process, no RCCL).
+        self.collective = bool(collective and dist.is_initialized() and dist.get_world_size() == self.world)
         self.packets = torch.zeros(self.world, self.packet_floats, **f32)
-        self.packet = torch.zeros(self.packet_floats, **f32) if (self.world > 1 and collective) else self.packets[self.rank]
+        self.packet = torch.zeros(self.packet_floats, **f32) if self.collective else self.packets[self.rank]
         self.rgb = self.packet[: 3 * batch * n].view(batch, n, 3)
         self.depth = self.packet[3 * batch * cap: 3 * batch * cap + batch * n].view(batch, n, 1)
         self.flow = self.packet[4 * batch * cap: 4 * batch * cap + 2 * batch * n].view(batch, n, 2)
@@ -158,7 +160,7 @@ class ShardedFrameStep:
 
     def exchange(self):
         """ONE collective (pixels + the 16-byte record of every rank), then the assemble kernel."""
-        if self.world > 1 and self.collective:
+        if self.collective:
             if dist.get_backend() == "nccl":
                 dist.all_gather_into_tensor(self.packets.view(-1), self.packet)
             else:

@@ -254,12 +254,16 @@ def test_patch_render_equals_forward(model_and_golden):
     k_norm = g["ctxt_k_norm"]
     o, d, _ = geometry.full_frame_rays(h, w, k_norm, g["trgt_c2w"])
     rin = RenderingInput(o, d, g["z_near"], g["z_far"])
-    ro = model.patch_render(cam, rin, rob, render_height=h, render_width=w)
-    out = model.forward(cam, rin, rob, compute_vis_features=True)
+    # (both calls render from the reference's encoder output: MIOpen's convolutions are not bit-reproducible call to call --
+    # measured 1.04e-5 on rgb between two encoder runs -- and with identical features the two calls ARE the same launches)
+    with _from_reference_features(model, g):
+        ro = model.patch_render(cam, rin, rob, render_height=h, render_width=w)
+        out = model.forward(cam, rin, rob, compute_vis_features=True)
     assert ro.rgb.shape == (2, h, w, 3) and ro.weights.shape == (2, h, w, 12)
-    # (the MIOpen encoder is not bit-reproducible call to call, so compare to 1e-5 rather than bitwise)
-    assert rel(ro.rgb.reshape(2, -1, 3), out.standard_output.rgb) < 1e-5
-    assert rel(ro.action_features.reshape(2, h * w, -1), out.vis_output.action_features) < 1e-4
+    assert torch.equal(ro.rgb.reshape(2, -1, 3), out.standard_output.rgb)
+    assert torch.equal(ro.action_features.reshape(2, h * w, -1), out.vis_output.action_features)
+    through_encoder = model.patch_render(cam, rin, rob, render_height=h, render_width=w)   # ... and through MIOpen: close
+    assert rel(through_encoder.rgb, ro.rgb) < 1e-3
     # colour-mapped outputs (model.py:598-626) are produced on the device
     assert ro.depth_rgb.shape == (2, h, w, 3) and ro.depth_rgb.is_cuda and 0 <= ro.depth_rgb.min() and ro.depth_rgb.max() <= 1
     assert ro.flow_rgb.shape == (2, h, w, 3) and ro.flow_rgb.dtype == torch.uint8 and ro.flow_rgb.is_cuda
