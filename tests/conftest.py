@@ -66,7 +66,8 @@ def margins():
                              "floor": float(f"{(noise if used_self_noise else floor64):.3e}"),
                              "floor_fp64": float(f"{floor64:.3e}"), "limit": float(f"{limit:.3e}"), "needs_floor": bool(err > tol),
                              "self_noise_floor_used": used_self_noise, "ok": bool(err <= limit)})
-        assert err <= limit, {"case": case, "key": key, "err": err, "floor_fp64": floor64, "self_noise": noise, "limit": limit}
+        if not err <= limit:   # (raised by hand: the payload stays a dict for callers that collect several failures)
+            raise AssertionError({"case": case, "key": key, "err": err, "floor_fp64": floor64, "self_noise": noise, "limit": limit})
         return err
 
     def record(case, rows):

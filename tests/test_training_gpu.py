@@ -175,13 +175,18 @@ def test_flow_backward_outside_action_mode_is_refused_loudly(setup):
         model.zero_grad(set_to_none=True)
 
 
-def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
+@pytest.mark.parametrize("precision", ["f32", "default"])
+def test_perception_mode_gradients_match_oracle_autograd(setup, margins, precision):
     """Reference perception mode (model_wrapper.py:117-146): every parameter trains; the losses read rgb, depth and
     the per-level weights.  HIP forward with activation dumps + GEMM backward, against autograd through the CPU oracle
-    (encoder included).  Deterministic (un-jittered) samples so both sides place the same points."""
+    (encoder included).  Deterministic (un-jittered) samples so both sides place the same points.  Run with exact fp32
+    products and in the package's default precision (f16f6 final pass, f16x2 proposal pass)."""
     import njf_oracle as orc
+    from neural_jacobian_field_amd import hip
     s = setup
     model, case, dev = s["model"], s["case"], s["dev"]
+    model.set_precision("f32" if precision == "f32" else hip.DEFAULT_PRECISION)
+    tag = f"train.perception[{precision}]"
     req = {n: p.requires_grad for n, p in model.named_parameters()}
     for p in model.parameters():
         p.requires_grad = True
@@ -244,7 +249,7 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
 
         base = oracle_backward(None)
         moved = {mode: oracle_backward(mode) for mode in FLOOR_MODES}
-        margins("train.perception", "loss", loss.reshape(1), losses[None],
+        margins(tag, "loss", loss.reshape(1), losses[None],
                 floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES), floor_fp64=rel(losses["fp64"], losses[None]))
         # EVERY parameter is held to ITS OWN floors (a group's largest floor used to excuse the group's worst
         # parameter): twice the oracle's fp32-vs-fp64 difference of that gradient, and only where that fails twice its
@@ -261,10 +266,11 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
             f64 = rel(moved["fp64"][name], g_ref)
             f_all = max(rel(m[name], g_ref) for m in moved.values())
             try:
-                margins("train.perception", "grad " + name, p.grad, g_ref, floor=f_all, floor_fp64=f64)
+                margins(tag, "grad " + name, p.grad, g_ref, floor=f_all, floor_fp64=f64)
             except AssertionError as e:
-                failures.append(str(e))
-        assert not failures, failures
+                d = e.args[0] if e.args and isinstance(e.args[0], dict) else {}
+                failures.append((round(d.get("err", 0.0) / max(d.get("limit", 1.0), 1e-30), 2), name))
+        assert not failures, (len(failures), sorted(failures, reverse=True)[:6])
     finally:
         for n, p in model.named_parameters():
             p.requires_grad = req[n]
@@ -272,6 +278,7 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins):
             smp.train_stratified = True
         model.zero_grad(set_to_none=True)
         model.eval()
+        model.set_precision(hip.DEFAULT_PRECISION)
 
 
 def test_perception_step_trains_all_parts(setup):
