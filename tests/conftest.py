@@ -97,6 +97,7 @@ def pytest_sessionfinish(session, exitstatus):
                "rows": len(_MARGIN_ROWS), "rows_over_1e-4": sum(r["needs_floor"] for r in _MARGIN_ROWS),
                "rows_on_self_noise_floor": sum(bool(r.get("self_noise_floor_used")) for r in _MARGIN_ROWS),
                "failed": sum(not r["ok"] for r in _MARGIN_ROWS), "table": _MARGIN_ROWS}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
         json.dump(summary, f, indent=0)
 
