@@ -2248,30 +2248,39 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+#define NJF_COMPOSITE_MAX_TILES 16  // 1,024 samples per ray
+
 __global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArgs a) {
+  __shared__ float tile_start[4][NJF_COMPOSITE_MAX_TILES];  // per wave: optical depth in front of each 64-sample tile
   const int ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (ray >= a.rays) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool live = ray < a.rays;
   const int S = a.samples, tiles = (S + 63) >> 6;
-  const size_t base = (size_t)ray * S;
-  // forward sweep: sum w, sum w t (depth) -- and the optical depth in front of every tile is recomputed in the reverse sweep
+  const size_t base = (size_t)min(ray, a.rays - 1) * S;
+  // forward sweep: the optical depth in front of every tile (accumulated front to back, like the forward pass -- taking it
+  // from the ray's total by subtraction loses 1e-4 of the transmittance on opaque rays), sum w and sum w t (depth)
   float sum_w = 0.f, sum_wt = 0.f, carry = 0.f;
   const bool need_depth = a.g_depth != nullptr;
-  if (need_depth) {
-    for (int t = 0; t < tiles; ++t) {
-      const int s = t * 64 + lane;
-      const bool valid = s < S;
-      const float delta = valid ? a.deltas[base + s] : 0.f;
-      const float ds = (valid && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
-      const float incl = wave_incl_scan(ds, lane);
+  for (int t = 0; t < tiles; ++t) {
+    const int s = t * 64 + lane;
+    const bool valid = s < S;
+    const float delta = valid ? a.deltas[base + s] : 0.f;
+    const float ds = (valid && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
+    const float incl = wave_incl_scan(ds, lane);
+    if (lane == 0) tile_start[wv][t] = carry;
+    if (need_depth) {
       const float w = (1.0f - expf(-ds)) * expf(-(carry + incl - ds));
-      carry += __shfl(incl, 63, 64);
       sum_w += valid ? w : 0.f;
       sum_wt += valid ? w * a.steps[base + s] : 0.f;
     }
+    carry += __shfl(incl, 63, 64);
+  }
+  if (need_depth) {
     sum_w = wave_sum(sum_w);
     sum_wt = wave_sum(sum_wt);
   }
+  __syncthreads();  // tile_start written by lane 0 of each wave, read by all of its lanes (uniform trip counts: S is per launch)
+  if (!live) return;
   const float denom = sum_w + 1e-10f;
   const float depth = sum_wt / denom;
   const float gd = need_depth ? a.g_depth[ray] / denom : 0.f;
@@ -2281,28 +2290,15 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArg
     gr[1] = a.g_rgb[3 * (size_t)ray + 1];
     gr[2] = a.g_rgb[3 * (size_t)ray + 2];
   }
-  // total optical depth of the ray (the reverse sweep walks the tiles from the far end)
-  float total = 0.f;
-  if (need_depth) total = carry;
-  else {
-    for (int t = 0; t < tiles; ++t) {
-      const int s = t * 64 + lane;
-      const float delta = s < S ? a.deltas[base + s] : 0.f;
-      total += (s < S && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
-    }
-    total = wave_sum(total);
-  }
   float behind = 0.f;   // sum of G_s w_s over the tiles already visited (samples further along the ray)
-  float after = total;  // optical depth up to the END of the current tile
   for (int t = tiles - 1; t >= 0; --t) {
     const int s = t * 64 + lane;
     const bool valid = s < S;
     const float delta = valid ? a.deltas[base + s] : 0.f;
     const float ds = (valid && delta > 0.f) ? delta * a.sigma[base + s] : 0.f;
     const float incl = wave_incl_scan(ds, lane);
-    const float tile_total = __shfl(incl, 63, 64);
-    const float before = after - tile_total;           // optical depth in front of this tile
-    const float t_next = expf(-(before + incl));       // T_{s+1}
+    const float before = tile_start[wv][t];             // optical depth in front of this tile
+    const float t_next = expf(-(before + incl));        // T_{s+1}
     const float w = (1.0f - expf(-ds)) * expf(-(before + incl - ds));
     float G = a.g_w ? (valid ? a.g_w[base + s] : 0.f) : 0.f;
     float c[3] = {0.f, 0.f, 0.f};
@@ -2327,7 +2323,6 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArg
       }
     }
     behind += tile_gw;
-    after = before;
   }
 }
 
@@ -2338,6 +2333,7 @@ extern "C" int njf_composite_backward(const float* deltas, const float* steps, c
   if (g_depth && !steps) return NJF_E_NULL;
   if ((g_rgb || g_color) && !color) return NJF_E_NULL;
   if (rays < 1 || samples < 1) return NJF_E_SHAPE;
+  if (samples > 64 * NJF_COMPOSITE_MAX_TILES) return NJF_E_SAMPLES;
   CompositeBwdArgs a{deltas, steps, sigma, color, g_weights, g_rgb, g_depth, rays, samples, g_sigma, g_color};
   composite_backward_kernel<<<(rays + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
   return launch_status();

@@ -526,7 +526,7 @@ class Model(nn.Module):
         inference path composites inside the render kernel)."""
         ds = torch.where(deltas > 0, deltas * densities, torch.zeros_like(densities))
         acc = torch.cumsum(ds[..., :-1, :], dim=-2)
-        acc = torch.cat([torch.zeros_like(acc[..., :1, :]), acc], dim=-2)
+        acc = torch.cat([torch.zeros_like(ds[..., :1, :]), acc], dim=-2)   # (ds, not acc: a single sample has no prefix)
         return (1 - torch.exp(-ds)) * torch.exp(-acc)
 
     def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
