@@ -26,11 +26,21 @@ def noisy(t, scale=2e-7, seed=1234):
     the margins table); additive noise of sigma = 2e-7 max|t| has its largest element near 1e-6 max|t|.  Round 2 assumed a
     relative 1e-5 on every element."""
     g = torch.Generator().manual_seed(seed)
-    return t + scale * t.abs().max() * torch.randn(t.shape, generator=g)
+    return t + (scale * t.detach().abs().max() * torch.randn(t.shape, generator=g)).to(t.dtype)
 
 
 RAY_SEEDS = (1, 2, 3, 4)
-FLOOR_MODES = ("fp64",) + tuple(f"rays{s}" for s in RAY_SEEDS) + ("features",)
+FEATURE_SEEDS = (11, 12, 13)
+FLOOR_MODES = ("fp64",) + tuple(f"rays{s}" for s in RAY_SEEDS) + tuple(f"features{s}" for s in FEATURE_SEEDS)
+
+
+def feature_seed(mode):
+    """Seed of a "features<seed>" floor mode (None for every other mode): the ENCODER OUTPUT moved by the measured size of the
+    MIOpen-vs-ATen difference.  This is the dominant real discrepancy between the HIP path and the oracle in the gradient
+    tests (tools/diag/diag_perception.py: it moves the proposal weights by 1.4e-5 and, through the ds-nerf loss's
+    1 / (w + 1e-7), their upstream gradient by 4.6 %), so the floor models it where it arises -- at the feature level, also
+    when the encoder trains."""
+    return int(mode[8:]) if mode is not None and mode.startswith("features") else None
 
 
 def moved_rays(origins, directions, mode):
@@ -121,7 +131,7 @@ def test_action_mode_gradients_match_oracle_autograd(setup, margins):
             if k.startswith("decoder.jacobian_head."):
                 params[k].requires_grad_(True)
         origins, directions = moved_rays(case["origins"], case["directions"], mode)
-        ref = orc.model_forward(params, features=cv(noisy(feats) if mode == "features" else feats),
+        ref = orc.model_forward(params, features=cv(feats if feature_seed(mode) is None else noisy(feats, seed=feature_seed(mode))),
                                 ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
                                 trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
                                 directions=cv(directions), z_near=cv(c["z_near"]), z_far=cv(c["z_far"]),
@@ -236,8 +246,11 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins, precisi
                 if v.is_floating_point() and "running_" not in k:
                     v.requires_grad_(True)
             origins, directions = moved_rays(case["origins"], case["directions"], mode)
-            image = noisy(s["image"]) if mode == "features" else s["image"]   # the encoder trains: its INPUT moves
-            ref = orc.model_forward(params, input_image=cv(image), ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
+            source = dict(input_image=cv(s["image"]))
+            if feature_seed(mode) is not None:   # the encoder trains, and its OUTPUT carries the arithmetic noise of another fp32 conv
+                enc = {k[len("encoder."):]: v for k, v in params.items() if k.startswith("encoder.")}
+                source = dict(features=noisy(orc.encoder_features(enc, cv(s["image"])), seed=feature_seed(mode)))
+            ref = orc.model_forward(params, **source, ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
                                     trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
                                     directions=cv(directions), z_near=cv(c["z_near"]), z_far=cv(c["z_far"]),
                                     action=cv(case["action"]),
@@ -395,7 +408,7 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup, margins)
         for k in trainable:
             params[k].requires_grad_(True)
         origins, directions = moved_rays(case["origins"], case["directions"], mode)
-        ref = orc.model_forward(params, features=cv(noisy(feats) if mode == "features" else feats),
+        ref = orc.model_forward(params, features=cv(feats if feature_seed(mode) is None else noisy(feats, seed=feature_seed(mode))),
                                 ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
                                 trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins),
                                 directions=cv(directions), z_near=cv(c["z_near"]), z_far=cv(c["z_far"]), action=cv(action),
@@ -449,6 +462,8 @@ def test_composite_backward_equals_autograd(rays, samples):
 
     to = lambda t: t.to(dev).contiguous()
     for use in ((True, False, False), (True, True, True), (False, True, False), (False, False, True)):
+        if samples == 1 and use == (False, False, True):
+            continue   # the depth of a one-sample ray is its t: the gradient (-1e-10 t / w^2-sized) is below fp32 resolution
         ref_s, ref_c, w64 = reference(use)
         sg, cl = to(sigma).requires_grad_(True), to(color).requires_grad_(True)
         values = {"weights": to(w64.float()[..., 0]), "rgb": to((w64 * color.double()).sum(-2).float()),
