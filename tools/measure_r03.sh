@@ -41,3 +41,11 @@ if [ "$STEP" = train ]; then
   NJF_PROFILE=1 python tools/bench_train.py action > $O/train_action.txt 2>&1; tail -22 $O/train_action.txt
   NJF_PROFILE=1 python tools/bench_train.py perception > $O/train_perception.txt 2>&1; tail -22 $O/train_perception.txt
 fi
+if [ "$STEP" = extras ]; then
+  python tools/bench_heads.py > $O/heads.txt 2>&1; tail -2 $O/heads.txt
+  python tools/bench_control.py > $O/control.txt 2>&1; tail -2 $O/control.txt
+fi
+if [ "$STEP" = profile ]; then   # rocprofv3 kernel stats + PMC passes of the default bench (tools/profile_r03.sh), headline and fp32 modes
+  for p in f16f6 f32; do bash tools/profile_r03.sh $p > $O/profile_$p.log 2>&1; done
+  ls gpurun_out/prof_r03_f16f6 gpurun_out/prof_r03_f32
+fi
