@@ -76,7 +76,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank")
     ap.add_argument("--graph", action="store_true",
                     help="strong scaling: replay each rank's compute (Model.forward + partial reduction) as ONE HIP graph; the "
-                         "per-kernel HIP-event timings then come from an eager pass after the timed loop")
+                         "per-kernel HIP-event timings then come from an eager pass after the timed loop.  Default at N > 1 "
+                         "(a shard step is 1.4 ms: launch gaps are 8 %% of it); at N = 1 the default is eager")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: keep the rank-local compute eager")
     ap.add_argument("--legacy-step", action="store_true",
                     help="the round-2 step (ATen depth clip / loss sums / concatenation, three collectives) for A/B")
     ap.add_argument("--height", type=int, default=H)
@@ -273,9 +275,21 @@ def main():
     model = models[precision]
     for _ in range(args.warmup):
         step(model)
-    graphed = bool(args.graph and use_frame_step)
+    graphed = bool(use_frame_step and not args.no_graph and (args.graph or world > 1))
     if graphed:   # record the rank-local compute once; the graph replays the per-image projection, so no cache reset
-        frame_steps[precision].capture(cam, rin, rob)
+        try:
+            frame_steps[precision].capture(cam, rin, rob)
+        except Exception as exc:   # capture is an optimisation: an eager step is always available
+            print(f"[bench] HIP-graph capture failed on rank {rank} ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
+            frame_steps[precision]._graph = None
+            graphed = False
+        if dist is not None:       # every rank must take the same path through the timed loop's collectives
+            flag = torch.tensor([1.0 if graphed else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if graphed and flag.item() == 0.0:
+                frame_steps[precision]._graph = None
+                graphed = False
+    if graphed:
         model.reset_image_cache = lambda: model
         for _ in range(2):
             step(model)
