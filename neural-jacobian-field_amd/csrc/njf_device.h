@@ -807,17 +807,20 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 // arg / 2pi evaluated as a two-float product: 1/2pi = C_HI + C_LO (24 + 24 bits), u = fl(arg * C_HI), the exact
 // rounding error of that product from one fma, plus arg * C_LO.  u - rint(u) is exact, so the phase is good to
 // half an ulp of 0.5 (2.8e-8 revolutions, sin error 1.8e-7) -- the same as rounding an fp64 reduction to float, at
-// a third of the cost (fp64 VALU runs at half rate and needs conversions both ways).
+// a third of the cost (fp64 VALU runs at half rate and needs conversions both ways).  Round 3: the sine of the reduced
+// phase is the hardware's v_sin_f32 (which works in revolutions) instead of a polynomial.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sin_accurate(float arg) {
   const float C_HI = 0.15915493667125702f, C_LO = 6.4206382432985265e-09f;
   const float u = arg * C_HI;
   float e = fmaf(arg, C_HI, -u);
   e = fmaf(arg, C_LO, e);
-  float y = (u - rintf(u)) + e;                          // [-0.5, 0.5] (+ rounding)
-  if (fabsf(y) > 0.25f) y = copysignf(0.5f, y) - y;      // sin(pi - x) = sin(x); |y| <= 0.25 afterwards
-  const float y2 = y * y;
-  // sin(2*pi*y) = y * P(y^2), Taylor to x^13 (truncation < 6e-10 at |x| = pi/2)
+  const float y = (u - rintf(u)) + e;                    // [-0.5, 0.5] (+ rounding)
+#ifdef NJF_SIN_POLYNOMIAL  // the rounds 1-2 form, kept for A/B builds
+  float f = y;
+  if (fabsf(f) > 0.25f) f = copysignf(0.5f, f) - f;      // sin(pi - x) = sin(x); |f| <= 0.25 afterwards
+  const float y2 = f * f;
+  // sin(2*pi*f) = f * P(f^2), Taylor to x^13 (truncation < 6e-10 at |x| = pi/2)
   float p = 3.8199525848482803f;            // +(2pi)^13/13!
   p = fmaf(p, y2, -15.094642576822984f);    // -(2pi)^11/11!
   p = fmaf(p, y2, 42.058693944897634f);     // +(2pi)^9/9!
@@ -825,7 +828,14 @@ __device__ __forceinline__ float sin_accurate(float arg) {
   p = fmaf(p, y2, 81.60524927607504f);      // +(2pi)^5/5!
   p = fmaf(p, y2, -41.341702240399755f);    // -(2pi)^3/3!
   p = fmaf(p, y2, 6.283185307179586f);      // 2pi
-  return y * p;
+  return f * p;
+#else
+  // v_sin_f32 takes its argument in REVOLUTIONS, which is what the reduction above produces: on [-0.5, 0.5] it measures
+  // 1.25e-7 max abs error against sin(2 pi y) in double (tools/probes/probe_sin.hip; the degree-13 polynomial with its
+  // quadrant fold it replaces: 1.93e-7) for one quarter-rate instruction instead of 13 full-rate ones -- the positional
+  // encoding is 1,200 of the render kernel's 7,700 VALU instructions per tile (profiles/r03_isa_budget.txt).
+  return __builtin_amdgcn_sinf(y);
+#endif
 }
 
 // Positional encoding in B-operand slot order (see njf_pack: kind 1).  Lane half hh=0 supplies
