@@ -627,7 +627,15 @@ __device__ __forceinline__ void point_footprint(const PointGeom& g, Footprint& f
   const float u1 = dot3(c.k + 3, xc, yc, zc);
   const float u2 = dot3(c.k + 6, xc, yc, zc);
   const float den = u2 + 1e-9f;
+#ifdef NJF_FOOTPRINT_IEEE_DIV  // rounds 1-2 (A/B builds): two IEEE divisions, ~20 VALU instructions per footprint
   const float u = u0 / den, v = u1 / den;
+#else
+  // one v_rcp_f32 (1 ulp) and two multiplications: the footprint only feeds the bilinear weights and texel indices -- smooth
+  // in uv, unlike the camera-space coordinates above, whose bits the positional encoding amplifies -- and it is recomputed
+  // in front of each of the six gathers of a tile
+  const float inv = __builtin_amdgcn_rcpf(den);
+  const float u = u0 * inv, v = u1 * inv;
+#endif
   const float gx = (u - 0.5f) * 2.0f, gy = (v - 0.5f) * 2.0f;
   float ix = ((gx + 1.0f) / 2.0f) * (float)(wf - 1);
   float iy = ((gy + 1.0f) / 2.0f) * (float)(hf - 1);
