@@ -257,13 +257,14 @@ def main():
             fs = parallel.ShardedFrameStep(m, BB, HH * WW, device, world_size=shard_world, rank=shard_rank,
                                            collective=not sim_world)
             fs.set_targets(rgb_loc, flow_loc)
+            fs.new_image_each_step = True   # the per-image projection stays inside every (eager or captured) step
             frame_steps[prec] = fs
 
     def step(model):
-        model.reset_image_cache()  # a new image every step: the per-image projection stays inside the timed region
-        if use_frame_step:
+        if use_frame_step:   # (resets the image cache itself: a new image every step, the projection inside the timed region)
             frame, scalars, out = frame_steps[model.decoder.precision](cam, rin, rob)
             return out, scalars, frame
+        model.reset_image_cache()  # a new image every step: the per-image projection stays inside the timed region
         out = model.forward(cam, rin, rob).standard_output
         # photometric + flow loss (model_wrapper.py:117-163): local sums, ONE all-reduce over the ranks
         losses = parallel.sharded_losses(out.rgb, rgb_loc, out.optical_flow, flow_loc)
@@ -290,7 +291,6 @@ def main():
                 frame_steps[precision]._graph = None
                 graphed = False
     if graphed:
-        model.reset_image_cache = lambda: model
         for _ in range(2):
             step(model)
     if dist is not None:
@@ -309,7 +309,6 @@ def main():
     hip.set_profile_sink(None)
     timing_note = "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"
     if graphed:   # events cannot be read back from inside a replayed graph: an eager pass of the same step, not part of `value`
-        del model.reset_image_cache
         frame_steps[precision]._graph = None
         hip.set_profile_sink(launches)
         for _ in range(args.steps):

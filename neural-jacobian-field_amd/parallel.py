@@ -134,6 +134,9 @@ class ShardedFrameStep:
         self.flow_scale = 0.01 / float(batch * frame_rays * 2)
         self._graph = None
         self._static = None
+        # True: every step renders a NEW image -- the per-image lin_z projection runs (and is captured) in every step instead
+        # of being served from the model's hoisted-map cache (bench.py; a control loop that re-renders one image leaves it False)
+        self.new_image_each_step = False
 
     # ---- pieces ------------------------------------------------------------------------------------------------------
     def set_targets(self, trgt_rgb: Optional[torch.Tensor] = None, trgt_flow: Optional[torch.Tensor] = None) -> None:
@@ -149,6 +152,8 @@ class ShardedFrameStep:
             self.record.copy_(torch.tensor([3.0e38, -3.0e38, 0.0, 0.0], device=self.record.device))
             return None
         m = self.model
+        if self.new_image_each_step:
+            m.reset_image_cache()
         prev = m.frame_io
         m.frame_io = self.io
         try:
