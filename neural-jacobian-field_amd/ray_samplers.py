@@ -214,11 +214,14 @@ class ProposalNetworkSampler(Sampler):
 
     @torch.no_grad()
     def generate_ray_samples_fused(self, ray_bundle: RayBundle, networks: Sequence, pixel_encoding, z_near, z_far,
-                                   want_lists: bool, dump_out: Optional[list] = None):
+                                   want_lists: bool, dump_out: Optional[list] = None,
+                                   feature_maps: Optional[Sequence] = None):
         """Fused route: one ``njf_proposal_forward`` per level.  ``networks`` are DensityDecoderMlp modules.
         ``dump_out`` (perception-mode training): receives one dict per level with the proposal net's backward-pass
         inputs (``act``, ``pe``, ``foot_idx``, ``foot_w``), its ``density`` [B,R,S] and ``updated`` -- whether this
-        step trains the proposal nets (the grad / no-grad schedule of ray_samplers.py:512-549)."""
+        step trains the proposal nets (the grad / no-grad schedule of ray_samplers.py:512-549).  ``feature_maps``: per
+        level (hip.FeatureMap, first channel) when the caller has hoisted every network of the frame into one map
+        (Model._joint_hoist); default: each network's own map."""
         assert len(networks) == self.num_proposal_network_iterations
         from .decoder import _cameras
 
@@ -235,7 +238,10 @@ class ProposalNetworkSampler(Sampler):
         for lvl, net in enumerate(networks):
             s_in, s_out = counts[lvl], counts[lvl + 1]
             w, bias = net.packed()
-            fmap = hip.make_feature_map(net.hoisted_map(pixel_encoding.features))
+            if feature_maps is None:
+                fmap, goff = hip.make_feature_map(net.hoisted_map(pixel_encoding.features)), 0
+            else:
+                fmap, goff = feature_maps[lvl]
             u = self.pdf_sampler.u_values((b, r), s_out, dev, shared_ok=True)
             bins_out = torch.empty(b, r, s_out + 1, dtype=torch.float32, device=dev)
             w_out = torch.empty(b, r, s_in, dtype=torch.float32, device=dev) if want_lists else None
@@ -248,7 +254,7 @@ class ProposalNetworkSampler(Sampler):
                         "foot_idx": torch.empty(pts, 4, dtype=torch.int32, device=dev),
                         "foot_w": torch.empty(pts, 4, dtype=torch.float32, device=dev)}
                 dump_out.append({**dump, "density": sigma, "updated": updated})
-            hip.proposal_forward(o, d, cams, fmap, 0, w, bias, bins.contiguous(), s_in, u, s_out, self._anneal, bins_out,
+            hip.proposal_forward(o, d, cams, fmap, goff, w, bias, bins.contiguous(), s_in, u, s_out, self._anneal, bins_out,
                                  w_out, sigma, precision=net.precision, dump=dump)
             if want_lists:
                 weights_list.append(w_out[..., None])
