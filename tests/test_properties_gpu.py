@@ -285,6 +285,48 @@ def test_binding_error_behaviour(dev):
         Model(model_cfg_from_dict({"action_dim": 11}))
 
 
+def test_joint_hoist_equals_the_per_network_maps(dev):
+    """Model._joint_hoist (ONE projection for the proposal nets and the decoder of a frame) writes, channel range by channel
+    range, exactly the maps the networks produce on their own (same products in the same order: bit for bit) -- from a feature
+    tensor and from the encoder's latents (pyramid producer), for the MLP and the transformer decoder; and a frame rendered
+    through it equals the frame rendered from the per-network maps."""
+    import parity_harness as ph
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.encoder import FeaturePyramid
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(2, 512, 12, 20, generator=g).to(dev)
+    levels = [torch.randn(2, c, h, w, generator=g).to(dev) for c, h, w in ((64, 12, 20), (64, 6, 10), (128, 3, 5), (256, 2, 3))]
+    case = ph.make_case(2, 24, 40, 64, 8, seed=1, identity_context=False)
+    for name in ("jacobian_mlp", "jacobian_transformer"):
+        cfg = model_cfg_from_dict({"action_dim": 8, "encoder": {"name": "precomputed"},
+                                   "rendering": {"num_proposal_samples": [16, 12], "num_nerf_samples": 10},
+                                   "action_decoder": {"name": name}})
+        model = Model(cfg).to(dev).eval().requires_grad_(False)
+        model.load_state_dict({k: v.to(dev) for k, v in synthetic.seeded_state_dict(synthetic.model_shapes(name, 8, num_proposal_networks=2, with_encoder=False), seed=0).items()})
+        for f in (feats, FeaturePyramid(levels)):
+            gmap, prop_bases, dec_base = model._joint_hoist(f)
+            nets = [*model.proposal_networks, model.decoder]
+            for net, base in zip(nets, [*prop_bases, dec_base]):
+                own = net.hoisted_map(f)
+                assert torch.equal(gmap[..., base:base + own.shape[-1]], own), (name, type(f).__name__, base)
+            assert gmap.shape[-1] == sum(n.hoisted_map(f).shape[-1] for n in nets)
+        # a frame through the joint map == the frame from the per-network maps
+        c = case["cams"]
+        d = lambda t: t.to(dev)
+        cam = CameraInput(None, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+        rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
+        rob = RobotInput(d(case["action"]))
+        model.encoder.set_features(feats)
+        a = model.forward(cam, rin, rob).standard_output
+        model._joint_hoist = lambda f: None
+        model.reset_image_cache()
+        b = model.forward(cam, rin, rob).standard_output
+        del model._joint_hoist
+        assert torch.equal(a.rgb, b.rgb) and torch.equal(a.depth, b.depth) and torch.equal(a.optical_flow, b.optical_flow)
+
+
 def test_sharded_frame_step_equals_the_unsharded_forward(dev):
     """parallel.ShardedFrameStep (frame-level reductions in the render kernel's epilogue, njf_reduce_frame_partials,
     njf_assemble_frame) on a ragged 3-way split rendered rank by rank on one GPU: the assembled frame equals the plain
