@@ -119,6 +119,9 @@ typedef struct NjfFeatureMap {
 
 /* ---- library info ------------------------------------------------------------------------ */
 int njf_abi_version(void);
+/* Rays one workgroup of the fused ray kernels renders (one per wave): NjfRenderOutputs.frame_partials has
+ * ceil(B*R / njf_rays_per_workgroup()) rows. */
+int njf_rays_per_workgroup(void);
 const char* njf_error_string(int code);
 
 /* ---- camera matrices -------------------------------------------------------------------------- */
@@ -249,7 +252,7 @@ typedef struct NjfRenderOutputs {
   float* col_in;          /* [P, 32] colour-head input [geo 15 | 1 | sh 16] (action_decoder_jacobian.py:315-322) */
   float* col_act;         /* [2, P, 64] ReLU'd outputs of the colour head's first and second layer */
   /* frame-level reductions folded into the kernel's epilogue (ABI v15; all may be NULL).  frame_partials
-   * [ceil(B*R / 4), 4]: per workgroup of four rays (min_t, max_t, sum (rgb - trgt_rgb)^2, sum (flow - trgt_flow)^2) --
+   * [ceil(B*R / njf_rays_per_workgroup()), 4]: per workgroup (min_t, max_t, sum (rgb - trgt_rgb)^2, sum (flow - trgt_flow)^2) --
    * the bounds of render_depth's tensor-global clip (model.py:277) and the numerators of the photometric / flow mse
    * (model_wrapper.py:117-163) of this launch's rays, reduced in a fixed order (bit-reproducible); the sums are 0 where
    * the target pointer is NULL.  njf_reduce_frame_partials folds the rows into one 4-vector. */

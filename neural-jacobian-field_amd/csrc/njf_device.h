@@ -50,14 +50,23 @@ typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 // LDS carve (floats).  One dynamic array only (a second __shared__ object makes hipcc drain
 // vmcnt(0) in front of every ds_read of a DMA pipeline).  Sized per kernel so that two workgroups
 // fit in the CU's 160 KiB: 2 x 32 KiB weight buffers + biases (+ per-wave scratch of the PDF stage).
+// NJF_ASYNC_STREAM (experiment build, needs -DNJF_WAVES=8: ONE 8-wave workgroup per CU): four weight buffers and a
+// barrier-free stream -- see stream_step.
+#ifdef NJF_ASYNC_STREAM
+#define NJF_STREAM_BUFFERS 4
+#define LDS_CTR_FLOATS 8            // eight arrival counters (ring) behind everything else
+#else
+#define NJF_STREAM_BUFFERS 2
+#define LDS_CTR_FLOATS 0
+#endif
 #define LDS_W0 0
 #define LDS_W1 NJF_CHUNK
-#define LDS_BIAS (2 * NJF_CHUNK)
+#define LDS_BIAS (NJF_STREAM_BUFFERS * NJF_CHUNK)
 #define LDS_BIAS_FLOATS 2752        // density 1312 | colour 96 | Jacobian head <= 1312 (+ pad)
 #define LDS_BIAS_FLOATS_PROPOSAL 1344
 #define LDS_SCRATCH_PER_WAVE 528    // proposal pass: w'[<=256] | cdf[<=257] (+ pad)
-#define LDS_FLOATS_RENDER (LDS_BIAS + LDS_BIAS_FLOATS)
-#define LDS_FLOATS_PROPOSAL (LDS_BIAS + LDS_BIAS_FLOATS_PROPOSAL + NJF_WAVES * LDS_SCRATCH_PER_WAVE)
+#define LDS_FLOATS_RENDER (LDS_BIAS + LDS_BIAS_FLOATS + LDS_CTR_FLOATS)
+#define LDS_FLOATS_PROPOSAL (LDS_BIAS + LDS_BIAS_FLOATS_PROPOSAL + NJF_WAVES * LDS_SCRATCH_PER_WAVE + LDS_CTR_FLOATS)
 #define LDS_SCRATCH_PROPOSAL (LDS_BIAS + LDS_BIAS_FLOATS_PROPOSAL)
 
 extern __shared__ __attribute__((aligned(16))) float njf_lds[];
@@ -86,6 +95,10 @@ struct WeightStream {
   int dma_soff;    // byte offset (wave-uniform) of this wave's share of round 0 of the chunk being prefetched
   float* dma_dst;  // this wave's LDS destination of round 0
   int dma_next;    // 0 = job pending, NJF_DMA_ROUNDS = issued (or nothing to prefetch)
+#ifdef NJF_ASYNC_STREAM
+  int ctr;         // float index of the eight arrival counters in LDS
+  int fetch_pass;  // (idx + 2) % per_pass: position in the blob of the chunk the next step prefetches
+#endif
 #ifdef NJF_STAMPS
   int stamp_i;     // next free slot of this wave's time-stamp log in LDS (-1: this wave does not log)
 #endif
@@ -125,6 +138,7 @@ __device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
 }
 
 // Issue the whole pending job at once (chunk shapes that do not interleave; start of the kernel).
+#ifndef NJF_ASYNC_STREAM
 __device__ __forceinline__ void stream_flush(WeightStream& st) {
   if (st.dma_next == 0) {
 #pragma unroll
@@ -132,6 +146,7 @@ __device__ __forceinline__ void stream_flush(WeightStream& st) {
     st.dma_next = NJF_DMA_ROUNDS;
   }
 }
+#endif
 
 __device__ __forceinline__ void dma_job(WeightStream& st, int chunk, int buf, int wave) {
   st.dma_soff = chunk * (NJF_CHUNK * 4) + wave * 1024;
@@ -139,6 +154,7 @@ __device__ __forceinline__ void dma_job(WeightStream& st, int chunk, int buf, in
   st.dma_next = 0;
 }
 
+#ifndef NJF_ASYNC_STREAM
 __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
                                              int lane) {
   // raw buffer descriptor: stride 0, num_records in bytes (range check far above any blob), dword 3 = 32-bit data format
@@ -181,6 +197,79 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
   if (st.idx < st.total) dma_job(st, st.in_pass, st.idx & 1, wave);
   return cur;
 }
+
+#else
+// ---- barrier-free weight stream (experiment) ---------------------------------------------------------------------------------
+// Four buffers, the eight waves of the workgroup drift by up to one chunk instead of meeting at a barrier per chunk.  At the
+// start of step k (consume chunk k) a wave
+//   1. waits vmcnt(0): the only DMA it can have outstanding is its share of chunk k+1, issued at step k-1 -- a whole chunk ago;
+//   2. adds one to arrival counter k & 7 (LDS atomic, lane 0);
+//   3. waits until ALL waves have arrived at step k-1: then every share of chunk k has landed (each wave passed its vmcnt(0)
+//      of step k-1 after issuing nothing newer than chunk k) and nobody reads buffer (k-2) & 3 any more;
+//   4. issues its share of chunk k+2 into buffer (k+2) & 3 = (k-2) & 3, as one burst (the waves are no longer in lock-step,
+//      so the bursts do not collide the way they did behind a barrier).
+// Counter k & 7 is reused every eight steps: its value after step k is NJF_WAVES * (k / 8 + 1).
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+__device__ __forceinline__ void stream_issue(WeightStream& st, int in_pass, int buf, int wave) {
+  dma_job(st, in_pass, buf, wave);
+#pragma unroll
+  for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
+  st.dma_next = NJF_DMA_ROUNDS;
+}
+__device__ __forceinline__ void stream_flush(WeightStream&) {}
+
+__device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
+                                             int lane, int ctr_index = LDS_FLOATS_RENDER - LDS_CTR_FLOATS) {
+  st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7ffffff0, 0x00020000);
+  st.per_pass = per_pass;
+  st.total = per_pass * passes;
+  st.idx = 0;
+  st.in_pass = 0;
+  st.dma_voff = lane * 16;
+  st.ctr = ctr_index;
+#ifdef NJF_STAMPS
+  st.stamp_i = -1;
+#endif
+  if (threadIdx.x < LDS_CTR_FLOATS) ((lds_u32*)(njf_lds + ctr_index))[threadIdx.x] = 0u;
+  stream_issue(st, 0, 0, wave);
+  if (st.total > 1) stream_issue(st, 1 % per_pass, 1, wave);
+  st.fetch_pass = 2 % per_pass;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // chunks 0 and 1 resident, counters zeroed, the bias block the caller loaded is published
+}
+
+__device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, int lane) {
+  const int k = st.idx;
+  NJF_STAMP(st, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of chunk k+1 (issued one chunk ago)
+  NJF_STAMP(st, 2);
+  // arrival counter k & 7 += 1 (lane 0 only) and the wait for counter (k-1) & 7, both as opaque asm: C-level control flow
+  // here (45 loops per tile) splits the tile's one huge basic block and costs ~40 spilled VGPRs
+  const unsigned base = (unsigned)(size_t)(lds_u32*)(njf_lds + st.ctr);
+  {
+    unsigned addr = base + 4u * (unsigned)(k & 7), one = 1u;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(addr), "v"(one) : "memory");
+  }
+  if (k > 0) {   // (k is wave-uniform: a scalar branch around the asm, no exec manipulation)
+    const unsigned want = (unsigned)NJF_WAVES * (unsigned)(((k - 1) >> 3) + 1);
+    unsigned addr = base + 4u * (unsigned)((k - 1) & 7), got;
+    asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_cmp_lt_u32 vcc, %0, %2\n\ts_cbranch_vccz 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 : "=&v"(got) : "v"(addr), "s"(want) : "vcc", "memory");
+  }
+  asm volatile("" ::: "memory");
+  NJF_STAMP(st, 3);
+  const float* cur = njf_lds + (k & 3) * NJF_CHUNK;
+  st.idx = k + 1;
+  if (k + 2 < st.total) {
+    stream_issue(st, st.fetch_pass, (k + 2) & 3, wave);
+    st.fetch_pass += 1;
+    if (st.fetch_pass == st.per_pass) st.fetch_pass = 0;
+  }
+  return cur;
+}
+#endif
 
 // hi/lo split of two fp32 values (ReLU'd on request) into elements 2p, 2p+1 of the packed B operands:
 // hi = fp16(x), lo = fp16(x - hi) (the residual is exact in fp32, so lo carries the next 11 bits of x).

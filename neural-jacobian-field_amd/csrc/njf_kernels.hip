@@ -27,6 +27,7 @@ enum {
 };
 
 extern "C" int njf_abi_version(void) { return NJF_ABI_VERSION; }
+extern "C" int njf_rays_per_workgroup(void) { return NJF_WAVES; }
 
 extern "C" const char* njf_error_string(int code) {
   switch (code) {
@@ -1053,7 +1054,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
   load_bias_block(a.b_pack, NJF_RESNET_B_FLOATS, 0);
   const int tiles = (a.s_in + 31) >> 5;
   WeightStream st;
+#ifdef NJF_ASYNC_STREAM
+  stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane, LDS_FLOATS_PROPOSAL - LDS_CTR_FLOATS);
+#else
   stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane);
+#endif
 #ifdef NJF_STAMPS_PROPOSAL
   const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
   if (stamping) st.stamp_i = 0;

@@ -104,6 +104,7 @@ _lib = None
 
 _SIGNATURES = {
     "njf_abi_version": ([], C.c_int),
+    "njf_rays_per_workgroup": ([], C.c_int),
     "njf_error_string": ([C.c_int], C.c_char_p),
     "njf_pack_resnetfc": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_resnetfc_ld": ([C.POINTER(ResnetFcWeights), _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp], C.c_int),
@@ -580,8 +581,9 @@ def relu_backward(upstream: torch.Tensor, act: torch.Tensor, residual: Optional[
 
 
 def frame_partial_groups(total_rays: int) -> int:
-    """Rows of NjfRenderOutputs.frame_partials for a launch of ``total_rays`` rays (one per workgroup of four rays)."""
-    return (total_rays + 3) // 4
+    """Rows of NjfRenderOutputs.frame_partials for a launch of ``total_rays`` rays (one per workgroup)."""
+    per = load_library().njf_rays_per_workgroup()
+    return (total_rays + per - 1) // per
 
 
 def reduce_frame_partials(partials: torch.Tensor, out4: torch.Tensor) -> None:
