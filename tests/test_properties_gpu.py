@@ -285,32 +285,18 @@ def test_binding_error_behaviour(dev):
         Model(model_cfg_from_dict({"action_dim": 11}))
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x2", "f16f6"])
-def test_transformer_head_at_full_c2_size_vs_oracle(dev, precision, margins):
-    """The reference's shipped Allegro decoder (jacobian_transformer, action_decoder_jacobian.py:340-446) on the C2 frame at
-    full size -- 256 x 256 image, 128 x 128 x 512 feature map, 64 + 64 samples, A = 8 -- on a 2,048-ray subset, against the
-    CPU oracle (floors: the oracle's own fp32-vs-float64 run; the reference-generated goldens for this head are 16 x 16):
-    end to end, and the composited action features / flow at the oracle's own final bins."""
+@pytest.fixture(scope="module")
+def transformer_c2(dev):
+    """The C2 frame (256 x 256 image, 128 x 128 x 512 map, 64 + 64 samples, A = 8, 2,048 rays) through the ORACLE with the
+    jacobian_transformer decoder: fp32, float64, and the float64 decoder + compositing at the fp32 run's sample locations --
+    computed once for the three precisions of the test below."""
     import njf_oracle as orc
     import parity_harness as ph
     from neural_jacobian_field_amd import synthetic
-    from neural_jacobian_field_amd.config import model_cfg_from_dict
-    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
     B, H, W, S, A, R = 1, 256, 256, 64, 8, 2048
     case = ph.make_case(B, H, W, R, A, seed=0)
     params = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_transformer", A, with_encoder=False), seed=0)
-    cfg = model_cfg_from_dict({"action_dim": A, "encoder": {"name": "precomputed"},
-                               "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
-                               "action_decoder": {"name": "jacobian_transformer"}})
-    model = Model(cfg).to(dev).eval().requires_grad_(False)
-    model.load_state_dict({k: v.to(dev) for k, v in params.items()}, strict=True)
-    model.set_precision(precision)
-    model.encoder.set_features(case["feats"].to(dev))
     c = case["cams"]
-    d = lambda t: t.to(dev)
-    cam = CameraInput(None, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
-    rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
-    rob = RobotInput(d(case["action"]))
 
     def oracle(cv):
         p = {k: cv(v) for k, v in params.items()}
@@ -321,25 +307,11 @@ def test_transformer_head_at_full_c2_size_vs_oracle(dev, precision, margins):
                                  decoder_kind="jacobian_transformer")
 
     ref = oracle(lambda t: t)
+    ref_bins = torch.cat([ref.samples_list[1].spacing_starts[..., 0], ref.samples_list[1].spacing_ends[..., -1:, 0]], -1)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
         r64 = oracle(lambda t: t.double() if t.is_floating_point() else t)
-    finally:
-        torch.set_default_dtype(prev)
-    out = model.forward(cam, rin, rob, compute_vis_features=True)
-    tag = f"C2@full[transformer head:{precision}]"
-    margins(tag, "rgb", out.standard_output.rgb, ref.rgb, r64.rgb)
-    margins(tag, "depth", out.standard_output.depth, ref.depth, r64.depth)
-    margins(tag, "optical_flow", out.standard_output.optical_flow, ref.optical_flow, r64.optical_flow)
-    # the head itself at identical sample locations (the oracle's final bins injected)
-    ref_bins = torch.cat([ref.samples_list[1].spacing_starts[..., 0], ref.samples_list[1].spacing_ends[..., -1:, 0]], -1)
-    with torch.no_grad():
-        outs, *_ = model._fused_render(cam, rin, rob, model._encode_for_render(None), want_lists=False, want_vis=True,
-                                       want_samples=True, final_bins=ref_bins.to(dev))
-    # float64 decoder + compositing at the fp32 oracle's sample locations: the floor of the per-sample comparison
-    torch.set_default_dtype(torch.float64)
-    try:
         p64 = {k: v.double() for k, v in params.items()}
         enc64 = orc.PixelEncoding(case["feats"].double(), c["ctxt_c2w"].double(), c["ctxt_k_norm"].double(), case["action"].double())
         smp64 = orc.samples_from_bins(case["origins"].double(), case["directions"].double(), c["z_near"].double(), c["z_far"].double(),
@@ -348,6 +320,39 @@ def test_transformer_head_at_full_c2_size_vs_oracle(dev, precision, margins):
                               "jacobian_transformer")
     finally:
         torch.set_default_dtype(prev)
+    return dict(case=case, params=params, ref=ref, r64=r64, f64=f64, ref_bins=ref_bins, S=S, A=A)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2", "f16f6"])
+def test_transformer_head_at_full_c2_size_vs_oracle(dev, precision, margins, transformer_c2):
+    """The reference's shipped Allegro decoder (jacobian_transformer, action_decoder_jacobian.py:340-446) on the C2 frame at
+    full size on a 2,048-ray subset, against the CPU oracle (floors: the oracle's own fp32-vs-float64 run; the
+    reference-generated goldens for this head are 16 x 16): end to end, and the per-sample Jacobian / composited action
+    features / flow / density at the oracle's own final bins."""
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    t = transformer_c2
+    case, params, ref, r64, f64, S, A = t["case"], t["params"], t["ref"], t["r64"], t["f64"], t["S"], t["A"]
+    cfg = model_cfg_from_dict({"action_dim": A, "encoder": {"name": "precomputed"},
+                               "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                               "action_decoder": {"name": "jacobian_transformer"}})
+    model = Model(cfg).to(dev).eval().requires_grad_(False)
+    model.load_state_dict({k: v.to(dev) for k, v in params.items()}, strict=True)
+    model.set_precision(precision)
+    model.encoder.set_features(case["feats"].to(dev))
+    c = case["cams"]
+    d = lambda x: x.to(dev)
+    cam = CameraInput(None, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+    rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
+    rob = RobotInput(d(case["action"]))
+    out = model.forward(cam, rin, rob, compute_vis_features=True)
+    tag = f"C2@full[transformer head:{precision}]"
+    margins(tag, "rgb", out.standard_output.rgb, ref.rgb, r64.rgb)
+    margins(tag, "depth", out.standard_output.depth, ref.depth, r64.depth)
+    margins(tag, "optical_flow", out.standard_output.optical_flow, ref.optical_flow, r64.optical_flow)
+    with torch.no_grad():   # the head itself at identical sample locations (the oracle's final bins injected)
+        outs, *_ = model._fused_render(cam, rin, rob, model._encode_for_render(None), want_lists=False, want_vis=True,
+                                       want_samples=True, final_bins=t["ref_bins"].to(dev))
     margins(tag, "s_jacobian", outs["jacobian"], ref.jacobian, f64.jacobian)
     margins(tag, "s_action_features", outs["action_features"], ref.action_features, f64.action_features)
     margins(tag, "s_optical_flow", outs["flow"], ref.optical_flow, f64.optical_flow)
