@@ -778,7 +778,7 @@ __device__ __forceinline__ unsigned quad_bcast_n(unsigned v, int s) {  // s is a
   return s == 0 ? quad_bcast<0>(v) : (s == 1 ? quad_bcast<1>(v) : (s == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
 }
 
-template <int MB>
+template <int MB, int DEPTH = 4>
 __device__ __forceinline__ void add_hoisted_latent_quad(const float* __restrict__ gz, const PointGeom& g, int lane,
                                                         f32x16 (&h)[MB]) {
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
@@ -792,7 +792,6 @@ __device__ __forceinline__ void add_hoisted_latent_quad(const float* __restrict_
   const unsigned gofs = g.gofs;
   const unsigned own[4] = {gofs + (unsigned)f.t00, gofs + (unsigned)f.t01, gofs + (unsigned)f.t10, gofs + (unsigned)f.t11};
   const float w[4] = {f.w00, f.w01, f.w10, f.w11};
-  constexpr int DEPTH = 4;
   f32x4 x[DEPTH][MB];
   auto issue = [&](int b) {
     const float* src = gz + (size_t)(quad_bcast_n(own[b >> 2], b & 3) + lane_off);
@@ -825,7 +824,7 @@ __device__ __forceinline__ void add_hoisted_latent_quad(const float* __restrict_
 // Within a block of 32*MB channels the map stores logical feature f = 16*MB*hh + 16*m + 4*q + e at position
 // 32*m + 8*q + 4*hh + e (njf_hoist_position, layout 0), so the two lanes that own a point read ADJACENT 16-byte
 // pieces in the same instruction.
-template <int MB>
+template <int MB, int DEPTH = 4>
 __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict__ gz, const PointGeom& g, int hh,
                                                         f32x16 (&h)[MB]) {
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
@@ -843,7 +842,7 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
   // request rate, not by the exposed round trips -- and kept as the one structure both forms share).  sched_barrier pins
   // the issue order (otherwise the scheduler hoists all 16*MB loads -> scratch).
   // Accumulation order per element stays t = 0..3: bit-identical results.
-  constexpr int DEPTH = 4, NB = 4 * MB;
+  constexpr int NB = 4 * MB;
   f32x4 v[DEPTH][4];
   auto issue = [&](int b) {
     const float* src = p[b / MB] + 32 * (b % MB);
@@ -885,16 +884,16 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
 // njf_hoist_layout): the quad/MFMA form where the matrix pipe has headroom -- the fp6-corrected networks, measured
 // -3.8 % on the C2 final pass -- and the half/VALU form where it is the busier pipe (F16X2: the proposal pass measured
 // +5 % with the quad form; F32: the matrix pipe is the bound).
-template <int MB, int PREC>
+template <int MB, int PREC, int DEPTH = 4>
 __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int lane,
                                                    f32x16 (&h)[MB]) {
 #if defined(NJF_GATHER_ALWAYS_HALF)  // A/B builds only (tools/ablate.sh)
-  add_hoisted_latent_half<MB>(gz, g, lane >> 5, h);
+  add_hoisted_latent_half<MB, DEPTH>(gz, g, lane >> 5, h);
 #elif defined(NJF_GATHER_ALWAYS_QUAD)
-  add_hoisted_latent_quad<MB>(gz, g, lane, h);
+  add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
 #else
-  if constexpr (PREC == PREC_F16F6) add_hoisted_latent_quad<MB>(gz, g, lane, h);
-  else add_hoisted_latent_half<MB>(gz, g, lane >> 5, h);
+  if constexpr (PREC == PREC_F16F6) add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
+  else add_hoisted_latent_half<MB, DEPTH>(gz, g, lane >> 5, h);
 #endif
 }
 
@@ -1028,6 +1027,47 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
         *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
       }
   }
+#ifdef NJF_GATHER_DEPHASE
+  // Experiment: the four waves of a workgroup reach every gather together (same barrier phase) and share the CU's texture
+  // addresser, which is what bounds the gather (6.2 k cycles each, 19 % of a tile, tools/stamps.py).  The latent of block k
+  // only has to be in h before fc_0 of block k reads it, and adding it commutes with the products accumulated into h, so
+  // HALF of the waves ("early": wave & 2) fetch it one chunk earlier -- the latent of block 0 in front of lin_in (net is
+  // free), the latents of blocks 1, 2 between the two K-halves of the previous block's fc_1 (the first half of net is dead
+  // by then: 32 landing registers, DEPTH 2) -- and the other half where they always did.  The order of the fp32 additions
+  // into h differs between the two groups (last-bit differences between rays that land in different wave slots).
+  const bool early = (wave & 2) != 0;
+  if (early) add_hoisted_latent<4, PREC>(gz, g, lane, h);
+  {
+    const float* wl = stream_step(st, wave, lane);
+    mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
+  }
+  if (!early) add_hoisted_latent<4, PREC>(gz, g, lane, h);
+  for (int blk = 0; blk < 5; ++blk) {
+    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
+    const float* bl = bias + blk * 256;
+    bias_init<4, true, PREC>(bl, hh, net);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, h, net);
+    }
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, h, net);
+    }
+    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
+    bias_init<4, false, PREC>(bl + 128, hh, h);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, net, h);
+    }
+    if (early && blk < 2) add_hoisted_latent<4, PREC, 2>(gz + (blk + 1) * 128, g, lane, h);
+    {
+      const float* wl = stream_step(st, wave, lane);
+      mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, net, h);
+    }
+    if (!early && blk < 2) add_hoisted_latent<4, PREC>(gz + (blk + 1) * 128, g, lane, h);
+  }
+#else
   {
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
@@ -1060,6 +1100,7 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
       mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, net, h);
     }
   }
+#endif
   if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h);
   bias_init<1, true, PREC>(bias + 1280, hh, out);
   {
