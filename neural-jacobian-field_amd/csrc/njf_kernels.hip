@@ -566,6 +566,91 @@ __global__ void __launch_bounds__(256) upsample_add_kernel(UpsampleArgs a) {
   *(f32x4*)(a.out + ((size_t)t * a.n + c)) = acc;
 }
 
+// The same sum for pyramids whose coarser levels are exact 2^-s images of level 0 (ResNet latents of an image whose sides
+// divide by 32: every shape the reference trains and renders): one thread = 4 channels of a 4 x 4 block of texels.  The
+// bilinear taps of a block are a 4 x 4 (s = 1), 3 x 3 (s = 2) or 2 x 2 (s >= 3) patch of the coarser level, loaded once
+// into registers -- 29 tap reads per 16 texels instead of 192, which is what bound the per-texel form (13 of its 14
+// 16-byte accesses per texel were taps served by L2).  Weights and the order of every sum are the per-texel form's
+// (src = (dst + 0.5) / 2^s - 0.5 is exact in fp32, so floor(src) is the compile-time offset table below; clamped patch
+// indices reproduce the border taps, whose weight is exactly 0 where the clamp changes the tap): bit-identical output.
+template <int S>  // 1, 2, or 3 = "3 or more"
+__device__ __forceinline__ void upsample_block_level(const float* __restrict__ src, int h, int w, int n, int shift, int bx, int by,
+                                                     int height, int width, f32x4 (&acc)[4][4]) {
+  constexpr int NC = S == 1 ? 4 : S == 2 ? 3 : 2;
+  constexpr int OFF[4] = {0, S == 1 ? 1 : 0, S == 3 ? 0 : 1, S == 1 ? 2 : S == 2 ? 1 : 0};
+  // floor((4 k + 0.5) / 2^s - 0.5) = (8 k + 1 - 2^s) >> (s + 1), arithmetic shift
+  const int base_x = (8 * bx + 1 - (1 << shift)) >> (shift + 1), base_y = (8 * by + 1 - (1 << shift)) >> (shift + 1);
+  f32x4 patch[NC][NC];
+#pragma unroll
+  for (int r = 0; r < NC; ++r) {
+    const int yy = min(max(base_y + r, 0), h - 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int xx = min(max(base_x + c, 0), w - 1);
+      patch[r][c] = *(const f32x4*)(src + ((size_t)yy * w + xx) * n);
+    }
+  }
+  float wx[4], wy[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sx = fmaxf(((float)(4 * bx + j) + 0.5f) * ((float)w / (float)width) - 0.5f, 0.f);
+    const float sy = fmaxf(((float)(4 * by + j) + 0.5f) * ((float)h / (float)height) - 0.5f, 0.f);
+    wx[j] = sx - (float)min((int)sx, w - 1);
+    wy[j] = sy - (float)min((int)sy, h - 1);
+  }
+#pragma unroll
+  for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+      const f32x4 v00 = patch[OFF[jy]][OFF[jx]], v01 = patch[OFF[jy]][OFF[jx] + 1];
+      const f32x4 v10 = patch[OFF[jy] + 1][OFF[jx]], v11 = patch[OFF[jy] + 1][OFF[jx] + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float top = v00[e] * (1.0f - wx[jx]) + v01[e] * wx[jx], bot = v10[e] * (1.0f - wx[jx]) + v11[e] * wx[jx];
+        acc[jy][jx][e] += top * (1.0f - wy[jy]) + bot * wy[jy];
+      }
+    }
+}
+
+struct UpsampleBlockArgs {
+  UpsampleArgs u;
+  int shift[3];
+};
+
+__global__ void __launch_bounds__(256) upsample_add_block_kernel(UpsampleBlockArgs p) {
+  const UpsampleArgs& a = p.u;
+  const int n4 = a.n >> 2, bw = a.width >> 2, bh = a.height >> 2;
+  const long long total = (long long)a.batch * bh * bw * n4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % n4) * 4;
+  const long long t = i / n4;
+  const int bx = (int)(t % bw), by = (int)((t / bw) % bh), b = (int)(t / ((long long)bw * bh));
+  float* out = a.out + (((size_t)b * a.height + 4 * by) * a.width + 4 * bx) * a.n + c;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) acc[jy][jx] = *(const f32x4*)(out + ((size_t)jy * a.width + jx) * a.n);
+  for (int l = 0; l < a.levels; ++l) {
+    const float* src = a.src[l] + (size_t)b * a.h[l] * a.w[l] * a.n + c;
+    if (p.shift[l] == 1) upsample_block_level<1>(src, a.h[l], a.w[l], a.n, 1, bx, by, a.height, a.width, acc);
+    else if (p.shift[l] == 2) upsample_block_level<2>(src, a.h[l], a.w[l], a.n, 2, bx, by, a.height, a.width, acc);
+    else upsample_block_level<3>(src, a.h[l], a.w[l], a.n, p.shift[l], bx, by, a.height, a.width, acc);
+  }
+#pragma unroll
+  for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) *(f32x4*)(out + ((size_t)jy * a.width + jx) * a.n) = acc[jy][jx];
+}
+
+// shift s with (h << s, w << s) == (height, width), or 0 if the level is not an exact 2^-s image
+static int pyramid_shift(int h, int w, int height, int width) {
+  for (int s = 1; s < 16; ++s)
+    if ((long long)h << s == height && (long long)w << s == width) return s;
+  return 0;
+}
+
 extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels, const float* wz, int wz_ld, const float* bz,
                                    int batch, int n, float* out, float* workspace, int precision, void* stream) {
   if (!levels || !wz || !bz || !out) return NJF_E_NULL;
@@ -603,8 +688,23 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
     row0 += levels[l].channels;
   }
   if (u.levels > 0) {
-    const long long total = (long long)batch * u.height * u.width * (n >> 2);
-    upsample_add_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(u);
+    UpsampleBlockArgs blk;
+    blk.u = u;
+    bool blocked = (u.height & 3) == 0 && (u.width & 3) == 0;
+    for (int l = 0; l < u.levels; ++l) {
+      blk.shift[l] = pyramid_shift(u.h[l], u.w[l], u.height, u.width);
+      blocked = blocked && blk.shift[l] > 0;
+    }
+#ifdef NJF_UPSAMPLE_PER_TEXEL  // experiment builds only: the per-texel form for every pyramid
+    blocked = false;
+#endif
+    if (blocked) {
+      const long long total = (long long)batch * (u.height >> 2) * (u.width >> 2) * (n >> 2);
+      upsample_add_block_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blk);
+    } else {
+      const long long total = (long long)batch * u.height * u.width * (n >> 2);
+      upsample_add_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(u);
+    }
   }
   return launch_status();
 }

@@ -155,21 +155,26 @@ def test_feature_projection_vs_float64(dev, precision, shape):
     assert err < max(2e-6, 4 * floor), (err, floor)
 
 
+@pytest.mark.parametrize("sizes", [((64, 24, 40), (64, 12, 20), (128, 6, 10), (256, 3, 5)),      # ResNet-34 ratios: 4 x 4-blocked up-sampled add
+                                   ((64, 8, 16), (64, 4, 8), (128, 2, 4), (256, 1, 2)),          # ... with a level one texel high
+                                   ((64, 24, 40), (64, 12, 20), (128, 6, 10), (256, 5, 7)),      # a non-2^-s level: per-texel form
+                                   ((64, 18, 30), (64, 9, 15), (128, 5, 8), (256, 3, 4))])       # sides not divisible by 4: per-texel form
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
-def test_pyramid_producer_equals_projecting_the_concatenated_map(dev, precision):
+def test_pyramid_producer_equals_projecting_the_concatenated_map(dev, precision, sizes):
     """encoder_resnet.py:78-86 (bilinear up-sampling to the conv1 resolution + concatenation) followed by the lin_z
     hoist, against the fused producer that projects every level at its own resolution and adds the up-sampled
-    projections: the same linear map, evaluated in a different order."""
+    projections: the same linear map, evaluated in a different order.  Both forms of the up-sampled add are covered (the
+    blocked one reproduces the per-texel one bit for bit: profiles/r03_ab_variants.txt section 8)."""
     import torch.nn.functional as F
     from neural_jacobian_field_amd import hip
     g = torch.Generator().manual_seed(77)
     b, n = 2, 832
-    levels = [torch.randn(b, c, h, w, generator=g).to(dev) for c, h, w in ((64, 24, 40), (64, 12, 20), (128, 6, 10), (256, 3, 5))]
+    levels = [torch.randn(b, c, h, w, generator=g).to(dev) for c, h, w in sizes]
     wz = (torch.randn(512, n, generator=g) * 0.05).to(dev)
     bz = torch.randn(n, generator=g).to(dev)
     feats = torch.cat([F.interpolate(lv, levels[0].shape[-2:], mode="bilinear", align_corners=False) for lv in levels], dim=1)
     ref = torch.einsum("bkhw,kn->bhwn", feats.double(), wz.double()) + bz.double()
-    out = torch.empty(b, 24, 40, n, device=dev)
+    out = torch.empty(b, sizes[0][1], sizes[0][2], n, device=dev)
     hip.project_pyramid(levels, wz, bz, out, precision=precision)
     err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
     assert err < 3e-6, err

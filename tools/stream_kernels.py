@@ -38,7 +38,7 @@ def workloads():
         "raygen": ("raygen_kernel", rays * (8 + 28), f"{rays} rays: pixel coordinate 8 B in, origin + direction + z 28 B out"),
         "alpha_weights": ("alpha_weights_kernel", rays * S * 12, f"[{rays},{S}] deltas + densities in, weights out (4 B each)"),
         "pdf": ("pdf_kernel", rays * (S + (S + 1) + (S + 1)) * 4, f"[{rays},{S}] weights + [{rays},{S + 1}] bins in, [{rays},{S + 1}] bins out"),
-        "upsample_add": ("upsample_add_kernel", (2 * HF * WF + lower) * n_dec * 4,
+        "upsample_add": ("upsample_add_block_kernel", (2 * HF * WF + lower) * n_dec * 4,
                          f"hoisted map [{HF},{WF},{n_dec}] read + written, projected coarser levels ({lower} texels x {n_dec}) read once"),
         "upsample_concat": ("upsample_concat_kernel", (sum(c * h * w for c, h, w in PYRAMID) + HF * WF * 512) * 4,
                             f"four NCHW latents in, [{HF * WF},512] channels-last matrix out"),
