@@ -385,7 +385,7 @@ def main():
                        "parallelism": f"dp{world} ({'one frame, rays sharded' if strong else 'one frame per rank'}, replicated weights "
                                       "and feature map)"},
             "kernel_ms": {k: round(v, 3) for k, v in k_ms.items()},
-            "step": {"form": ("ShardedFrameStep: Model.forward (per-image projection x2, njf_proposal_forward, njf_render_forward "
+            "step": {"form": ("ShardedFrameStep: Model.forward (one per-image projection for all networks, njf_proposal_forward, njf_render_forward "
                               "with the frame reductions in its epilogue) + njf_reduce_frame_partials + "
                               + ("ONE all_gather of [pixels | 4 scalars] + " if world > 1 else "")
                               + "njf_assemble_frame (global depth clip, rgb / flow loss)") if use_frame_step else

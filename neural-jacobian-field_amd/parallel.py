@@ -185,7 +185,10 @@ class ShardedFrameStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         self._static = (camera_input, rendering_input, robot_input)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # with a process group alive, its watchdog thread polls events while this thread captures: only calls of the
+        # capturing thread itself may invalidate the capture
+        mode = "thread_local" if dist.is_initialized() else "global"
+        with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._out = self.local(camera_input, rendering_input, robot_input)
 
     def __call__(self, camera_input=None, rendering_input=None, robot_input=None):
