@@ -106,58 +106,6 @@ def test_model_forward_from_reference_features(model_and_golden, margins, precis
             out = model.forward(*_inputs(g), compute_vis_features=True)
     finally:
         model.set_precision("f16x2")
-
-
-def test_plain_checkpoint_load_never_renders_finite_but_wrong_pixels(model_and_golden):
-    """INTEGRATION.md section A as written -- Model(cfg), load_state_dict, forward / patch_render, nothing else -- on a
-    checkpoint whose hidden activations leave fp16's range (first layer of the density head scaled by 3e5, activations
-    ~1e6).  In the fp16-carried default precision the overflow does NOT surface by itself (hi becomes inf, the integer
-    ReLU can flush the NaN): the automatic range check of the first forward pass after load_state_dict must warn and move
-    the model to exact fp32 products, whose output equals a model that was put on "f32" by hand, bit for bit."""
-    import copy
-    import warnings
-    from neural_jacobian_field_amd.model import Model
-    src, g = model_and_golden
-    cam, rin, rob = _inputs(g)
-    sd = {k: v.clone() for k, v in src.state_dict().items()}
-    sd["decoder.density_head.lin_in.weight"] *= 3.0e5
-    sd["decoder.density_head.lin_in.bias"] *= 3.0e5
-    dev = g["image"].device
-    plain = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
-    plain.load_state_dict(sd)                                   # the snippet of INTEGRATION.md section A ends here
-    assert plain.decoder.precision == "f16f6"                   # the package default, fp16-carried
-    # (every model below renders from the reference's encoder output: MIOpen's convolutions are not bit-reproducible from
-    # run to run, and the comparison is bit for bit)
-    with warnings.catch_warnings(record=True) as caught, _from_reference_features(plain, g):
-        warnings.simplefilter("always")
-        out = plain.forward(cam, rin, rob).standard_output
-    assert any("fp16's range" in str(w.message) for w in caught), [str(w.message) for w in caught]
-    assert plain.decoder.precision == "f32" and all(m.precision == "f32" for m in plain.proposal_networks)
-    by_hand = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
-    by_hand.auto_range_check = False
-    by_hand.load_state_dict(sd)
-    by_hand.set_precision("f32")
-    with _from_reference_features(by_hand, g):
-        ref = by_hand.forward(cam, rin, rob).standard_output
-    for a, b in ((out.rgb, ref.rgb), (out.depth, ref.depth), (out.optical_flow, ref.optical_flow)):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
-    # the guard is what made the difference: with it switched off the same checkpoint renders something else in f16f6
-    unguarded = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
-    unguarded.auto_range_check = False
-    unguarded.load_state_dict(sd)
-    with _from_reference_features(unguarded, g):
-        bad = unguarded.forward(cam, rin, rob).standard_output
-    assert unguarded.decoder.precision == "f16f6"
-    assert not torch.isfinite(bad.rgb).all() or rel(bad.rgb, ref.rgb) > 1e-3   # non-finite, or finite and WRONG
-    # ... and a sane checkpoint is checked once, silently, and keeps the default precision
-    with warnings.catch_warnings(record=True) as caught:
-        warnings.simplefilter("always")
-        sane = Model(copy.deepcopy(src.cfg)).to(dev).eval().requires_grad_(False)
-        sane.load_state_dict(src.state_dict())
-        sane.forward(cam, rin, rob)
-        checked = sane._range_checked
-        sane.forward(cam, rin, rob)
-    assert not caught and sane.decoder.precision == "f16f6" and checked is not None and sane._range_checked == checked
     _check_forward(margins, f"model_mlp.forward[{precision}]", out, g, encoder=False)
 
 
@@ -650,3 +598,25 @@ def test_plain_checkpoint_load_never_renders_finite_but_wrong_pixels(model_and_g
         checked = sane._range_checked
         sane.forward(cam, rin, rob)
     assert not caught and sane.decoder.precision == "f16f6" and checked is not None and sane._range_checked == checked
+
+
+def test_empty_and_single_ray_batches(model_and_golden):
+    """Edge sizes of the ray batch.  The reference cannot render an empty batch either (render_depth takes min()/max() of an
+    empty tensor, model.py:277: RuntimeError): here it is refused before any launch, with the C ABI's shape error, and the
+    model keeps working afterwards; ONE ray (a single wave, one half-empty tile) renders the same pixel as inside a batch."""
+    from neural_jacobian_field_amd.model import RenderingInput
+    model, g = model_and_golden
+    cam, rin, rob = _inputs(g)
+    with _from_reference_features(model, g):
+        full = model.forward(cam, rin, rob).standard_output
+        empty = RenderingInput(rin.origins[:, :0].contiguous(), rin.directions[:, :0].contiguous(), rin.z_near, rin.z_far)
+        with pytest.raises((ValueError, RuntimeError)):
+            model.forward(cam, empty, rob)
+        one = RenderingInput(rin.origins[:, 5:6].contiguous(), rin.directions[:, 5:6].contiguous(), rin.z_near, rin.z_far)
+        out = model.forward(cam, one, rob).standard_output
+    assert out.rgb.shape == (full.rgb.shape[0], 1, 3)
+    assert torch.equal(out.rgb, full.rgb[:, 5:6]) and torch.equal(out.optical_flow, full.optical_flow[:, 5:6])
+    # depth is clipped with the bounds of the rays of the CALL (model.py:277), so only the un-clipped case must agree
+    lo, hi = full.depth.min(), full.depth.max()
+    inside = (full.depth[:, 5:6] > lo) & (full.depth[:, 5:6] < hi)
+    assert torch.equal(out.depth[inside], full.depth[:, 5:6][inside])
