@@ -7,22 +7,36 @@ fp32 operands.  The image encoder is excluded as SURVEY 8(d) prescribes (it is p
 built with the ``"precomputed"`` encoder entry, whose forward returns the synthetic 512-channel feature map, so the
 timed call IS ``Model.forward`` -- per step and per rank
 
-    per-image lin_z projection of the feature map (proposal net + decoder; the cache is reset every step)
-    -> njf_proposal_forward -> njf_render_forward -> depth clip -> photometric + flow loss against synthetic targets
+    per-image lin_z projection of the feature map (ONE launch for all networks; the cache is reset every step)
+    -> njf_proposal_forward -> njf_render_forward (frame reductions in its epilogue) -> njf_reduce_frame_partials
+    -> [N > 1: ONE all_gather of (pixels | 4 scalars)] -> njf_assemble_frame (global depth clip, rgb + flow loss)
 
 Inputs are resident in HBM when the clock starts.
 
-N > 1 (``torchrun``, one rank per GPU, RCCL over xGMI) -- ``--scaling strong`` (default), SURVEY.md 8(e) literally: the
-R rays of ONE frame are split into N contiguous shards (``parallel.shard_rays``), weights and feature map are
-replicated, each rank renders its shard through the same ``Model.forward``, and three small collectives run per step:
-all-reduce(MAX) of the two depth-clip bounds (``parallel.global_depth_clip``), all-reduce(SUM) of the image/flow loss
-sums (``parallel.sharded_losses``), all_gather of the [R/N, 6] pixel shards (``parallel.gather_frame``).
-value = rays of the frame / max-over-ranks time.  ``--scaling weak``: every rank renders its own full frame.
+**Which arithmetic is the headline (VERDICT r03 "next" #2).**  ``value`` / ``dtype`` / ``roofline`` are the run with EXACT fp32
+products (``v_mfma_f32_32x32x2_f32``, the reference's arithmetic; roofline against the 157.3 TFLOP/s fp32-MFMA peak).  The
+package's default precision (``f16f6``: error-compensated fp16 split with fp6 correction terms) is measured in the same
+process with the same --steps / --warmup, the same barriers and the same max-over-ranks, and reported as
+``value_default_precision`` with its own roofline block against the 2.5 PFLOP/s f16 peak -- it is an accelerated mode inside
+the parity bounds, not fp32 arithmetic, so it is not in the headline slot.  ``--precision`` moves another mode there.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]      (torchrun launches N>1)
+**Launch (VERDICT r03 "next" #1).**  ``python bench.py --gpus N`` started as a plain process spawns its N ranks itself
+(``neural_jacobian_field_amd.launch``: ``python -m torch.distributed.run``, one rank per GPU, rendezvous on 127.0.0.1);
+started under a launcher (the driver's ``torch.distributed.run`` line) it checks that WORLD_SIZE == N.  In both cases the
+line is refused -- no JSON, non-zero exit -- when its ``n_gpus`` would differ from ``--gpus`` or two ranks share a device, and
+it carries ``rccl``: backend, world size, per-rank device identity (PCI bus id / uuid, all-gathered through the process
+group) and per-rank step times.
+
+N > 1 -- ``--scaling strong`` (default), SURVEY.md 8(e) literally: the R rays of ONE frame are split into N contiguous
+shards (``parallel.shard_bounds``), weights and feature map are replicated, each rank renders its shard through the same
+``Model.forward``, ONE collective per step.  value = rays of the frame / max-over-ranks time.  ``--scaling weak``: every
+rank renders its own full frame.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import importlib.util
 import json
 import os
 import statistics
@@ -36,7 +50,8 @@ sys.path.insert(0, ROOT)
 
 H = W = 256
 S_PROP, S_FINAL, ACTION_DIM = 64, 64, 8
-PROFILE_ROUND = "r03"
+PROFILE_ROUNDS = ("r04", "r03")   # newest first: where roofline.traffic (PMC passes, never taken in the timed run) is looked up
+HEADLINE_PRECISION = "f32"        # the reference's arithmetic; see the module docstring
 
 # Algorithmic work (hoisted-lin_z formulation), MACs per point
 MAC_PROPOSAL = 172_032
@@ -47,15 +62,14 @@ PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "f16f6": 2500.0}
 # matrix-pipe time per algorithmic product block, in units of one f16 32x32x16 MFMA: f16x2 evaluates hi*hi + hi*lo + lo*hi;
 # f16f6 evaluates hi*hi in f16 and both corrections of FOUR K-steps in two fp6 instructions of the same issue time
 ISSUE_FACTOR = {"f32": 1.0, "f16x2": 3.0, "f16f6": 1.5}
-# `dtype` names the ARITHMETIC of the matrix products, not the I/O type (fp32 in, fp32 accumulate, fp32 out
-# in every mode).  The fp32-arithmetic number is the co-headline `value_fp32_arithmetic`.
+# `dtype` names the ARITHMETIC of the matrix products, not the I/O type (fp32 in, fp32 accumulate, fp32 out in every mode).
 DTYPE_TEXT = {
-    "f32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
+    "f32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- the reference's arithmetic)",
     "f16x2": "f16x2 (every fp32 operand split into two fp16, hi*hi + hi*lo + lo*hi as 3 f16 MFMAs per block, fp32 accumulate; "
              "fp32 inputs/outputs; measured error vs fp32 arithmetic ~4e-7 per network)",
     "f16f6": "f16f6 (final pass: hi*hi in f16 MFMAs + both 2^-11-sized correction products in block-scaled fp6 MFMAs, fp32 "
              "accumulate; proposal pass: f16x2; fp32 inputs/outputs; measured error vs fp32 arithmetic ~1.5e-5 per network, "
-             "inside north_star's 1e-4 -- see parity_on_bench_frame and profiles/r03_parity_margins.json)",
+             "inside north_star's 1e-4 -- see parity_on_bench_frame and profiles/r04_parity_margins.json)",
 }
 
 
@@ -86,8 +100,13 @@ def parse():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--samples", type=int, default=S_FINAL, help="proposal and final samples per ray")
     ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default=None,
-                    help="MFMA precision of the fused MLPs (default: the package default, hip.DEFAULT_PRECISION)")
+                    help=f"MFMA precision in the headline slot (default {HEADLINE_PRECISION}: the reference's fp32 arithmetic; the "
+                         "package default, hip.DEFAULT_PRECISION, is always measured next to it as value_default_precision)")
     ap.add_argument("--no-other-precisions", action="store_true")
+    ap.add_argument("--dry-launch", metavar="STANDINS.py", default=None,
+                    help="launcher self-test WITHOUT a GPU (tests/test_host_cpu.py): the same launch / world check / barriers / "
+                         "rank evidence / one JSON line, over the gloo backend, with parallel.ShardedFrameStep driven by the "
+                         "stand-in kernels the given python file provides.  The line says dry_launch: true and has no value")
     return ap.parse_args()
 
 
@@ -100,6 +119,40 @@ def cpu_model_name() -> str:
     except OSError:
         pass
     return "unknown"
+
+
+def timed_loop(step_fn, steps: int, dist, sync):
+    """EXACTLY `steps` steps between (barrier + device synchronisation) on both sides.  Returns (seconds until every rank
+    has passed the closing barrier, seconds until THIS rank's own device work was done)."""
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    sync()
+    return time.perf_counter() - t0, local
+
+
+def max_over_ranks(dist, seconds: float, device) -> float:
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def emit(line: dict, gpus: int) -> None:
+    from neural_jacobian_field_amd import launch
+    launch.check_line(line, gpus)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)  # anything native libraries buffered on stdout goes out BEFORE the JSON line
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
 
 
 def cpu_baseline(case, ray_index, passes: int):
@@ -143,55 +196,86 @@ def parity_on_bench_frame(models, cam, rob, z_near, z_far, origins, directions, 
     """The HIP outputs of the timed frame's rays `ray_index` against the CPU oracle's outputs on the same rays (ray shards
     render bit-identically to the full frame, tests/test_properties_gpu.py, so this IS a full-size check of what was timed),
     for every MFMA precision.  Bound per quantity as in the test-suite: max(1e-4, 2 x floor), floor = the oracle's own
-    fp32-vs-float64 difference on these rays."""
+    fp32-vs-float64 difference on these rays; next to it the truth-referenced element-wise columns of
+    oracle/parity_harness.py::truth_columns (e_hip = |hip - fp64| against e_ref = |fp32 oracle - fp64|)."""
     import parity_harness as ph
     from neural_jacobian_field_amd.model import RenderingInput
 
     idx = ray_index.to(origins.device)
     rin = RenderingInput(origins[:, idx].contiguous(), directions[:, idx].contiguous(), z_near, z_far)
-    ref_bins = torch.cat([ref.samples_list[1].spacing_starts[..., 0], ref.samples_list[1].spacing_ends[..., -1:, 0]], -1)
-    ref64_bins = torch.cat([ref64.samples_list[1].spacing_starts[..., 0], ref64.samples_list[1].spacing_ends[..., -1:, 0]], -1)
-    floors = {"rgb": ph.rel_err(ref.rgb, ref64.rgb), "depth": ph.rel_err(ref.depth, ref64.depth),
-              "optical_flow": ph.rel_err(ref.optical_flow, ref64.optical_flow),
-              "prop_weights": ph.rel_err(ref.weights_list[0], ref64.weights_list[0]),
-              "final_bins": ph.rel_err(ref_bins, ref64_bins)}
+    bins_of = lambda r: torch.cat([r.samples_list[1].spacing_starts[..., 0], r.samples_list[1].spacing_ends[..., -1:, 0]], -1)
+    ref_bins, ref64_bins = bins_of(ref), bins_of(ref64)
+    pairs = {"rgb": (ref.rgb, ref64.rgb), "depth": (ref.depth, ref64.depth), "optical_flow": (ref.optical_flow, ref64.optical_flow),
+             "prop_weights": (ref.weights_list[0], ref64.weights_list[0]), "final_bins": (ref_bins, ref64_bins)}
+    floors = {k: ph.rel_err(a, b) for k, (a, b) in pairs.items()}
     report = {}
     for prec, m in models.items():
         with torch.no_grad():
             outs, bins, wl, bl, _ = m._fused_render(cam, rin, rob, m._encode_for_render(None), want_lists=True, want_vis=False,
                                                     want_samples=False)
         torch.cuda.synchronize()
-        got = {"rgb": (outs["rgb"], ref.rgb), "depth": (outs["depth"], ref.depth), "optical_flow": (outs["flow"], ref.optical_flow),
-               "prop_weights": (wl[0], ref.weights_list[0]), "final_bins": (bins, ref_bins)}
+        got = {"rgb": outs["rgb"], "depth": outs["depth"], "optical_flow": outs["flow"], "prop_weights": wl[0], "final_bins": bins}
         rows = {}
-        for k, (a, b) in got.items():
+        for k, a in got.items():
+            b, b64 = pairs[k]
             err, floor = ph.rel_err(a.reshape(b.shape), b), floors[k]
             limit = max(1e-4, 2.0 * floor)
             rows[k] = {"err": float(f"{err:.3e}"), "floor": float(f"{floor:.3e}"), "limit": float(f"{limit:.3e}"),
-                       "ok": bool(err <= limit)}
+                       "ok": bool(err <= limit), "truth": ph.truth_columns(a.reshape(b.shape), b, b64)}
         report[prec] = rows
     return report
 
 
+def dry_launch(args, dist, rank: int, world: int) -> None:
+    """The launcher path without a GPU: same world check, barriers, max-over-ranks, rank evidence and line gate as a real
+    run, with parallel.ShardedFrameStep on CPU tensors and the stand-in kernels of the file named by --dry-launch (the
+    tests' tensor-op restatements).  Nothing here is a measurement and the line says so."""
+    from neural_jacobian_field_amd import launch, parallel
+
+    spec = importlib.util.spec_from_file_location("njf_dry_standins", args.dry_launch)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    step, check = mod.make_frame_step(parallel, world, rank)
+    run = lambda: step(None, None, None)
+    for _ in range(args.warmup):
+        run()
+    elapsed, local = timed_loop(run, args.steps, dist, lambda: None)
+    elapsed = max_over_ranks(dist, elapsed, "cpu")
+    frame, scalars, _ = run()
+    ok = torch.tensor([1.0 if check(frame, scalars) else 0.0])
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    evidence = launch.rank_evidence(dist, torch.device("cpu"), 1e3 * local / args.steps)
+    if rank == 0:
+        emit({"metric": "launcher dry run: stand-in kernels on CPU tensors over gloo -- NOT a measurement", "value": None,
+              "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(1e3 * elapsed / args.steps, 3), "dry_launch": True, "frame_ok": bool(ok.item() == 1.0),
+              "scaling": "strong", "rccl": evidence}, args.gpus)
+
+
 def main():
     args = parse()
+    from neural_jacobian_field_amd import launch
+
+    dry = args.dry_launch is not None
+    # a plain process with --gpus N > 1 spawns its N ranks and exits with their status; under a launcher the world is checked
+    launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_devices=not dry)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:     # (ensure_world has already refused every such case; kept as the invariant of what follows)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if dry:
+        dist = launch.init_process_group("gloo") if (world > 1 or args.force_dist) else None
+        dry_launch(args, dist, rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
-        if "MASTER_ADDR" not in os.environ:  # --force-dist without torchrun
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+    dist = launch.init_process_group("nccl", device) if (world > 1 or args.force_dist) else None
 
     import __graft_entry__ as entry
 
@@ -232,9 +316,11 @@ def main():
     cfg = model_cfg_from_dict({"action_dim": ACTION_DIM, "encoder": {"name": "precomputed"},
                                "rendering": {"num_proposal_samples": [SS], "num_nerf_samples": SS},
                                "action_decoder": {"name": "jacobian_mlp"}})
-    precision = args.precision or hip.DEFAULT_PRECISION
+    precision = args.precision or HEADLINE_PRECISION
+    default_precision = hip.DEFAULT_PRECISION
+    wanted = [precision] + ([] if args.no_other_precisions else [p for p in (default_precision, "f16f6", "f16x2", "f32")])
     models = {}
-    for prec in [precision] + ([] if args.no_other_precisions else [p for p in ("f16f6", "f16x2", "f32") if p != precision]):
+    for prec in dict.fromkeys(wanted):
         m = Model(cfg).to(device).eval().requires_grad_(False)
         m.load_state_dict({k: dev(v) for k, v in params.items()}, strict=True)
         m.set_precision(prec)
@@ -273,55 +359,7 @@ def main():
             frame = parallel.gather_frame(torch.cat([out.rgb, out.depth, out.optical_flow], dim=-1), HH * WW)
         return out, losses, frame
 
-    model = models[precision]
-    for _ in range(args.warmup):
-        step(model)
-    graphed = bool(use_frame_step and not args.no_graph and (args.graph or world > 1))
-    if graphed:   # record the rank-local compute once; the graph replays the per-image projection, so no cache reset
-        try:
-            frame_steps[precision].capture(cam, rin, rob)
-        except Exception as exc:   # capture is an optimisation: an eager step is always available
-            print(f"[bench] HIP-graph capture failed on rank {rank} ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
-            frame_steps[precision]._graph = None
-            graphed = False
-        if dist is not None:       # every rank must take the same path through the timed loop's collectives
-            flag = torch.tensor([1.0 if graphed else 0.0], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if graphed and flag.item() == 0.0:
-                frame_steps[precision]._graph = None
-                graphed = False
-    if graphed:
-        for _ in range(2):
-            step(model)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    launches = []
-    if not graphed:
-        hip.set_profile_sink(launches)   # per-launch HIP events on the launch stream (roofline.achieved)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(model)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    hip.set_profile_sink(None)
-    timing_note = "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"
-    if graphed:   # events cannot be read back from inside a replayed graph: an eager pass of the same step, not part of `value`
-        frame_steps[precision]._graph = None
-        hip.set_profile_sink(launches)
-        for _ in range(args.steps):
-            step(model)
-        torch.cuda.synchronize()
-        hip.set_profile_sink(None)
-        timing_note = ("mean njf_render_forward launch duration over an EAGER pass of the same steps right after the timed "
-                       "(graph-replayed) loop, HIP events on the launch stream")
-    launches_per_step = len(launches) / max(args.steps, 1)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    sync = lambda: torch.cuda.synchronize(device)
 
     def kernel_ms(records, steps):
         acc = {"project": 0.0, "proposal": 0.0, "render": 0.0}
@@ -332,50 +370,92 @@ def main():
                 acc[key] += e0.elapsed_time(e1)
         return {k: v / steps for k, v in acc.items()}
 
-    # the other MFMA precisions, measured in the same process (never part of `value`): the exact-fp32-arithmetic mode with
-    # the SAME --steps / --warmup as the headline (it is the co-headline `value_fp32_arithmetic`), the rest briefly
-    others = {}
-    for prec, m in models.items():
-        if prec == precision:
-            continue
-        n = args.steps if prec == "f32" else max(2, args.steps // 4)
-        for _ in range(args.warmup if prec == "f32" else 1):
-            step(m)
-        torch.cuda.synchronize()
-        rec = []
-        hip.set_profile_sink(rec)
-        ta = time.perf_counter()
-        for _ in range(n):
-            step(m)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - ta
+    def measure(prec: str, steps: int, warmup: int) -> dict:
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks.
+        Per-launch HIP events on the launch stream give the kernel durations: inside the timed steps when they run eagerly,
+        in an eager pass right after the timed loop when the rank-local compute is replayed as a HIP graph."""
+        model = models[prec]
+        for _ in range(warmup):
+            step(model)
+        graphed = bool(use_frame_step and not args.no_graph and (args.graph or world > 1))
+        if graphed:   # record the rank-local compute once; the graph replays the per-image projection, so no cache reset
+            try:
+                frame_steps[prec].capture(cam, rin, rob)
+            except Exception as exc:   # capture is an optimisation: an eager step is always available
+                print(f"[bench] HIP-graph capture failed on rank {rank} ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
+                frame_steps[prec]._graph = None
+                graphed = False
+            if dist is not None:       # every rank must take the same path through the timed loop's collectives
+                flag = torch.tensor([1.0 if graphed else 0.0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if graphed and flag.item() == 0.0:
+                    frame_steps[prec]._graph = None
+                    graphed = False
+        if graphed:
+            for _ in range(2):
+                step(model)
+        launches = []
+        if not graphed:
+            hip.set_profile_sink(launches)   # per-launch HIP events on the launch stream (roofline.achieved)
+        elapsed, local = timed_loop(lambda: step(model), steps, dist, sync)
         hip.set_profile_sink(None)
-        others[prec] = (1e3 * dt / n, kernel_ms(rec, n), n)
+        timing_note = "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"
+        if graphed:   # events cannot be read back from inside a replayed graph: an eager pass of the same step, not part of `value`
+            frame_steps[prec]._graph = None
+            hip.set_profile_sink(launches)
+            for _ in range(steps):
+                step(model)
+            sync()
+            hip.set_profile_sink(None)
+            timing_note = ("mean njf_render_forward launch duration over an EAGER pass of the same steps right after the timed "
+                           "(graph-replayed) loop, HIP events on the launch stream")
+        return {"elapsed": max_over_ranks(dist, elapsed, device), "local_ms": 1e3 * local / steps, "steps": steps, "warmup": warmup,
+                "kernel_ms": kernel_ms(launches, steps), "launches_per_step": len(launches) / max(steps, 1), "graphed": graphed,
+                "timing_note": timing_note}
+
+    # headline first; the package's default precision with the SAME steps / warm-up / barriers; any remaining mode briefly
+    runs = {precision: measure(precision, args.steps, args.warmup)}
+    for prec in models:
+        if prec not in runs:
+            full = prec == default_precision
+            runs[prec] = measure(prec, args.steps if full else max(2, args.steps // 4), args.warmup if full else 1)
+    head = runs[precision]
+    evidence = launch.rank_evidence(dist, device, head["local_ms"], graph=head["graphed"])
+
+    total_rays = local_rays if sim_world else (frame_rays if strong else world * frame_rays)
+    render_flop = 2.0 * local_rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
+
+    def roofline(prec: str, run: dict) -> dict:
+        achieved = render_flop / (run["kernel_ms"]["render"] * 1e-3) / 1e12
+        traffic, traffic_source = None, None
+        if local_rays == H * W and SS == S_FINAL:
+            for rnd in PROFILE_ROUNDS:
+                pmc = os.path.join(ROOT, "profiles", f"{rnd}_render_kernel_hbm_bytes_{prec}.json")
+                if os.path.exists(pmc):
+                    with open(pmc) as f:
+                        traffic = json.load(f).get("hbm_bytes_per_launch")
+                    traffic_source = (f"NOT measured in this run: read from profiles/{os.path.basename(pmc)} (rocprofv3 --pmc passes "
+                                      "of this command on an earlier box, tools/profile_r04.sh + tools/summarize_profile.py)")
+                    break
+        return {"kernel": f"render_kernel<jacobian_mlp, {prec}> (density+colour+Jacobian MLPs + compositing)",
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[prec], 4), "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_flop_per_launch": render_flop, "mfma_issue_factor": ISSUE_FACTOR[prec],
+                "timing": run["timing_note"]}
 
     if rank == 0:
-        ms_step = 1e3 * elapsed / args.steps
-        total_rays = frame_rays if strong else world * frame_rays
-        if sim_world:
-            total_rays = local_rays
-        value = total_rays * args.steps / elapsed
-        k_ms = kernel_ms(launches, args.steps)
-        render_flop = 2.0 * local_rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
-        achieved = render_flop / (k_ms["render"] * 1e-3) / 1e12
-        traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_render_kernel_hbm_bytes_{precision}.json")
-        if os.path.exists(pmc) and local_rays == H * W and SS == S_FINAL:
-            with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-            traffic_source = (f"NOT measured in this run: read from profiles/{os.path.basename(pmc)} (rocprofv3 --pmc passes of "
-                              "this command on an earlier box, tools/profile_r02.sh + tools/summarize_profile.py)")
+        ms_step = 1e3 * head["elapsed"] / head["steps"]
+        value = total_rays * head["steps"] / head["elapsed"]
         mode = "strong" if strong else "weak"
         workload = ("C2: " if (BB, HH, WW, SS) == (1, 256, 256, 64) else "") + (
             f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final samples/ray, jacobian_mlp, A=8, "
             "eval-mode Model.forward (encoder excluded: 'precomputed' encoder entry returning the synthetic feature map; the "
             "per-image lin_z projection is inside the timed call) + rgb/flow loss")
         if world > 1:
-            workload += (" + RCCL: depth-clip all-reduce, loss all-reduce, all_gather of the pixel shards (rays of ONE frame split "
-                         "over the ranks)" if strong else " + RCCL loss all-reduce (one frame per rank)")
+            workload += (" + RCCL: ONE all_gather of [pixel shard | depth-clip bounds, loss sums] per step (rays of ONE frame split "
+                         "over the ranks)" if strong and use_frame_step else
+                         (" + RCCL: depth-clip all-reduce, loss all-reduce, all_gather of the pixel shards" if strong else
+                          " + RCCL loss all-reduce (one frame per rank)"))
         out = {
             "metric": "rendered rays/s (64 samples/ray, 256^2 image)",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -384,62 +464,62 @@ def main():
             "config": {"workload": workload, "precision": precision, "rays_per_gpu": local_rays,
                        "parallelism": f"dp{world} ({'one frame, rays sharded' if strong else 'one frame per rank'}, replicated weights "
                                       "and feature map)"},
-            "kernel_ms": {k: round(v, 3) for k, v in k_ms.items()},
+            "kernel_ms": {k: round(v, 3) for k, v in head["kernel_ms"].items()},
             "step": {"form": ("ShardedFrameStep: Model.forward (one per-image projection for all networks, njf_proposal_forward, njf_render_forward "
                               "with the frame reductions in its epilogue) + njf_reduce_frame_partials + "
                               + ("ONE all_gather of [pixels | 4 scalars] + " if world > 1 else "")
                               + "njf_assemble_frame (global depth clip, rgb / flow loss)") if use_frame_step else
                              "round-2 step: Model.forward + ATen depth clip, loss sums, concatenation (three collectives at N > 1)",
-                     "c_abi_launches_per_step": round(launches_per_step, 2), "hip_graph": graphed},
-            "roofline": {"kernel": f"render_kernel<jacobian_mlp, {precision}> (density+colour+Jacobian MLPs + compositing)",
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_flop_per_launch": render_flop,
-                         "mfma_issue_factor": ISSUE_FACTOR[precision],
-                         "timing": timing_note},
+                     "c_abi_launches_per_step": round(head["launches_per_step"], 2), "hip_graph": head["graphed"]},
+            "roofline": roofline(precision, head),
+            "rccl": evidence,
         }
         if sim_world:
             out["simulated"] = f"rank 0's shard of a {sim_world}-way strong split rendered on ONE GPU, no collectives: value counts only these rays"
         out["other_precisions"] = {}
-        for prec, (ms, km, n) in others.items():
-            ach = render_flop / (km["render"] * 1e-3) / 1e12
-            rec = {"ms_per_step": round(ms, 3), "steps": n, "rays_per_s_per_gpu": round(local_rays / (ms * 1e-3), 1),
-                   "kernel_ms": {k: round(v, 3) for k, v in km.items()},
-                   "roofline_achieved_tflops": round(ach, 2), "roofline_peak_tflops": PEAK_TFLOPS[prec],
-                   "roofline_frac": round(ach / PEAK_TFLOPS[prec], 4)}
-            out["other_precisions"][prec] = rec
-            if prec == "f32":   # the number whose ARITHMETIC matches the reference's (fp32 products): co-headline
-                out["value_fp32_arithmetic"] = {
-                    "value": round(total_rays / (ms * 1e-3), 1),
-                    "unit": "rays/s", "ms_per_step": round(ms, 3), "steps": n, "warmup": args.warmup,
-                    "dtype": DTYPE_TEXT["f32"],
-                    "timing": "same step function, same process, after the headline loop; wall clock around the loop (no barrier "
-                              "across ranks: rank 0's time)",
-                    "roofline": {"kernel": "render_kernel<jacobian_mlp, f32>", "bound": "mfma", "achieved": round(ach, 2),
-                                 "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["f32"], 4)}}
+        for prec, run in runs.items():
+            if prec == precision:
+                continue
+            ms = 1e3 * run["elapsed"] / run["steps"]
+            rf = roofline(prec, run)
+            out["other_precisions"][prec] = {
+                "ms_per_step": round(ms, 3), "steps": run["steps"], "warmup": run["warmup"],
+                "rays_per_s": round(total_rays / (ms * 1e-3), 1), "kernel_ms": {k: round(v, 3) for k, v in run["kernel_ms"].items()},
+                "roofline_achieved_tflops": rf["achieved"], "roofline_peak_tflops": rf["peak"], "roofline_frac": rf["frac"],
+                "hip_graph": run["graphed"]}
+            if prec == default_precision:   # the mode a user gets without asking: same protocol as the headline, NOT fp32 arithmetic
+                out["value_default_precision"] = {
+                    "value": round(total_rays / (ms * 1e-3), 1), "unit": "rays/s", "ms_per_step": round(ms, 3), "steps": run["steps"],
+                    "warmup": run["warmup"], "dtype": DTYPE_TEXT[prec],
+                    "timing": "same step function and process as the headline, its own warm-up, barrier + synchronize on both sides "
+                              "of exactly `steps` steps, max over ranks",
+                    "kernel_ms": {k: round(v, 3) for k, v in run["kernel_ms"].items()}, "roofline": rf,
+                    "note": "an accelerated mode held to the same parity bounds (parity_on_bench_frame, profiles/r04_parity_margins.json); "
+                            "its products are not fp32 products, so it is not the headline"}
         out["parity_note"] = ("every precision is held to the SAME bound against the CPU oracle / the reference's goldens: "
-                              "max(1e-4, 2 x the reference's own fp32-vs-fp64 difference of that quantity).  rgb, depth and the "
-                              "per-sample fields meet north_star's 1e-4; END-TO-END optical_flow is bounded by the reference's own "
-                              "fp32 floor (5e-4 ... 3e-3: sample placement feeds a 2*pi*512-gain encoding), not by 1e-4, in EVERY "
-                              "precision including exact fp32 arithmetic")
+                              "max(1e-4, 2 x the reference's own fp32-vs-fp64 difference of that quantity), and is reported "
+                              "element-wise against the float64 truth next to the reference's own fp32 error (truth columns).  rgb, "
+                              "depth and the per-sample fields meet north_star's 1e-4; END-TO-END optical_flow is bounded by the "
+                              "reference's own fp32 floor (5e-4 ... 3e-3: sample placement feeds a 2*pi*512-gain encoding), not by "
+                              "1e-4, in EVERY precision including exact fp32 arithmetic")
         if world == 1 and not sim_world and not args.no_cpu_baseline and (BB, HH, WW, SS) == (1, 256, 256, 64):
             case = {"params": params, "feats": feats_cpu, "cams": cams, "origins": origins.cpu(), "directions": directions.cpu(),
                     "k_pix": k_pix.cpu(), "action": action_cpu}
             stride = max(1, (HH * WW) // args.cpu_sample_rays)
             ray_index = torch.arange(0, HH * WW, stride)[: args.cpu_sample_rays]
             out["cpu_baseline"], ref, ref64, _ = cpu_baseline(case, ray_index, args.cpu_passes)
-            # full-size parity of the frame that was just timed, in every precision (VERDICT r02 #1a)
+            # full-size parity of the frame that was just timed, in every precision
             out["parity_on_bench_frame"] = {
                 "rays": f"{ray_index.numel()} rays of the timed C2 frame (every {stride}th), 128x128x512 feature map, 64+64 samples",
                 "rule": "err <= max(1e-4, 2 x floor); err, floor norm-wise (max|a-b| / max|b|); floor = CPU oracle fp32 vs the same "
-                        "oracle in float64 on these rays",
+                        "oracle in float64 on these rays.  truth: element-wise |hip - fp64| against |fp32 oracle - fp64|, relative "
+                        "to max|fp64|; truth_ok = max and 99.9th percentile within 1.5 x the oracle's own (or 4 fp32 ulps of scale)",
                 **parity_on_bench_frame(models, cam, rob, z_near, z_far, origins, directions, ray_index, ref, ref64)}
             out["parity_on_bench_frame"]["all_ok"] = all(r["ok"] for k, v in out["parity_on_bench_frame"].items()
                                                          if isinstance(v, dict) for r in v.values())
-        import ctypes
-        ctypes.CDLL(None).fflush(None)  # anything native libraries buffered on stdout goes out BEFORE the JSON line
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+            out["parity_on_bench_frame"]["headline_truth_ok"] = all(
+                r["truth"]["truth_ok"] for r in out["parity_on_bench_frame"][precision].values())
+        emit(out, args.gpus)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -135,6 +135,17 @@ class _HoistCache:
         return self.gmap
 
 
+def _map_of(net, features, action=None):
+    """(hoisted map, first channel of `net`'s block in it) for a point query: the frame's JOINT map when the owning Model
+    has one for these features (``net.joint_source``, set by Model.__init__), else the network's own map."""
+    source = getattr(net, "joint_source", None)
+    # (flow_mlp adds a per-image action bias to its block: it never shares a map -- Model._joint_hoist returns None for it)
+    hit = source(features) if source is not None else None
+    if hit is not None:
+        return hit
+    return (net.hoisted_map(features) if action is None else net.hoisted_map(features, action)), 0
+
+
 _ZEROS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -198,10 +209,10 @@ class DensityDecoderMlp(nn.Module):
         """[B,R,S,3] world points -> density [B,R,S,1]  (density_decoder.py:45-71)."""
         b, r, s = world_space_xyz.shape[:3]
         w, bias = self.packed()
-        fmap = hip.make_feature_map(self.hoisted_map(pixel_encoding.features))
+        gmap, base = _map_of(self, pixel_encoding.features)
         out = torch.empty(b, r, s, 1, dtype=torch.float32, device=world_space_xyz.device)
         xyz = world_space_xyz.reshape(b, r * s, 3).contiguous()
-        hip.points_forward(xyz, None, _cameras(pixel_encoding, False), fmap, 0, 0, 0, w, bias, density=out,
+        hip.points_forward(xyz, None, _cameras(pixel_encoding, False), hip.make_feature_map(gmap), base, base, 0, w, bias, density=out,
                            precision=self.precision)
         return out
 
@@ -332,7 +343,8 @@ class ActionDecoderJacobian(ActionDecoder):
         b, n = xyz_flat.shape[:2]
         dev = xyz_flat.device
         w, bd, bc, bj = self.packed()
-        fmap = hip.make_feature_map(self.hoisted_map(enc.features, enc.action))
+        gmap, base = _map_of(self, enc.features, enc.action)
+        fmap = hip.make_feature_map(gmap)
         f32 = dict(dtype=torch.float32, device=dev)
         out = {"density": torch.empty(b, n, 1, **f32)}
         if want.get("color"):
@@ -346,7 +358,7 @@ class ActionDecoderJacobian(ActionDecoder):
         hip.points_forward(xyz_flat.contiguous(), None if dirs_flat is None else dirs_flat.contiguous(),
                            _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.kernel_action_dim,
                                     action=self.kernel_action(enc.action)), fmap,
-                           self.GOFF_DENSITY, self.GOFF_JACOBIAN, 1, w, bd, bc, bj,
+                           base + self.GOFF_DENSITY, base + self.GOFF_JACOBIAN, 1, w, bd, bc, bj,
                            jacobian_kind=self.JACOBIAN_KIND if with_jacobian else hip.JACOBIAN_NONE,
                            precision=self.precision, jacobian_precision=self.j_precision, **out)
         return out

@@ -127,6 +127,13 @@ class Model(nn.Module):
         self.proposal_networks = nn.ModuleList(
             [get_density_decoder(cfg.density_decoder, encoder_dim=self.encoder.get_output_dim()) for _ in range(n_prop)])
         self.density_fns = [net.get_density for net in self.proposal_networks]
+        # point queries of a network read its channel range of the frame's joint hoisted map when there is one
+        # (plain attributes holding a bound method of a weak proxy: the networks must not own the model)
+        import weakref
+        me = weakref.proxy(self)
+        for i, net in enumerate(self.proposal_networks):
+            net.joint_source = (lambda f, i=i: (lambda j: None if j is None else (j[0], j[1][i]))(me._joint_lookup(f)))
+        self.decoder.joint_source = lambda f: (lambda j: None if j is None else (j[0], j[2]))(me._joint_lookup(f))
         r = cfg.rendering
         update_schedule = lambda step: np.clip(np.interp(step, [0, r.proposal_warmup], [0, r.proposal_update_every]), 1,
                                                r.proposal_update_every)
@@ -147,6 +154,7 @@ class Model(nn.Module):
         # per-workgroup partials of the frame-level reductions and the depth clip is deferred to njf_assemble_frame.
         self.frame_io: Optional[Dict[str, torch.Tensor]] = None
         self._inverse_cache: Dict[str, tuple] = {}
+        self.inverse_cache_enabled = True
         self._joint: Dict[str, object] = {"features": None}   # ONE per-image projection for all networks of a frame (_joint_hoist)
         self.auto_range_check = True
         self.range_check_interval = 100
@@ -193,6 +201,11 @@ class Model(nn.Module):
     def _inverse(self, name: str, m: torch.Tensor) -> torch.Tensor:
         """hip.inverse(m), kept while ``m`` is the same tensor object at the same version (a camera rig that does not move
         costs no launch per forward pass; the cache holds a reference to ``m``, so its address cannot be recycled)."""
+        if not self.inverse_cache_enabled:
+            # a step that is being recorded into a HIP graph (parallel.ShardedFrameStep.capture, warm-up included) must
+            # LAUNCH its inverses: the graph's static camera tensors are refilled in place between replays, and an inverse
+            # served from the cache would be baked into the graph as a constant (ADVICE r03)
+            return hip.inverse(m)
         hit = self._inverse_cache.get(name)
         if hit is not None and hit[0] is m and hit[1] == m._version:
             return hit[2]
@@ -244,6 +257,22 @@ class Model(nn.Module):
             else:
                 hip.project_features(features.contiguous(), c["wz"], c["bz"], gmap, precision=self.decoder.precision)
             c["features"], c["key"], c["gmap"] = features, key, gmap
+        return c["gmap"], c["bases"][:-1], c["bases"][-1]
+
+    def _joint_lookup(self, features):
+        """The joint map of `features` IF one is already there (never projects): (map, [proposal bases], decoder base) or
+        None.  Point queries (decoder.forward / compute_density / get_density) and renders at given bins read their channel
+        range of it instead of projecting a map of their own next to it (a second per-image projection and a
+        duplicate map when forward and compute_density were mixed on one image)."""
+        c = self._joint
+        if c.get("features") is not features or features is None or "wkey" not in c:
+            return None
+        nets = [*self.proposal_networks, self.decoder]
+        for n in nets:
+            n.packed()
+        versions = tuple(n._packed_version for n in nets)
+        if c["wkey"] != versions or c.get("key") != (features._version, tuple(features.shape), versions):
+            return None
         return c["gmap"], c["bases"][:-1], c["bases"][-1]
 
     def set_precision(self, precision: str, proposal_precision: Optional[str] = None,
@@ -421,7 +450,9 @@ class Model(nn.Module):
         ray_bundle = self.compute_ray_bundle(rendering_input)
         self.proposal_sampler.train(self.training)
         proposal_dumps = [] if dump_perception else None
-        joint = self._joint_hoist(features)
+        # one projection for all networks of the frame; a render at GIVEN bins runs no proposal level, so it only reads a
+        # joint map that already exists and otherwise projects the decoder's channels alone
+        joint = self._joint_hoist(features) if final_bins is None else self._joint_lookup(features)
         joint_fmap = None if joint is None else hip.make_feature_map(joint[0])
         if final_bins is None:
             bins, weights_list, bins_list = self.proposal_sampler.generate_ray_samples_fused(

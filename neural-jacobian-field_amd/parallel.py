@@ -132,6 +132,9 @@ class ShardedFrameStep:
                    "trgt_rgb": self.trgt_rgb, "trgt_flow": self.trgt_flow}
         self.rgb_scale = 1.0 / float(batch * frame_rays * 3)
         self.flow_scale = 0.01 / float(batch * frame_rays * 2)
+        self._neutral = torch.tensor([3.0e38, -3.0e38, 0.0, 0.0], **f32)   # the record of a rank without rays, uploaded once
+        self.partials[:, 0], self.partials[:, 1] = 3.0e38, -3.0e38         # neutral until the first forward pass writes them
+        self.partials[:, 2:] = 0.0
         self._graph = None
         self._static = None
         # True: every step renders a NEW image -- the per-image lin_z projection runs (and is captured) in every step instead
@@ -149,7 +152,7 @@ class ShardedFrameStep:
     def local(self, camera_input, rendering_input, robot_input):
         """The rank-local part: Model.forward on the shard + the fold of its partials into the packet's record."""
         if self.hi == self.lo:   # a rank without rays (more ranks than rays): neutral record, nothing to render
-            self.record.copy_(torch.tensor([3.0e38, -3.0e38, 0.0, 0.0], device=self.record.device))
+            self.record.copy_(self._neutral)    # device-to-device: no host copy per step, capturable
             return None
         m = self.model
         if self.new_image_each_step:
@@ -157,7 +160,10 @@ class ShardedFrameStep:
         prev = m.frame_io
         m.frame_io = self.io
         try:
-            out = m.forward(camera_input, rendering_input, robot_input)
+            # the packet views are only written by the INFERENCE path of Model.forward (the training paths return autograd
+            # outputs and ignore frame_io): a model with trainable parameters would otherwise leave the packet unwritten
+            with torch.no_grad():
+                out = m.forward(camera_input, rendering_input, robot_input)
         finally:
             m.frame_io = prev
         self._reduce(self.partials, self.record)
@@ -176,25 +182,45 @@ class ShardedFrameStep:
     # ---- the step ----------------------------------------------------------------------------------------------------
     def capture(self, camera_input, rendering_input, robot_input, warmup: int = 2) -> None:
         """Record ``local`` into a HIP graph (the C-ABI launches are plain stream work).  The input tensors of this call
-        become the step's static inputs: refill them in place (``.copy_``) between steps."""
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.local(camera_input, rendering_input, robot_input)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        self._static = (camera_input, rendering_input, robot_input)
-        self._graph = torch.cuda.CUDAGraph()
-        # with a process group alive, its watchdog thread polls events while this thread captures: only calls of the
-        # capturing thread itself may invalidate the capture
-        mode = "thread_local" if dist.is_initialized() else "global"
-        with torch.cuda.graph(self._graph, capture_error_mode=mode):
-            self._out = self.local(camera_input, rendering_input, robot_input)
+        become the step's static inputs: refill them in place (``.copy_``) between steps -- rays, cameras, command, feature
+        map alike.  Everything derived from them is recomputed by the replay: the camera inverses are launched INSIDE the
+        graph (the model's per-tensor inverse cache is switched off for warm-up and capture, and emptied), and the per-image
+        projection is part of the graph when ``new_image_each_step`` is set."""
+        m = self.model
+        cached = getattr(m, "inverse_cache_enabled", None)
+        if cached is not None:
+            m.inverse_cache_enabled = False
+            m._inverse_cache.clear()
+        try:
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.local(camera_input, rendering_input, robot_input)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._static = (camera_input, rendering_input, robot_input)
+            self._graph = torch.cuda.CUDAGraph()
+            # with a process group alive, its watchdog thread polls events while this thread captures: only calls of the
+            # capturing thread itself may invalidate the capture
+            mode = "thread_local" if dist.is_initialized() else "global"
+            with torch.cuda.graph(self._graph, capture_error_mode=mode):
+                self._out = self.local(camera_input, rendering_input, robot_input)
+        finally:
+            if cached is not None:
+                m.inverse_cache_enabled = cached
 
     def __call__(self, camera_input=None, rendering_input=None, robot_input=None):
         """-> (frame [B,R,6], scalars [6] = (t_min, t_max, S_rgb, S_flow, loss/rgb, loss/flow_loss), the rank's ModelOutput
-        whose depth is NOT clipped -- the clipped depth of the whole frame is frame[..., 3])."""
+        whose depth is NOT clipped -- the clipped depth of the whole frame is frame[..., 3]).
+
+        After ``capture()`` the step replays the recorded launches on the STATIC inputs of the capture call; new inputs are
+        given by refilling those tensors in place.  Arguments are then accepted only if they ARE the static objects (or
+        omitted) -- anything else would be silently ignored, so it raises."""
         if self._graph is not None:
+            for given, static in zip((camera_input, rendering_input, robot_input), self._static):
+                if given is not None and given is not static:
+                    raise ValueError("ShardedFrameStep was captured: refill the static inputs of capture() in place (.copy_) "
+                                     "instead of passing new input objects")
             self._graph.replay()
             out = self._out
         else:

@@ -213,3 +213,28 @@ def synthetic_action(batch: int, action_dim: int, seed: int = 2) -> torch.Tensor
     g = torch.Generator()
     g.manual_seed(seed)
     return 0.1 * torch.randn((batch, action_dim), generator=g)
+
+
+def synthetic_training_batch(batch: int, height: int, width: int, rays: int, action_dim: int, seed: int, device) -> Dict[str, torch.Tensor]:
+    """One training batch of the reference's shape (``configurations/config.yaml:18-20``: 7 scenes x 256 random pixels,
+    the SAME pixel set for every scene, ``models/model_wrapper.py:438-444``) on ``device``: context images, cameras, the
+    rays of the selected target pixels (the HIP ray-generation kernel), a command per scene and random targets.  Every
+    value depends only on the arguments -- rank r of a data-parallel job passes ``seed = r`` and so owns its scenes."""
+    from . import geometry
+
+    g = torch.Generator().manual_seed(seed * 7919 + 17)
+    cams = {k: v.to(device) for k, v in synthetic_cameras(batch).items()}
+    sel = torch.randperm(height * width, generator=g)[:rays]
+    coords, _ = geometry.get_pixel_coordinates(height, width)
+    xy = coords.reshape(1, -1, 2)[:, sel].repeat(batch, 1, 1).contiguous().to(device)
+    origins, directions, _ = geometry.get_world_rays_with_z(xy, cams["trgt_k_norm"], cams["trgt_c2w"])
+    return {
+        "image": torch.rand(batch, 3, height, width, generator=g).to(device),
+        "ctxt_c2w": cams["ctxt_c2w"], "ctxt_k_norm": cams["ctxt_k_norm"], "trgt_c2w": cams["trgt_c2w"],
+        "trgt_k_pix": geometry.denormalize_intrinsics(cams["trgt_k_norm"], width, height),
+        "z_near": cams["z_near"], "z_far": cams["z_far"], "origins": origins, "directions": directions,
+        "action": synthetic_action(batch, action_dim, seed + 2).to(device),
+        "target_rgb": torch.rand(batch, rays, 3, generator=g).to(device),
+        "target_depth": (torch.rand(batch, rays, 1, generator=g) + 0.5).to(device),
+        "target_flow": torch.randn(batch, rays, 2, generator=g).to(device),
+    }

@@ -31,6 +31,10 @@ def pytest_collection_modifyitems(config, items):
 # {case, key, err, floor, limit} and asserts err <= max(tol, 2 x floor).  The floor is the REFERENCE's own fp32-vs-fp64
 # difference for that quantity (tests/golden/*_f64.npz, harness_reference.npz).  The table is written at session end.
 _MARGIN_ROWS = []
+# truth-referenced, element-wise rows (round 4, oracle/parity_harness.py::truth_columns): e_hip = |hip - ref64| against
+# e_ref = |ref32 - ref64| per compared tensor -- recorded for every comparison that has a float64 partner, ASSERTED where
+# the caller says so (the exact-fp32-product mode)
+_TRUTH_ROWS = []
 SELF_NOISE_CEILING = 5e-3   # no parity limit is looser than this, whatever the reference's self-noise
 
 
@@ -42,7 +46,8 @@ def _rel(a, b):
 
 @pytest.fixture(scope="session")
 def margins():
-    def check(case, key, got, ref32, ref64=None, tol=1e-4, floor=None, self_noise=(), floor_fp64=None, ceiling=None):
+    def check(case, key, got, ref32, ref64=None, tol=1e-4, floor=None, self_noise=(), floor_fp64=None, ceiling=None,
+              truth_assert=False):
         """assert rel(got, ref32) <= max(tol, 2 * floor_fp64), floor_fp64 = rel(ref32, ref64): the reference's fp32 run
         against its float64 run (or the explicit ``floor_fp64`` / ``floor``).  Only where that fails are the `self_noise`
         figures consulted -- how far the reference's OWN fp32 output moves when its inputs move by what no fp32
@@ -55,6 +60,13 @@ def margins():
         proposal weights into a 5 % difference of their upstream gradient (tools/diag/diag_perception.py); north_star's
         tolerance is about outputs, so these rows are reported against their floors rather than failed on them."""
         err = _rel(got, ref32)
+        truth_failure = None
+        if ref64 is not None:
+            import parity_harness as ph
+            cols = ph.truth_columns(got, ref32, ref64, tol)
+            _TRUTH_ROWS.append({"case": case, "key": key, **cols, "asserted": bool(truth_assert)})
+            if truth_assert and not cols["truth_ok"]:
+                truth_failure = {"case": case, "key": key, **cols}
         if floor is None:
             floor = _rel(ref32, ref64) if ref64 is not None else 0.0
         floor64 = floor if floor_fp64 is None else float(floor_fp64)
@@ -77,18 +89,25 @@ def margins():
         _MARGIN_ROWS.append(row)
         if not err <= limit:   # (raised by hand: the payload stays a dict for callers that collect several failures)
             raise AssertionError({"case": case, "key": key, "err": err, "floor_fp64": floor64, "self_noise": noise, "limit": limit})
+        if truth_failure is not None:
+            raise AssertionError({"truth-referenced criterion failed": truth_failure})
         return err
 
     def record(case, rows):
         for r in rows:
             _MARGIN_ROWS.append({"case": case, **r})
 
+    def record_truth(case, rows, asserted=False):
+        for r in rows:
+            _TRUTH_ROWS.append({"case": case, **r, "asserted": bool(asserted)})
+
     check.record = record
+    check.record_truth = record_truth
     return check
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if not _MARGIN_ROWS:
+    if not _MARGIN_ROWS and not _TRUTH_ROWS:
         return
     import json
 
@@ -107,7 +126,15 @@ def pytest_sessionfinish(session, exitstatus):
                "rows_on_self_noise_floor": sum(bool(r.get("self_noise_floor_used")) for r in _MARGIN_ROWS),
                "gradient_rows_beyond_twice_their_floors (passed on the fixed gradient ceiling, see DESIGN.md section 5)":
                    sum(bool(r.get("beyond_floors")) for r in _MARGIN_ROWS),
-               "failed": sum(not r["ok"] for r in _MARGIN_ROWS), "table": _MARGIN_ROWS}
+               "failed": sum(not r["ok"] for r in _MARGIN_ROWS), "table": _MARGIN_ROWS,
+               "truth_rule": "element-wise against the float64 result: e_hip = |hip - ref64|, e_ref = |ref32 - ref64| (ref = the "
+                             "reference's fixture tensors, else the oracle), both relative to max|ref64|; truth_ok <=> max e_hip <= "
+                             "max(1.5 x max e_ref, 4 fp32 ulps of scale) and the same for the 99.9th percentile; "
+                             "frac_within_1e-4_of_ref32 = share of elements with |hip - ref32| <= 1e-4 max|ref32|",
+               "truth_rows": len(_TRUTH_ROWS), "truth_rows_asserted": sum(r["asserted"] for r in _TRUTH_ROWS),
+               "truth_rows_not_ok": sum(not r["truth_ok"] for r in _TRUTH_ROWS),
+               "truth_rows_asserted_not_ok": sum(r["asserted"] and not r["truth_ok"] for r in _TRUTH_ROWS),
+               "truth_table": _TRUTH_ROWS}
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
         json.dump(summary, f, indent=0)

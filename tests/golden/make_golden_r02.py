@@ -339,6 +339,10 @@ def harness_reference(build, mlp_dec, ref_model, PixelEncoding, only=None):
         pre = f"c{i}."
         for k in ("rgb", "depth", "optical_flow", "bins"):
             arrays[pre + k] = r32[k]
+        # round 4 (VERDICT r03 "next" #3): the float64 run's end-to-end outputs THEMSELVES, so that the GPU tests can hold the
+        # HIP path to the truth element by element: e_hip = |hip - ref64| against e_ref = |ref32 - ref64|
+        for k in ("rgb", "depth", "optical_flow", "bins"):
+            arrays[pre + k + "64"] = r64[k]
         # the exact inputs of this run: derived quantities (normalised directions, matrix exponentials, inverses) can differ
         # by an ulp between CPUs, and the positional encoding turns one ulp of a ray direction into ~1e-4 of depth -- the
         # harness feeds THESE tensors to the oracle and to the HIP path on the GPU box

@@ -241,60 +241,17 @@ def test_ray_sharding_world_size_2_gloo(tmp_path):
     assert all(open(os.path.join(tmp_path, f"ok{r}")).read() == "True" for r in range(2))
 
 
-class _FakeShardModel:
-    """Stands in for Model in the layout test of parallel.ShardedFrameStep: `forward` fills the buffers the step handed over
-    (frame_io) with this rank's slice of a known frame and with the per-group partials the render kernel's epilogue writes."""
-
-    def __init__(self, frame_rgb, frame_depth, frame_flow, tmin, tmax, lo, hi):
-        self.frame_io = None
-        self.args = (frame_rgb, frame_depth, frame_flow, tmin, tmax, lo, hi)
-
-    def forward(self, cam, rin, rob):
-        rgb, depth, flow, tmin, tmax, lo, hi = self.args
-        io = self.frame_io
-        io["rgb"].copy_(rgb[:, lo:hi])
-        io["depth"].copy_(depth[:, lo:hi])
-        io["flow"].copy_(flow[:, lo:hi])
-        b, n = rgb.shape[0], hi - lo
-        flat = lambda t: t[:, lo:hi].reshape(b * n, -1)
-        se_rgb = ((flat(rgb) - io["trgt_rgb"].reshape(b * n, 3)) ** 2).sum(-1)
-        se_flow = ((flat(flow) - io["trgt_flow"].reshape(b * n, 2)) ** 2).sum(-1)
-        groups = io["frame_partials"].shape[0]
-        pad = groups * 4 - b * n
-        grp = lambda v, fill: torch.cat([v, torch.full((pad,), fill)]).view(groups, 4)
-        io["frame_partials"][:, 0] = grp(flat(tmin)[:, 0], 3.0e38).min(-1).values
-        io["frame_partials"][:, 1] = grp(flat(tmax)[:, 0], -3.0e38).max(-1).values
-        io["frame_partials"][:, 2] = grp(se_rgb, 0.0).sum(-1)
-        io["frame_partials"][:, 3] = grp(se_flow, 0.0).sum(-1)
-        return "out"
-
-
 def _frame_step_worker(rank, world, port, tmp):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import frame_reference as fr
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frame_standins
     from neural_jacobian_field_amd import parallel as par
-    g = torch.Generator().manual_seed(1)
-    B, R = 2, 101                                    # ragged: 51 + 50 rays
-    rgb, trg = torch.rand(B, R, 3, generator=g), torch.rand(B, R, 3, generator=g)
-    flow, tflow = torch.randn(B, R, 2, generator=g), torch.randn(B, R, 2, generator=g)
-    depth = torch.rand(B, R, 1, generator=g) * 12
-    tmin, tmax = torch.rand(B, R, 1, generator=g) + 0.5, torch.rand(B, R, 1, generator=g) + 9
-    lo, hi = par.shard_bounds(R, world, rank)
-    step = par.ShardedFrameStep(_FakeShardModel(rgb, depth, flow, tmin, tmax, lo, hi), B, R, "cpu",
-                                reduce_fn=fr.reduce_frame_partials, assemble_fn=fr.assemble_frame)
-    assert (step.lo, step.hi) == (lo, hi) and step.world == world
-    step.set_targets(trg[:, lo:hi], tflow[:, lo:hi])
+    step, check = frame_standins.make_frame_step(par, world, rank)     # B = 2, R = 101: ragged, 51 + 50 rays
     frame, scalars, out = step(None, None, None)
-    ref_depth = torch.clip(depth, tmin.min(), tmax.max())
-    ok = (out == "out" and torch.equal(frame[..., 0:3], rgb) and torch.equal(frame[..., 3:4], ref_depth)
-          and torch.equal(frame[..., 4:6], flow)
-          and abs(scalars[4] - torch.nn.functional.mse_loss(rgb, trg)) < 1e-6
-          and abs(scalars[5] - 0.01 * torch.nn.functional.mse_loss(flow, tflow)) < 1e-6
-          and scalars[0] == tmin.min() and scalars[1] == tmax.max())
+    ok = out == "out" and check(frame, scalars)
     # a second step reuses every buffer (nothing is reallocated) and reproduces the first
     ptr = step.frame.data_ptr()
     frame2, scalars2, _ = step(None, None, None)
@@ -312,6 +269,67 @@ def test_sharded_frame_step_world_size_2_gloo(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_frame_step_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(open(os.path.join(tmp_path, f"fs{r}")).read() == "True" for r in range(2))
+
+
+def _run_bench(argv, env_extra=None, script="bench.py"):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, script), *argv], env=env, capture_output=True, text=True, timeout=600)
+
+
+def _json_lines(text):
+    rows = []
+    for line in text.splitlines():
+        if line.startswith("{"):
+            try:
+                rows.append(json.loads(line))
+            except ValueError:
+                pass
+    return rows
+
+
+def test_bench_self_launches_its_ranks_under_gloo():
+    """`python bench.py --gpus 2` as a PLAIN process (no torchrun, no WORLD_SIZE) must spawn two ranks itself and print ONE
+    line whose n_gpus is 2, with the evidence that two ranks really exchanged data: backend, world size, one device record
+    per rank (distinct pids), per-rank step times (VERDICT r03 "next" #1).  Driven without a GPU through --dry-launch: gloo,
+    parallel.ShardedFrameStep on CPU tensors with the stand-in kernels of tests/frame_standins.py -- the launcher, the world
+    check, the barriers, the max over ranks, the evidence and the line gate are bench.py's own code."""
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch", os.path.join(ROOT, "tests", "frame_standins.py")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = _json_lines(r.stdout)
+    assert len(rows) == 1, r.stdout
+    line = rows[0]
+    assert line["n_gpus"] == 2 and line["dry_launch"] is True and line["value"] is None and line["frame_ok"] is True
+    ev = line["rccl"]
+    assert ev["backend"] == "gloo" and ev["world_size"] == 2 and ev["self_launched"] is True
+    assert [d["rank"] for d in ev["devices"]] == [0, 1] and len({d["pid"] for d in ev["devices"]}) == 2
+    assert len(ev["rank_step_ms"]["per_rank"]) == 2 and ev["rank_step_ms"]["max"] >= ev["rank_step_ms"]["min"] > 0
+
+
+def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
+    """The case that used to print a one-GPU line for --gpus 8: a launcher environment with WORLD_SIZE=1.  Now: no JSON
+    line, non-zero exit.  Same for a GPU run asked for more devices than are visible (none here)."""
+    standins = os.path.join(ROOT, "tests", "frame_standins.py")
+    r = _run_bench(["--gpus", "8", "--dry-launch", standins], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not _json_lines(r.stdout) and "WORLD_SIZE is 1" in r.stderr
+    r = _run_bench(["--gpus", "2", "--dry-launch", standins], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not _json_lines(r.stdout)
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "8"])
+        assert r.returncode != 0 and not _json_lines(r.stdout) and "GPU(s) are visible" in r.stderr
+
+
+def test_line_gate_and_rank_evidence():
+    """launch.check_line / launch.rank_evidence: a line whose n_gpus or evidence disagrees with --gpus is refused; a world
+    of one without a process group still yields a well-formed record."""
+    from neural_jacobian_field_amd import launch
+    ev = launch.rank_evidence(None, torch.device("cpu"), 1.25)
+    assert ev["world_size"] == 1 and ev["devices"][0]["rank"] == 0 and ev["rank_step_ms"]["per_rank"] == [1.25]
+    assert launch.check_line({"n_gpus": 1, "rccl": ev}, 1)["n_gpus"] == 1
+    with pytest.raises(SystemExit):
+        launch.check_line({"n_gpus": 1, "rccl": ev}, 8)
+    with pytest.raises(SystemExit):
+        launch.check_line({"n_gpus": 8, "rccl": ev}, 8)
 
 
 def _synthetic_linearization(device="cpu"):

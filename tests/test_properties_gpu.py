@@ -404,6 +404,20 @@ def test_joint_hoist_equals_the_per_network_maps(dev):
         b = model.forward(cam, rin, rob).standard_output
         del model._joint_hoist
         assert torch.equal(a.rgb, b.rgb) and torch.equal(a.depth, b.depth) and torch.equal(a.optical_flow, b.optical_flow)
+        # point queries on the image of a frame read THEIR channel range of the frame's joint map -- no second projection,
+        # no duplicate map -- and return bit for bit what they return from a map of their own
+        from neural_jacobian_field_amd.decoder import PixelEncoding
+        enc = PixelEncoding(feats, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(case["action"]))
+        xyz = (torch.rand(2, 5, 7, 3, generator=g) * torch.tensor([1.0, 1.0, 2.0]) + torch.tensor([-0.5, -0.5, 1.0])).to(dev)
+        own = (model.compute_density(xyz.reshape(2, 35, 3), enc)[0].density, model.proposal_networks[1].get_density(xyz, enc))
+        model.reset_image_cache()
+        for net in (model.decoder, *model.proposal_networks):
+            net._hoist.gmap = net._hoist.features = None
+        model.forward(cam, rin, rob)                                   # the frame: ONE joint projection
+        assert model._joint_lookup(feats) is not None
+        shared = (model.compute_density(xyz.reshape(2, 35, 3), enc)[0].density, model.proposal_networks[1].get_density(xyz, enc))
+        assert all(net._hoist.gmap is None for net in (model.decoder, *model.proposal_networks))   # nothing projected again
+        assert torch.equal(own[0], shared[0]) and torch.equal(own[1], shared[1])
 
 
 def test_sharded_frame_step_equals_the_unsharded_forward(dev):
@@ -470,6 +484,22 @@ def test_sharded_frame_step_equals_the_unsharded_forward(dev):
     f2, s2, _ = one()
     torch.cuda.synchronize()
     assert torch.equal(f2, f1) and torch.equal(s2, s1)
+    # capture()'s contract: the static inputs are refilled IN PLACE between replays.  Moving both cameras must change the
+    # replayed frame exactly as it changes an eager step -- the camera inverses are launched inside the graph, not served
+    # from Model's per-tensor cache filled during the warm-up (a stale w2c rendered a silently wrong frame)
+    f2, s2 = f2.clone(), s2.clone()
+    cam.trgt_extrinsics.copy_(cam.trgt_extrinsics @ d(ph.general_pose(41, B, scale=0.05)))
+    cam.ctxt_extrinsics.copy_(cam.ctxt_extrinsics @ d(ph.general_pose(42, B, scale=0.02)))
+    f3, s3, _ = one()
+    f3, s3 = f3.clone(), s3.clone()
+    eager = parallel.ShardedFrameStep(model, B, R, dev, world_size=1, rank=0)
+    eager.set_targets(trgt_rgb, trgt_flow)
+    f4, s4, _ = eager(cam, rin, rob)
+    torch.cuda.synchronize()
+    assert not torch.equal(f3[..., 0:3], f2[..., 0:3]) and not torch.equal(f3[..., 4:6], f2[..., 4:6])
+    assert torch.equal(f3, f4) and torch.equal(s3, s4)
+    with pytest.raises(ValueError, match="captured"):      # new input OBJECTS would be silently ignored by a replay: refused
+        one(cam, RenderingInput(o.clone(), dr, d(c["z_near"]), d(c["z_far"])), rob)
 
 
 # ---- BASELINE config 5 at its full size: 512 x 512 rays, F = [1,512,256,256], A = 6 --------------------------------------

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-4 measurement sweep (GPU box, one gpurun call per step list, from the repo root).
+#   bash tools/measure_r04.sh <step> [<step> ...]
+# Outputs land in gpurun_out/measure_r04/; the ones that are evidence are copied to profiles/r04_* by hand.
+cd "$(dirname "$0")/.."
+O=gpurun_out/measure_r04; mkdir -p $O
+for STEP in "$@"; do
+case $STEP in
+probe)     # VERDICT r03 "next" #4: MFMA || VALU co-issue on one SIMD
+  timeout 120 build/probe_coissue > $O/probe_coissue.txt 2>&1; echo "probe rc=$?"; cat $O/probe_coissue.txt ;;
+tests)
+  NJF_MARGINS_OUT=$PWD/$O/r04_parity_margins.json timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
+  echo "pytest rc=$?"; tail -5 $O/pytest_gpu.txt ;;
+bench)
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 2500 $O/bench.json ;;
+dist)      # the N > 1 code on ONE GPU: RCCL initialised with a single rank (collective for real), eager and graph
+  for extra in "" "--graph"; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-dist $extra 2>>$O/dist.err | tail -1 > $O/force_dist${extra:+_graph}.json
+    python -c "import sys,json; d=json.load(open('$O/force_dist${extra:+_graph}.json')); print('force-dist $extra', d['ms_per_step'], d['value_default_precision']['ms_per_step'], d['rccl']['backend'], d['rccl']['devices'][0].get('pci_bus_id'), d['rccl']['rank_step_ms'])"
+  done
+  for n in 2 4 8; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --simulate-world $n --graph 2>>$O/dist.err | tail -1
+  done > $O/simulate_world.txt
+  python - <<PY
+import json
+for l in open('$O/simulate_world.txt'):
+    d = json.loads(l); print('sim', d['config']['rays_per_gpu'], d['ms_per_step'], d['value_default_precision']['ms_per_step'], d['kernel_ms'])
+PY
+  ;;
+train)
+  for m in action perception; do
+    NJF_PROFILE=1 timeout 600 python tools/bench_train.py --mode $m --force-dist > $O/train_$m.json 2> $O/train_$m.txt; echo "train $m rc=$?"
+    tail -1 $O/train_$m.json | cut -c1-600; tail -20 $O/train_$m.txt
+  done ;;
+configs)
+  for a in "--batch 4 --samples 128" "--height 512 --width 512" "--samples 256" "--samples 32"; do
+    echo "ARGS $a"; python bench.py --steps 5 --warmup 2 --no-cpu-baseline $a 2>/dev/null | tail -1
+  done > $O/configs.txt ;;
+stream)
+  timeout 300 python tools/stream_kernels.py --json $O/stream_hip_events.json > $O/stream_hip_events.txt 2>&1; tail -12 $O/stream_hip_events.txt ;;
+profile)   # rocprofv3 kernel stats + PMC passes of the default bench, headline (f32) and default-precision (f16f6) modes
+  for p in f32 f16f6; do bash tools/profile_r04.sh $p > $O/profile_$p.log 2>&1; done
+  ls gpurun_out/prof_r04_f32 gpurun_out/prof_r04_f16f6 ;;
+*) echo "unknown step $STEP" ;;
+esac
+done
