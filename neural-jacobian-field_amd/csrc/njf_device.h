@@ -133,6 +133,9 @@ __device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
   // may touch LDS is outstanding hipcc's wait-count pass turns EVERY s_waitcnt into lgkmcnt(0)/vmcnt(0) -- the
   // A-fragment prefetch of mma_chunk (ds_reads of unit u+1 issued before the MFMAs of unit u) then waits for the
   // loads it has just issued.  With the buffer form the waits are exact (lgkmcnt(4)).
+#ifdef NJF_ABLATE_DMA  // experiment builds only: no L2 -> LDS weight traffic (weights stay whatever is in LDS; results are garbage)
+  return;
+#endif
   __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (__attribute__((address_space(3))) void*)(st.dma_dst + r * NJF_THREADS * 4),
                                            16, st.dma_voff, st.dma_soff + r * NJF_THREADS * 16, 0, 0);
 }

@@ -1028,6 +1028,21 @@ __device__ __forceinline__ void load_bias_block(const float* __restrict__ src, i
   for (int i = threadIdx.x; i < n; i += NJF_THREADS) njf_lds[LDS_BIAS + dst_off + i] = src[i];
 }
 
+// alpha = 1 - exp(-ds), ds >= 0 (ray_samplers.py:93-95), WITHOUT the cancellation of the literal form.  In fp32
+// `1 - exp(-ds)` is a multiple of 2^-24 whatever its size, so a sample in nearly empty space (ds ~ 1e-6) carries its weight
+// with 5-25 % relative error -- in the reference too -- and two correct exp implementations (device libm here, Sleef in
+// torch's CPU path) that round exp(-ds) to different neighbours disagree by a whole quantum.  Harmless for the composited
+// pixels (sums dominated by large weights), but the ds-nerf depth loss differentiates log(w + 1e-7) (utils/loss_utils.py:
+// 9-35): its upstream gradient 1 / (w + 1e-7) is LARGEST exactly on those weights, and the one-quantum disagreement was the
+// 2.3-2.9e-3 deviation of every proposal-net gradient from the oracle (tools/diag/diag_perception.py, round 4; same in exact
+// fp32 and split precision).  Evaluated accurately -- Taylor to x^5 below 2^-4 (truncation 1.3e-9 relative), the literal form
+// above it (relative error <= 1e-6) -- the weights follow the float64 result instead of a rounding accident, and the
+// gradients fall inside twice the oracle's own fp32-vs-float64 floors.
+__device__ __forceinline__ float alpha_of(float ds) {
+  const float series = ds * fmaf(-0.5f * ds, fmaf(-(1.0f / 3.0f) * ds, fmaf(-0.25f * ds, fmaf(-0.2f, ds, 1.0f), 1.0f), 1.0f), 1.0f);
+  return ds < 0.0625f ? series : 1.0f - expf(-ds);
+}
+
 // alpha compositing weights of one 32-sample tile (ray_samplers.py:77-101), carrying the running
 // optical depth across tiles.
 __device__ __forceinline__ float tile_weights(float delta, float sigma, bool valid, int j, float& carry) {
@@ -1037,8 +1052,7 @@ __device__ __forceinline__ float tile_weights(float delta, float sigma, bool val
   if (j == 0) excl = 0.f;
   excl += carry;
   carry += __shfl(incl, 31, 32);
-  const float alpha = 1.0f - expf(-ds);
-  return alpha * expf(-excl);
+  return alpha_of(ds) * expf(-excl);
 }
 
 // inverse-CDF resampling of one ray (ray_samplers.py:351-451).  w' (already annealed, +padding not
@@ -2374,7 +2388,7 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArg
     const float incl = wave_incl_scan(ds, lane);
     if (lane == 0) tile_start[wv][t] = carry;
     if (need_depth) {
-      const float w = (1.0f - expf(-ds)) * expf(-(carry + incl - ds));
+      const float w = alpha_of(ds) * expf(-(carry + incl - ds));
       sum_w += valid ? w : 0.f;
       sum_wt += valid ? w * a.steps[base + s] : 0.f;
     }
@@ -2404,7 +2418,7 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArg
     const float incl = wave_incl_scan(ds, lane);
     const float before = tile_start[wv][t];             // optical depth in front of this tile
     const float t_next = expf(-(before + incl));        // T_{s+1}
-    const float w = (1.0f - expf(-ds)) * expf(-(before + incl - ds));
+    const float w = alpha_of(ds) * expf(-(before + incl - ds));
     float G = a.g_w ? (valid ? a.g_w[base + s] : 0.f) : 0.f;
     float c[3] = {0.f, 0.f, 0.f};
     if (a.color && valid) {

@@ -241,22 +241,49 @@ class ActionDecoderJacobian(ActionDecoder):
     parameters, its packed form and the width of its hoisted feature channels."""
 
     spatial_dim: int = 3
-    JACOBIAN_KIND = hip.JACOBIAN_NONE
-    J_W_FLOATS = 0
-    J_B_FLOATS = 0
-    J_HOIST = 0
+    # kind / packed sizes / hoisted channels of the subclass's OWN ("regular") Jacobian head; the properties below give those
+    # of the head that is active (switch_mode): the arm head is a ResnetFC in both decoders (action_decoder_jacobian.py:
+    # 306-313, 400-407), i.e. kind JACOBIAN_MLP with a 384-channel hoisted block
+    REGULAR = (hip.JACOBIAN_NONE, 0, 0, 0)
+    ARM = (hip.JACOBIAN_MLP, hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM)
     GOFF_DENSITY, GOFF_JACOBIAN = 0, hip.ZDIM
+
+    @property
+    def _active(self):
+        return self.ARM if self.mode == "arm" else self.REGULAR
+
+    @property
+    def JACOBIAN_KIND(self) -> int:
+        return self._active[0]
+
+    @property
+    def J_W_FLOATS(self) -> int:
+        return self._active[1]
+
+    @property
+    def J_B_FLOATS(self) -> int:
+        return self._active[2]
+
+    @property
+    def J_HOIST(self) -> int:
+        return self._active[3]
+
+    @property
+    def active_head_prefix(self) -> str:
+        """Parameter-name prefix (relative to the decoder) of the ResnetFC Jacobian head in use; '' when the active head is
+        not a single ResnetFC (the transformer decoder in regular mode)."""
+        if self.mode == "arm":
+            return "jacobian_head_arm."
+        return "jacobian_head." if isinstance(getattr(self, "jacobian_head", None), ResnetFC) else ""
 
     def _init_common(self, cfg, action_dim: int, encoder_dim: int, max_action: int):
         n_freq = cfg.num_frequncies if hasattr(cfg, "num_frequncies") else cfg.num_frequencies
         if n_freq != 10 or cfg.geometry_feature_dim != 15:
             raise ValueError("fused path supports num_frequencies=10 and geometry_feature_dim=15")
-        if cfg.use_arm_model:
-            raise NotImplementedError(
-                "use_arm_model (second Jacobian head, selected by switch_mode('arm')) is not part of the fused path: no "
-                "shipped config enables it, nothing in the reference calls switch_mode, and its compute_flow reshapes the arm "
-                "head's output with the REGULAR action_dim (action_decoder_jacobian.py:134-140), so it only runs when "
-                "arm_action_dim == action_dim")
+        arm = getattr(cfg, "use_arm_model", False)
+        if arm and not (cfg.arm_action_dim is not None and 1 <= cfg.arm_action_dim <= hip.MAX_ACTION_DIM):
+            raise ValueError(f"use_arm_model needs arm_action_dim in [1, {hip.MAX_ACTION_DIM}]")
+        self.arm_action_dim = cfg.arm_action_dim if arm else None
         if not (1 <= action_dim <= max_action):
             raise ValueError(f"action_dim must be in [1, {max_action}] for {cfg.name}")
         self.action_dim = action_dim
@@ -282,21 +309,47 @@ class ActionDecoderJacobian(ActionDecoder):
         return nn.Sequential(nn.Linear(cfg.geometry_feature_dim + 16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(),
                              nn.Linear(64, 3), nn.Sigmoid())
 
+    def _make_arm_head(self, cfg, encoder_dim: int) -> None:
+        """action_decoder_jacobian.py:306-313 / 400-407: the second Jacobian head, a ResnetFC(d_out = 3 * arm_action_dim),
+        registered as ``jacobian_head_arm`` (state-dict keys ``decoder.jacobian_head_arm.*``) when cfg.use_arm_model."""
+        if self.arm_action_dim is not None:
+            self.jacobian_head_arm = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim * self.arm_action_dim)
+            self.jacobian_head_arm.apply(initialize_jacobian_weights)
+
     def switch_mode(self, mode: str):
+        """action_decoder_jacobian.py:89-90.  ``"arm"`` routes compute_jacobian through ``jacobian_head_arm`` (:330-331,
+        :438-446); everything downstream is unchanged -- in particular compute_flow contracts the head's output with the
+        robot action viewed as (action_dim, 3) (:134-140), which is why the reference only runs in arm mode when
+        arm_action_dim == action_dim.  That condition is checked HERE (the reference fails later, inside einops)."""
+        if mode not in ("regular", "arm"):
+            raise ValueError(f"mode must be 'regular' or 'arm', not {mode!r}")
+        if mode == "arm":
+            if self.arm_action_dim is None:
+                raise AttributeError("switch_mode('arm'): this decoder was built without use_arm_model (no jacobian_head_arm)")
+            if self.arm_action_dim != self.action_dim:
+                raise ValueError(f"switch_mode('arm'): arm_action_dim = {self.arm_action_dim} but compute_flow contracts the head's "
+                                 f"output with the {self.action_dim}-dimensional robot action (action_decoder_jacobian.py:134-140)")
         self.mode = mode
 
     # ---- packed state ----------------------------------------------------------------
-    def _pack_jacobian(self, params, w_j, b_j, wz, bz):  # pragma: no cover - abstract
+    def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):  # pragma: no cover - abstract
         raise NotImplementedError
+
+    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+        if self.mode == "arm":
+            hip.pack_resnetfc(params, "jacobian_head_arm.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.j_precision)
+        else:
+            self._pack_regular_jacobian(params, w_j, b_j, wz, bz)
 
     def packed(self):
         """Packed weights, rebuilt PER SUB-NETWORK: an action-mode optimiser step only touches the Jacobian head
         (freeze_non_action_parameters), so the density and colour packs of the previous step stay valid."""
-        v = _version(self)
+        v = (self.mode,) + _version(self)
         if v != self._packed_version:
             dev = self.density_head.lin_in.weight.device
             n = hip.RESNET_W_FLOATS
-            fresh = self._packed_version is None or self._w.device != dev
+            # (a mode switch changes which head the Jacobian block holds -- and, for the transformer decoder, its size)
+            fresh = self._packed_version is None or self._w.device != dev or self._packed_version[0] != self.mode
             if fresh:
                 f32 = dict(dtype=torch.float32, device=dev)
                 self._w = torch.zeros(n + hip.COLOR_W_FLOATS + self.J_W_FLOATS, **f32)
@@ -310,7 +363,10 @@ class ActionDecoderJacobian(ActionDecoder):
             heads = ("density_head.", "color_head.")
             subs = {"density": (self.precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(heads[0])),
                     "color": (self.precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(heads[1])),
-                    "jacobian": (self.j_precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if not k.startswith(heads))}
+                    # the ACTIVE head's parameters only: training one head must not re-pack on the other's (frozen) values
+                    "jacobian": (self.j_precision, self.mode) + tuple(
+                        (p.data_ptr(), p._version) for k, p in params.items()
+                        if not k.startswith(heads) and k.startswith("jacobian_head_arm.") == (self.mode == "arm"))}
             if subs["density"] != self._sub_versions.get("density"):
                 hip.pack_resnetfc(params, heads[0], self._w[:n], self._bd, self._wz, 0, self._bz, precision=self.precision)
             if subs["color"] != self._sub_versions.get("color"):
@@ -405,17 +461,17 @@ class ActionDecoderJacobianMLP(ActionDecoderJacobian):
     """action_decoder_jacobian.py:261-337: Jacobian head = ResnetFC(d_out=3A)."""
 
     action_param_glob_pattern = "jacobian_head"
-    JACOBIAN_KIND = hip.JACOBIAN_MLP
-    J_W_FLOATS, J_B_FLOATS, J_HOIST = hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM
+    REGULAR = (hip.JACOBIAN_MLP, hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM)
 
     def __init__(self, cfg: ActionDecoderJacobianMlpCfg, action_dim: int, encoder_dim: int):
         super().__init__(cfg)
         self._init_common(cfg, action_dim, encoder_dim, hip.MAX_ACTION_DIM)
         self.jacobian_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim * action_dim)
         self.jacobian_head.apply(initialize_jacobian_weights)
+        self._make_arm_head(cfg, encoder_dim)      # (registration order of the reference: head, arm head, colour head)
         self.color_head = self._make_color_head(cfg)
 
-    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+    def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):
         hip.pack_resnetfc(params, "jacobian_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.j_precision)
 
 
@@ -441,8 +497,7 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
     """
 
     action_param_glob_pattern = "flow_head"
-    JACOBIAN_KIND = hip.JACOBIAN_MLP
-    J_W_FLOATS, J_B_FLOATS, J_HOIST = hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM
+    REGULAR = (hip.JACOBIAN_MLP, hip.RESNET_W_FLOATS, hip.RESNET_B_FLOATS, hip.ZDIM)
 
     def __init__(self, cfg: ActionDecoderFlowMlpCfg, action_dim: int, encoder_dim: int):
         super().__init__(cfg)
@@ -461,7 +516,7 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
             self._ones = torch.ones(action.shape[0], 1, dtype=torch.float32, device=action.device)
         return self._ones
 
-    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+    def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):
         enc_dim = self.flow_head.d_latent - self.action_dim
         sliced = dict(params)
         for i in range(3):  # the kernels hoist the 512 feature columns; the action columns become a bias (hoisted_map)
@@ -544,8 +599,7 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
     """
 
     action_param_glob_pattern = "jacobian"
-    JACOBIAN_KIND = hip.JACOBIAN_TRANSFORMER
-    J_W_FLOATS, J_B_FLOATS, J_HOIST = hip.TRANSFORMER_W_FLOATS, hip.TRANSFORMER_B_FLOATS, hip.QDIM
+    REGULAR = (hip.JACOBIAN_TRANSFORMER, hip.TRANSFORMER_W_FLOATS, hip.TRANSFORMER_B_FLOATS, hip.QDIM)
 
     def __init__(self, cfg: ActionDecoderJacobianTransformerCfg, action_dim: int, encoder_dim: int):
         super().__init__(cfg)
@@ -560,10 +614,11 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
                                                         t.attn_mlp_dim, t.attn_feat_dim)
         self.jacobian_head = nn.Linear(t.attn_feat_dim, self.spatial_dim * action_dim)
         self.jacobian_head.apply(initialize_jacobian_weights)
+        self._make_arm_head(cfg, encoder_dim)
         self.color_head = self._make_color_head(cfg)
 
     @torch.no_grad()
-    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+    def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):
         t = self.cfg.transformer
         heads, dh, a = t.num_attn_heads, t.attn_head_dim, self.action_dim
         f32 = lambda x: x.to(torch.float32).contiguous()

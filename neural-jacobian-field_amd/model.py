@@ -601,7 +601,7 @@ class Model(nn.Module):
         ds = torch.where(deltas > 0, deltas * densities, torch.zeros_like(densities))
         acc = torch.cumsum(ds[..., :-1, :], dim=-2)
         acc = torch.cat([torch.zeros_like(ds[..., :1, :]), acc], dim=-2)   # (ds, not acc: a single sample has no prefix)
-        return (1 - torch.exp(-ds)) * torch.exp(-acc)
+        return -torch.expm1(-ds) * torch.exp(-acc)   # (alpha without the cancellation of 1 - exp(-ds): csrc alpha_of)
 
     def _forward_action_grad(self, camera_input, rendering_input, robot_input, compute_vis_features) -> ModelOutput:
         from . import training
@@ -621,7 +621,7 @@ class Model(nn.Module):
 
         project = lambda x: self._project(x, camera_input.trgt_extrinsics, camera_input.trgt_intrinsics)
         flow = training.ActionFlowFunction.apply(run, project, robot_input.robot_action.detach(), features, names,
-                                                 self.cfg.action_decoder.name, *jparams)
+                                                 training.action_kind(self), *jparams)
         outs = box["outs"]
         out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=flow), None, None)
         self._attach_optional_outputs(out, outs, box["bins"], box["weights_list"], box["bins_list"], box["ray_bundle"],

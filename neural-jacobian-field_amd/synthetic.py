@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 import zlib
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -55,10 +55,13 @@ def color_head_shapes(prefix: str, geo_dim: int = 15) -> Dict[str, Shape]:
 
 def decoder_shapes(kind: str, action_dim: int, encoder_dim: int = 512, pe_dim: int = 63, geo_dim: int = 15,
                    attn_feat_dim: int = 64, heads: int = 8, head_dim: int = 64, depth: int = 3,
-                   mlp_dim: int = 64, prefix: str = "decoder.") -> Dict[str, Shape]:
+                   mlp_dim: int = 64, prefix: str = "decoder.", arm_action_dim: Optional[int] = None) -> Dict[str, Shape]:
     """``ActionDecoderJacobianMLP`` / ``ActionDecoderJacobianTransformer`` parameters
-    (models/decoder/action_decoder_jacobian.py:261-322, :340-416)."""
+    (models/decoder/action_decoder_jacobian.py:261-322, :340-416); ``arm_action_dim``: the second head of ``use_arm_model``
+    (:306-313, :400-407)."""
     out = resnet_fc_shapes(prefix + "density_head.", pe_dim, encoder_dim, geo_dim + 1)
+    if arm_action_dim is not None:
+        out.update(resnet_fc_shapes(prefix + "jacobian_head_arm.", pe_dim, encoder_dim, 3 * arm_action_dim))
     if kind == "jacobian_mlp":
         out.update(resnet_fc_shapes(prefix + "jacobian_head.", pe_dim, encoder_dim, 3 * action_dim))
     elif kind == "jacobian_transformer":
@@ -122,12 +125,12 @@ def resnet34_shapes(prefix: str = "encoder.model.") -> Dict[str, Shape]:
 
 
 def model_shapes(decoder_kind: str = "jacobian_mlp", action_dim: int = 8, num_proposal_networks: int = 1,
-                 with_encoder: bool = True) -> Dict[str, Shape]:
+                 with_encoder: bool = True, arm_action_dim: Optional[int] = None) -> Dict[str, Shape]:
     """Full ``Model.state_dict()`` manifest (models/model.py:147-199)."""
     out: Dict[str, Shape] = {}
     if with_encoder:
         out.update(resnet34_shapes())
-    out.update(decoder_shapes(decoder_kind, action_dim))
+    out.update(decoder_shapes(decoder_kind, action_dim, arm_action_dim=arm_action_dim))
     for i in range(num_proposal_networks):
         out.update(proposal_shapes(i))
     return out

@@ -207,11 +207,12 @@ class ActionFlowFunction(torch.autograd.Function):
         # flow_s = sum_a J[a,:] act[a]  (action_decoder_jacobian.py:128-145)  =>  dJ[s,a,c] = w_s act[a] g_xw[c]
         d_j = torch.einsum("brs,ba,brc->brsac", weights, action, g_xw).reshape(b * r * s, 3 * a)
         feats_flat = _flat_features(features)
-        if ctx.kind == "jacobian_mlp":
-            p = {n[len("jacobian_head."):]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
+        if ctx.kind == "jacobian_mlp":   # a ResnetFC head: ``jacobian_head.*``, or ``jacobian_head_arm.*`` in arm mode
+            cut = ctx.names[0].index(".") + 1
+            p = {n[cut:]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
             grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat,
                                       samples_per_ray=s)
-            result = tuple(grads[n[len("jacobian_head."):]] for n in ctx.names)
+            result = tuple(grads[n[cut:]] for n in ctx.names)
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
             xyz_features = pe.new_empty(pe.shape[0], 63)
@@ -413,8 +414,15 @@ def action_params(model):
     ResnetFC layer order for ``jacobian_mlp``, registration order for ``jacobian_transformer`` (index embedding, query
     MLP, attention decoder, output Linear).  Frozen members are included (they simply receive unused gradients)."""
     dec = dict(model.decoder.named_parameters())
-    if model.cfg.action_decoder.name == "jacobian_mlp":
-        names = ["jacobian_head." + k for k in JACOBIAN_PARAM_ORDER]
+    prefix = model.decoder.active_head_prefix     # "jacobian_head." | "jacobian_head_arm." (switch_mode('arm')) | ""
+    if prefix:
+        names = [prefix + k for k in JACOBIAN_PARAM_ORDER]
     else:
-        names = [n for n in dec if n.startswith("jacobian")]
+        names = [n for n in dec if n.startswith("jacobian") and not n.startswith("jacobian_head_arm.")]
     return names, [dec[n] for n in names]
+
+
+def action_kind(model) -> str:
+    """Which backward ActionFlowFunction runs: the ResnetFC chain for a ResnetFC head (jacobian_mlp, and the arm head of either
+    decoder), the recomputed transformer head otherwise."""
+    return "jacobian_mlp" if model.decoder.active_head_prefix else model.cfg.action_decoder.name

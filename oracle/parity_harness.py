@@ -97,11 +97,19 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 # "Is the HIP output at least as close to the float64 result as the reference's own fp32 output is?"  Per compared tensor:
 #   e_hip = |hip - ref64|,  e_ref = |ref32 - ref64|   (element-wise; ref32 / ref64 = the reference -- or, where the reference's
 #   tensors are not in a fixture, the oracle -- evaluated in fp32 / float64 on the same inputs)
-#   truth_ok  <=>  max e_hip <= max(1.5 x max e_ref, ulp_floor)  AND  p99.9(e_hip) <= max(1.5 x p99.9(e_ref), ulp_floor)
+#   strict     <=>  max e_hip <= max(1.5 x max e_ref, ulp_floor)  AND  p99.9(e_hip) <= max(1.5 x p99.9(e_ref), ulp_floor)
+#   truth_ok   <=>  strict,  OR  (both ratios <= 2.0 AND rms e_hip <= 1.5 x rms e_ref)  -- the row is then marked `tail_outlier`
+# Why the second clause: e_hip and e_ref are two DRAWS of fp32 rounding noise pushed through the same ill-conditioned map (the
+# positional encoding's 2*pi*512 gain, the inverse CDF where the CDF is flat); their maxima are the extreme-value statistics of
+# heavy-tailed samples and differ by chance -- measured on the exact-fp32-product mode itself (profiles/r04_parity_margins.json:
+# 3 of its 66 full-size rows sit between 1.5 and 2.0 on ONE of the two ratios, with rms ratios of 1.0), so a mode cannot be
+# failed for it; the rms, which is stable, is held to the same 1.5.
 # ulp_floor = TRUTH_ULPS fp32 ulps of the tensor's scale: where the reference's own error IS the last-bit rounding of the
 # output (ray positions, bins), "1.5 x the maximum of one draw of rounding errors" is decided by chance, not by quality.
 TRUTH_FACTOR = 1.5
+TRUTH_TAIL_FACTOR = 2.0
 TRUTH_ULPS = 4.0
+TRUTH_MIN_ELEMENTS = 1024   # below this a tensor's maximum is one or two ill-conditioned elements: recorded, not asserted
 
 
 def truth_columns(hip: torch.Tensor, ref32: torch.Tensor, ref64: torch.Tensor, tol: float = 1e-4) -> Dict:
@@ -110,20 +118,24 @@ def truth_columns(hip: torch.Tensor, ref32: torch.Tensor, ref64: torch.Tensor, t
     r32, r64 = ref32.detach().double().cpu().reshape(-1), ref64.detach().double().cpu().reshape(-1)
     assert h.shape == r32.shape == r64.shape, (hip.shape, ref32.shape, ref64.shape)
     if h.numel() == 0:
-        return {"truth_ok": True, "elements": 0}
+        return {"truth_ok": True, "truth_ok_strict": True, "elements": 0}
     scale = float(r64.abs().max()) + 1e-300
     e_hip, e_ref = (h - r64).abs() / scale, (r32 - r64).abs() / scale
     k = max(1, int(math.ceil(0.999 * h.numel())))
     p = lambda e: float(e.kthvalue(k).values)
+    rms = lambda e: float(e.pow(2).mean().sqrt())
     ulp_floor = TRUTH_ULPS * 2.0 ** -24
-    hm, rm, hp, rp = float(e_hip.max()), float(e_ref.max()), p(e_hip), p(e_ref)
-    ok = bool(hm <= max(TRUTH_FACTOR * rm, ulp_floor) and hp <= max(TRUTH_FACTOR * rp, ulp_floor))
-    within = float(((h - r32).abs() <= tol * (float(r32.abs().max()) + 1e-300)).double().mean())
+    hm, rm, hp, rp, hr, rr = float(e_hip.max()), float(e_ref.max()), p(e_hip), p(e_ref), rms(e_hip), rms(e_ref)
+    within = lambda f: bool(hm <= max(f * rm, ulp_floor) and hp <= max(f * rp, ulp_floor))
+    strict = within(TRUTH_FACTOR)
+    tail = bool(not strict and within(TRUTH_TAIL_FACTOR) and hr <= max(TRUTH_FACTOR * rr, ulp_floor))
+    frac = float(((h - r32).abs() <= tol * (float(r32.abs().max()) + 1e-300)).double().mean())
     sig = lambda v: float(f"{v:.3e}")
-    return {"e_hip_max": sig(hm), "e_ref_max": sig(rm), "e_hip_p999": sig(hp), "e_ref_p999": sig(rp),
-            "ratio_max": sig(hm / max(rm, 1e-300)), "ratio_p999": sig(hp / max(rp, 1e-300)),
-            "frac_within_1e-4_of_ref32": sig(within), "elements": int(h.numel()), "truth_ok": ok,
-            "on_ulp_floor": bool(hm > TRUTH_FACTOR * rm or hp > TRUTH_FACTOR * rp) and ok}
+    return {"e_hip_max": sig(hm), "e_ref_max": sig(rm), "e_hip_p999": sig(hp), "e_ref_p999": sig(rp), "e_hip_rms": sig(hr),
+            "e_ref_rms": sig(rr), "ratio_max": sig(hm / max(rm, 1e-300)), "ratio_p999": sig(hp / max(rp, 1e-300)),
+            "ratio_rms": sig(hr / max(rr, 1e-300)), "frac_within_1e-4_of_ref32": sig(frac), "elements": int(h.numel()),
+            "truth_ok_strict": strict, "tail_outlier": tail, "truth_ok": bool(strict or tail),
+            "on_ulp_floor": bool(strict and (hm > TRUTH_FACTOR * rm or hp > TRUTH_FACTOR * rp))}
 
 
 def general_pose(seed: int, batch: int, scale: float = 0.15) -> torch.Tensor:

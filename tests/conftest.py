@@ -64,8 +64,13 @@ def margins():
         if ref64 is not None:
             import parity_harness as ph
             cols = ph.truth_columns(got, ref32, ref64, tol)
-            _TRUTH_ROWS.append({"case": case, "key": key, **cols, "asserted": bool(truth_assert)})
-            if truth_assert and not cols["truth_ok"]:
+            # asserted only on tensors large enough for their maxima / percentiles to be statistics: on a 40-ray golden case
+            # ONE ill-conditioned ray carries the maximum of both sides, and the ratio of two single draws of rounding noise
+            # through the same gain exceeds 2 three times in ten for implementations of identical quality (|X| / |Y| of two
+            # normal draws) -- such rows are recorded with asserted = false
+            enforce = bool(truth_assert) and cols.get("elements", 0) >= ph.TRUTH_MIN_ELEMENTS
+            _TRUTH_ROWS.append({"case": case, "key": key, **cols, "asserted": enforce})
+            if enforce and not cols["truth_ok"]:
                 truth_failure = {"case": case, "key": key, **cols}
         if floor is None:
             floor = _rel(ref32, ref64) if ref64 is not None else 0.0
@@ -147,6 +152,6 @@ def golden():
 
     def load(name):
         with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
-            return {k: torch.from_numpy(f[k]) for k in f.files}
+            return {k: torch.from_numpy(f[k]) for k in f.files if f[k].dtype.kind in "fiub"}   # (string arrays: key manifests)
 
     return load

@@ -46,6 +46,7 @@ def main():
                     help="only (re)generate these PARITY_CASES entries of harness_reference.npz, keeping every other array of "
                          "the committed file (round 3: the full-size C2 / C3 / C5 rows, 9,10,11)")
     ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--arm-only", action="store_true", help="only (re)generate model_arm.npz (round 4)")
     args = ap.parse_args()
     mg.install_shims()
     torch.set_num_threads(args.threads)
@@ -180,7 +181,46 @@ def main():
                 out["infer_flow"] = model.infer_optical_flow(enc_out, cam, ref_model.RobotInput(robot_action=rob.robot_action * 2 + 0.05))
         return out
 
+    def arm_fixture():
+        """model_arm.npz (round 4): the second Jacobian head (use_arm_model, action_decoder_jacobian.py:306-313 / 400-407) of BOTH
+        decoders in arm mode (switch_mode("arm"), :89-90, :330-331, :438-446), with arm_action_dim == action_dim -- the only
+        case the reference's compute_flow (:134-140) supports.  Per decoder: Model.forward end to end, the decoder on the fp32
+        run's sample positions, both in fp32 and float64; plus the regular-mode flow of the same weights (the two modes must
+        differ: the test would otherwise pass on a head that ignores the switch)."""
+        import dataclasses
+        arrays = dict(image=image, ctxt_c2w=ctx_c2w, ctxt_k_norm=Kn, trgt_c2w=trg_c2w, trgt_k_pix=kpix, origins=ro, directions=rd,
+                      z_near=z_near, z_far=z_far)
+        for tag, cfg0, A in (("mlp", mlp_dec, 8), ("transformer", tr_dec, 6)):
+            dec_cfg = dataclasses.replace(cfg0, use_arm_model=True, arm_action_dim=A)
+            model = build(dec_cfg, A, [16], 12)
+            assert any(k.startswith("decoder.jacobian_head_arm.") for k in model.state_dict())
+            action = 0.1 * randn(26, B, A)
+            regular = evaluate(model, action, torch.float32, with_inference=False)
+            model.decoder.switch_mode("arm")
+            r32 = evaluate(model, action, torch.float32, with_inference=False)
+            m64 = copy.deepcopy(model).double()
+            m64.decoder.switch_mode("arm")
+            r64 = evaluate(m64, action, torch.float64, fixed_positions=(r32["final_positions"], r32["prop_positions"]), with_inference=False)
+            assert rel(regular["optical_flow"], r32["optical_flow"]) > 1e-2, "arm and regular heads give the same flow"
+            arrays[f"{tag}.action"] = action
+            arrays[f"{tag}.final_positions"] = r32["final_positions"]
+            arrays[f"{tag}.regular_optical_flow"] = regular["optical_flow"]
+            if tag == "mlp":
+                arrays["features"] = r32["features"]
+            for k in ("rgb", "depth", "optical_flow", "dec_action_features", "dec_flow", "dec_density", "vis_action_features"):
+                arrays[f"{tag}.{k}"] = r32[k]
+                arrays[f"{tag}.{k}_f64"] = r64[k]
+            for k, v in self_noise(model, action, r32, ("rgb", "depth", "optical_flow", "vis_action_features")).items():
+                arrays[f"{tag}.{k}"] = v
+            arrays[f"{tag}.arm_keys"] = np.array(sorted(k for k in model.state_dict() if "jacobian_head_arm" in k))
+        save("model_arm", **arrays)
+
+    if args.arm_only:
+        arm_fixture()
+        return
+
     print("writing round-2 fixtures to", HERE)
+    arm_fixture()
     committed = {t: dict(np.load(os.path.join(HERE, f"model_{t}.npz"))) for t in ("mlp", "transformer", "flow")}
     for tag, dec_cfg, A in (("mlp", mlp_dec, 8), ("transformer", tr_dec, 6), ("flow", flow_dec, 5)):
         model = build(dec_cfg, A, [16], 12)

@@ -21,7 +21,9 @@ import parity_harness as _ph
 PRECISIONS = ["f32", "f16x2", "f16f6"]  # "f16f6": the final pass with fp6-corrected products, proposal nets on f16x2
 # the truth-referenced element-wise criterion (oracle/parity_harness.py::truth_columns: the HIP output is as close to the
 # float64 result as the reference's own fp32 output is) is ASSERTED for these modes and recorded for the others
-TRUTH_ASSERTED = ()
+# (asserted on BASELINE's frames at full size -- 2,048 rays and up to 6 M elements per tensor; on the 17 ... 96-ray cases the
+#  maxima of both sides are extreme values of a few hundred elements and the ratio is recorded, not asserted)
+TRUTH_ASSERTED = ("f32",)
 
 
 @pytest.mark.parametrize("case_id", range(len(_ph.PARITY_CASES)))
@@ -38,10 +40,11 @@ def test_fused_forward_matches_oracle(device, case_id, precision, margins):
     name = ph.FULL_SIZE_CASES.get(case_id)
     tag = f"{name}[{precision}]" if name else f"parity[{case_id}:{precision}]"
     margins.record(tag, rep["rows"])
-    margins.record_truth(tag, rep["truth_rows"], asserted=precision in TRUTH_ASSERTED)
+    asserted = bool(name) and precision in TRUTH_ASSERTED
+    margins.record_truth(tag, rep["truth_rows"], asserted=asserted)
     assert rep["floor_source"].startswith("reference"), rep["floor_source"]
     assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
-    if precision in TRUTH_ASSERTED:
+    if asserted:
         assert rep["truth_ok"], [r for r in rep["truth_rows"] if not r["truth_ok"]]
 
 
@@ -61,7 +64,7 @@ def test_ragged_shapes_match_oracle(device, shape, precision, margins):
     import parity_harness as ph
     rep = ph.run_parity_case(device=device, tol=TOL, precision=precision, **RAGGED[shape])
     margins.record(f"parity[ragged{shape}:{precision}]", rep["rows"])
-    margins.record_truth(f"parity[ragged{shape}:{precision}]", rep["truth_rows"], asserted=precision in TRUTH_ASSERTED)
+    margins.record_truth(f"parity[ragged{shape}:{precision}]", rep["truth_rows"], asserted=False)
     assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
 
 
@@ -82,7 +85,7 @@ def test_reference_initialisation_of_the_jacobian_head(device, precision, margin
     rep = ph.run_parity_case(device=device, tol=TOL, precision=precision, batch=2, height=16, width=16, rays=64,
                              s_prop=32, s_final=32, param_hook=reference_init)
     margins.record(f"parity[reference-init:{precision}]", rep["rows"])
-    margins.record_truth(f"parity[reference-init:{precision}]", rep["truth_rows"], asserted=precision in TRUTH_ASSERTED)
+    margins.record_truth(f"parity[reference-init:{precision}]", rep["truth_rows"], asserted=False)
     assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
     assert rep["errors"]["s_jacobian"] < 2e-5, rep["errors"]
 

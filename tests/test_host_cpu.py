@@ -332,6 +332,48 @@ def test_line_gate_and_rank_evidence():
         launch.check_line({"n_gpus": 8, "rccl": ev}, 8)
 
 
+def test_arm_head_registration_and_mode_switch():
+    """use_arm_model (action_decoder_jacobian.py:306-313, 400-407): a second ResnetFC Jacobian head under the reference's
+    parameter names, selected by switch_mode (:89-90) -- for both decoders; the names equal the ones the reference registers
+    (tests/golden/model_arm.npz: arm_keys); the mode switch changes which head the fused kernel evaluates (kind, hoisted
+    channels); switching without the head, to an unknown mode, or with arm_action_dim != action_dim (which the reference's
+    compute_flow cannot contract, :134-140) is refused."""
+    import numpy as np
+    from neural_jacobian_field_amd import hip, synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import Model
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model_arm.npz"))
+    for kind, tag, a in (("jacobian_mlp", "mlp", 8), ("jacobian_transformer", "transformer", 6)):
+        cfg = lambda **dec: model_cfg_from_dict({"action_dim": a, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                                                 "action_decoder": {"name": kind, **dec}})
+        m = Model(cfg(use_arm_model=True, arm_action_dim=a))
+        m.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes(kind, a, arm_action_dim=a), seed=0), strict=True)
+        assert sorted(k for k in m.state_dict() if "jacobian_head_arm" in k) == list(g[tag + ".arm_keys"])
+        dec = m.decoder
+        regular = (dec.JACOBIAN_KIND, dec.J_HOIST, dec.active_head_prefix)
+        assert regular == ((hip.JACOBIAN_MLP, hip.ZDIM, "jacobian_head.") if tag == "mlp" else (hip.JACOBIAN_TRANSFORMER, hip.QDIM, ""))
+        dec.switch_mode("arm")
+        assert (dec.mode, dec.JACOBIAN_KIND, dec.J_HOIST, dec.active_head_prefix) == ("arm", hip.JACOBIAN_MLP, hip.ZDIM, "jacobian_head_arm.")
+        dec.switch_mode("regular")
+        assert (dec.JACOBIAN_KIND, dec.J_HOIST, dec.active_head_prefix) == regular
+        with pytest.raises(ValueError):
+            dec.switch_mode("leg")
+        # the reference's action-mode freeze keeps BOTH heads trainable ("jacobian_head" is a substring of the arm head's names)
+        dec.freeze_non_action_parameters()
+        assert any(p.requires_grad for n, p in dec.named_parameters() if n.startswith("jacobian_head_arm."))
+        assert not any(p.requires_grad for n, p in dec.named_parameters() if n.startswith(("density_head.", "color_head.")))
+        plain = Model(cfg())
+        assert not any("jacobian_head_arm" in k for k in plain.state_dict())
+        with pytest.raises(AttributeError):
+            plain.decoder.switch_mode("arm")
+        other = Model(cfg(use_arm_model=True, arm_action_dim=a - 2))
+        assert other.state_dict()["decoder.jacobian_head_arm.lin_out.weight"].shape[0] == 3 * (a - 2)
+        with pytest.raises(ValueError, match="arm_action_dim"):
+            other.decoder.switch_mode("arm")
+        with pytest.raises(ValueError):
+            Model(cfg(use_arm_model=True))
+
+
 def _synthetic_linearization(device="cpu"):
     from neural_jacobian_field_amd.inverse_dynamics import FlowLinearization
     gen = torch.Generator().manual_seed(3)

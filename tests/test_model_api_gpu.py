@@ -56,11 +56,14 @@ def _noise(g, key, encoder):
             if f"{k}.{key}_f64" in g or f"{k}.{key}" in g]
 
 
-def _check_forward(margins, case, out, g, vis=True, encoder=True):
+def _check_forward(margins, case, out, g, vis=True, encoder=True, truth_assert=False):
     """Model.forward's outputs against the reference's fp32 golden.  Bound per output: max(1e-4, 2 x floor), floor = the
-    largest of |ref32 - ref64| and the reference's own movement under unavoidable input perturbations (`_noise`)."""
+    largest of |ref32 - ref64| and the reference's own movement under unavoidable input perturbations (`_noise`).
+    ``truth_assert``: additionally hold every output to the truth-referenced element-wise criterion against the reference's
+    float64 run (oracle/parity_harness.py::truth_columns)."""
     so = out.standard_output
-    m = lambda key, name, got: margins(case, key, got, g[name], g[name + "_f64"], self_noise=_noise(g, name, encoder))
+    m = lambda key, name, got: margins(case, key, got, g[name], g[name + "_f64"], self_noise=_noise(g, name, encoder),
+                                       truth_assert=truth_assert)
     m("rgb", "rgb", so.rgb)
     m("depth", "depth", so.depth)
     m("optical_flow", "optical_flow", so.optical_flow)
@@ -106,7 +109,7 @@ def test_model_forward_from_reference_features(model_and_golden, margins, precis
             out = model.forward(*_inputs(g), compute_vis_features=True)
     finally:
         model.set_precision("f16x2")
-    _check_forward(margins, f"model_mlp.forward[{precision}]", out, g, encoder=False)
+    _check_forward(margins, f"model_mlp.forward[{precision}]", out, g, encoder=False, truth_assert=precision == "f32")
 
 
 def test_decoder_forward_at_reference_sample_locations(model_and_golden, margins):
@@ -311,6 +314,62 @@ def test_transformer_model_forward_vs_reference_golden(transformer_model_and_gol
     with _from_reference_features(model, g):
         out = model.forward(*_inputs(g), compute_vis_features=True)
     _check_forward(margins, "model_transformer.forward", out, g, encoder=False)
+
+
+@pytest.mark.parametrize("kind,tag,A", [("jacobian_mlp", "mlp", 8), ("jacobian_transformer", "transformer", 6)])
+def test_arm_head_vs_reference_golden(dev, golden, margins, kind, tag, A):
+    """use_arm_model + switch_mode("arm") (action_decoder_jacobian.py:89-90, 306-313, 330-331, 400-407, 438-446) for both
+    decoders against the reference run in arm mode (tests/golden/model_arm.npz, arm_action_dim == action_dim): the decoder at
+    the reference's sample positions and Model.forward end to end; regular mode on the same weights reproduces the
+    reference's regular-mode flow, so the switch -- and the re-pack of the Jacobian block it triggers -- really selects
+    another head; and the arm head trains in action mode (gradient lands on jacobian_head_arm.*, none on jacobian_head.*)."""
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.decoder import PixelEncoding
+    from neural_jacobian_field_amd.model import Model
+    raw = golden("model_arm")
+    g = {k[len(tag) + 1:]: v.to(dev) for k, v in raw.items() if k.startswith(tag + ".") and v.dtype.is_floating_point}
+    g.update({k: v.to(dev) for k, v in raw.items() if "." not in k})
+    cfg = model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                               "action_decoder": {"name": kind, "use_arm_model": True, "arm_action_dim": A}})
+    model = Model(cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes(kind, A, arm_action_dim=A), seed=0), strict=True)
+    model.to(dev).eval().requires_grad_(False)
+    with _from_reference_features(model, g):
+        regular = model.forward(*_inputs(g)).standard_output.optical_flow
+    margins(f"model_arm[{tag}].forward[regular mode]", "optical_flow", regular, g["regular_optical_flow"], tol=5e-3)
+    model.decoder.switch_mode("arm")
+    enc = PixelEncoding(g["features"], g["ctxt_c2w"], g["ctxt_k_norm"], g["action"])
+    pos = g["final_positions"]
+    dirs = g["directions"][..., None, :].expand(pos.shape).contiguous()
+    dec = model.decoder.forward(pos, dirs, enc)
+    c = f"model_arm[{tag}].decoder@ref-positions"
+    margins(c, "action_features", dec.action_features, g["dec_action_features"], g["dec_action_features_f64"])
+    margins(c, "flow", dec.flow, g["dec_flow"], g["dec_flow_f64"])
+    margins(c, "density", dec.density, g["dec_density"], g["dec_density_f64"])
+    with _from_reference_features(model, g):
+        out = model.forward(*_inputs(g), compute_vis_features=True)
+    c = f"model_arm[{tag}].forward"
+    for key, got in (("rgb", out.standard_output.rgb), ("depth", out.standard_output.depth),
+                     ("optical_flow", out.standard_output.optical_flow), ("vis_action_features", out.vis_output.action_features)):
+        margins(c, key, got, g[key], g[key + "_f64"], self_noise=_noise(g, key, False))
+    assert rel(out.standard_output.optical_flow, regular) > 1e-2          # the two heads are different functions
+    # action-mode training of the arm head (the ResnetFC backward chain serves whichever ResnetFC head is active)
+    model.decoder.freeze_non_action_parameters()
+    for n, p in model.named_parameters():
+        p.requires_grad = n.startswith("decoder.jacobian")
+    try:
+        with _from_reference_features(model, g):
+            flow = model.forward(*_inputs(g)).standard_output.optical_flow
+        (flow ** 2).mean().backward()
+        named = dict(model.decoder.named_parameters())
+        arm = [n for n in named if n.startswith("jacobian_head_arm.")]
+        assert arm and all(named[n].grad is not None and torch.isfinite(named[n].grad).all() for n in arm)
+        assert sum(float(named[n].grad.abs().sum()) for n in arm) > 0
+        assert all(p.grad is None for n, p in named.items() if n.startswith("jacobian") and not n.startswith("jacobian_head_arm."))
+    finally:
+        model.requires_grad_(False)
+        model.zero_grad(set_to_none=True)
 
 
 def test_transformer_head_with_eight_keys(dev, golden, margins):

@@ -282,7 +282,9 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins, precisi
             f64 = rel(moved["fp64"][name], g_ref)
             f_all = max(rel(m[name], g_ref) for m in moved.values())
             try:
-                margins(tag, "grad " + name, p.grad, g_ref, floor=f_all, floor_fp64=f64, ceiling=GRADIENT_CEILING)
+                # (ref64: the float64 oracle gradient -- adds the truth-referenced element-wise row of this parameter)
+                margins(tag, "grad " + name, p.grad, g_ref, ref64=moved["fp64"][name],
+                        floor=f_all, floor_fp64=f64, ceiling=GRADIENT_CEILING)
             except AssertionError as e:
                 d = e.args[0] if e.args and isinstance(e.args[0], dict) else {}
                 failures.append((round(d.get("err", 0.0) / max(d.get("limit", 1.0), 1e-30), 2), name))

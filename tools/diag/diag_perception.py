@@ -78,6 +78,32 @@ for prec in ("f32", "f16f6"):
     for lvl in range(2):
         print(f"  level {lvl}: weights {rel(tr.weights_list[lvl], ref.weights_list[lvl]):.2e}  g_weights {rel(tr.weights_list[lvl].grad, ref.weights_list[lvl].grad):.2e}"
               f"  starts {rel(tr.ray_samples_list[lvl].starts, ref.samples_list[lvl].starts):.2e}")
+    if prec == "f32" and os.environ.get("NJF_DIAG_DETAIL"):
+        # round 4 (ADVICE r03 / VERDICT r03 "weak" #2): WHERE does the proposal level's upstream gradient leave the oracle?
+        # element by element at level 0 (uniform samples: identical positions on both sides)
+        wh, wr = tr.weights_list[0].detach().cpu().double().flatten(), ref.weights_list[0].detach().double().flatten()
+        gh, gr = tr.weights_list[0].grad.cpu().double().flatten(), ref.weights_list[0].grad.double().flatten()
+        call0 = [c_ for c_ in stash["calls"] if c_["sigma"].shape[-2] == S and c_["g_w"] is not None]
+        print(f"  level-0 detail: max|w| {wr.abs().max():.3e}  max|g_w| {gr.abs().max():.3e}")
+        idx = (gh - gr).abs().argsort(descending=True)[:8]
+        for i in idx.tolist():
+            print(f"    elem {i:5d}: w_hip {wh[i]:.6e} w_ref {wr[i]:.6e} (abs diff {abs(wh[i]-wr[i]):.2e}, rel {abs(wh[i]-wr[i])/max(abs(wr[i]),1e-300):.2e})"
+                  f"  g_hip {gh[i]:.5e} g_ref {gr[i]:.5e} (rel {abs(gh[i]-gr[i])/max(abs(gr[i]),1e-300):.2e})")
+        # relative error of w as a function of its size
+        for lo_, hi_ in ((0, 1e-9), (1e-9, 1e-7), (1e-7, 1e-5), (1e-5, 1e-3), (1e-3, 1)):
+            m_ = (wr >= lo_) & (wr < hi_)
+            if m_.any():
+                print(f"    w in [{lo_:.0e},{hi_:.0e}): n {int(m_.sum()):5d}  max abs dw {(wh-wr)[m_].abs().max():.2e}  max rel dw {((wh-wr).abs()/wr.clamp_min(1e-300))[m_].max():.2e}"
+                      f"  share of |g_w|_1 {(gr[m_].abs().sum()/gr.abs().sum()):.3f}  max rel dg {((gh-gr).abs()/gr.abs().clamp_min(1e-300))[m_].max():.2e}")
+        # the same level-0 densities: HIP's sigma (what the backward saved) against the oracle's
+        sig_h = [c_["sigma"] for c_ in stash["calls"]][-1].detach().cpu().double().flatten() if stash.get("calls") else None
+        # weights recomputed in float64 from HIP's OWN sigma: is w_hip what its sigma implies?
+        for c_ in stash["calls"]:
+            if c_["g_w"] is not None and c_["sigma"].shape[-2] == S:
+                w64 = Model._weights_from_density(c_["deltas"].cpu().double(), c_["sigma"].detach().cpu().double()).flatten()
+                cand = tr.weights_list[0].detach().cpu().double().flatten()
+                if w64.shape == cand.shape:
+                    print(f"    a composite call: |w_kernel - w64(sigma_kernel)| max abs {(cand - w64).abs().max():.2e}, at small w (<1e-5): max abs {(cand - w64)[w64 < 1e-5].abs().max() if (w64 < 1e-5).any() else 0:.2e} max rel {((cand - w64).abs()/w64.clamp_min(1e-300))[w64 < 1e-5].max() if (w64 < 1e-5).any() else 0:.2e}")
     # the gradient w.r.t. the weights, evaluated by the ORACLE's formula on HIP's weights: is the difference in g_w explained by the weights?
     for lvl in range(2):
         w = tr.weights_list[lvl].detach().cpu().clone().requires_grad_(True)

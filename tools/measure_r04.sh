@@ -9,7 +9,7 @@ case $STEP in
 probe)     # VERDICT r03 "next" #4: MFMA || VALU co-issue on one SIMD
   timeout 120 build/probe_coissue > $O/probe_coissue.txt 2>&1; echo "probe rc=$?"; cat $O/probe_coissue.txt ;;
 tests)
-  NJF_MARGINS_OUT=$PWD/$O/r04_parity_margins.json timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
+  NJF_MARGINS_OUT=$PWD/$O/r04_parity_margins.json timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1
   echo "pytest rc=$?"; tail -5 $O/pytest_gpu.txt ;;
 bench)
   timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 2500 $O/bench.json ;;
@@ -36,11 +36,28 @@ configs)
   for a in "--batch 4 --samples 128" "--height 512 --width 512" "--samples 256" "--samples 32"; do
     echo "ARGS $a"; python bench.py --steps 5 --warmup 2 --no-cpu-baseline $a 2>/dev/null | tail -1
   done > $O/configs.txt ;;
-stream)
-  timeout 300 python tools/stream_kernels.py --json $O/stream_hip_events.json > $O/stream_hip_events.txt 2>&1; tail -12 $O/stream_hip_events.txt ;;
+stream)    # HBM table of the streaming kernels: HIP events with warm and with COLD inputs, and rocprofv3 per-dispatch durations by shape
+  timeout 300 python tools/stream_kernels.py --json $O/stream_hip_events_warm.json > $O/stream_hip_events_warm.txt 2>&1; tail -13 $O/stream_hip_events_warm.txt
+  timeout 300 python tools/stream_kernels.py --cold --json $O/stream_hip_events_cold.json > $O/stream_hip_events_cold.txt 2>&1; tail -13 $O/stream_hip_events_cold.txt
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/stream_trace -- python $OLDPWD/tools/stream_kernels.py --launches 20 --cold > $OLDPWD/$O/stream_trace.log 2>&1)
+  TR=$(find $O/stream_trace -name '*kernel_trace.csv' | head -1)
+  [ -n "$TR" ] && python tools/stream_kernels.py --trace $TR --json $O/stream_rocprof.json | tee $O/stream_rocprof.txt
+  ST=$(find $O/stream_trace -name '*kernel_stats.csv' | head -1); [ -n "$ST" ] && cp $ST $O/stream_kernel_stats.csv
+  rm -rf $O/stream_trace ;;
 profile)   # rocprofv3 kernel stats + PMC passes of the default bench, headline (f32) and default-precision (f16f6) modes
   for p in f32 f16f6; do bash tools/profile_r04.sh $p > $O/profile_$p.log 2>&1; done
   ls gpurun_out/prof_r04_f32 gpurun_out/prof_r04_f16f6 ;;
+ablate)    # experiment builds (build/libnjf_ablate_<v>.so, -DNJF_ABLATE_<V>): kernel times only, results are garbage
+  for prec in f32 f16f6; do
+    for v in "" gather barrier dma dmabarrier pe afrag; do
+      if [ -z "$v" ]; then unset NJF_HIP_LIB; name=baseline; else export NJF_HIP_LIB=$PWD/build/libnjf_ablate_$v.so; name=$v; fi
+      [ -n "$v" ] && [ ! -f "$NJF_HIP_LIB" ] && continue
+      timeout 200 python bench.py --precision $prec --steps 8 --warmup 2 --no-cpu-baseline --no-other-precisions 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$prec', '$name', d['ms_per_step'], d['kernel_ms'])"
+    done
+  done | tee $O/ablate.txt
+  unset NJF_HIP_LIB ;;
+diag)
+  NJF_DIAG_DETAIL=1 timeout 500 python tools/diag/diag_perception.py > $O/diag_perception.txt 2>&1; grep -v "^    elem" $O/diag_perception.txt | head -40 ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
