@@ -32,9 +32,10 @@ def noisy(t, scale=2e-7, seed=1234):
 RAY_SEEDS = (1, 2, 3, 4)
 FEATURE_SEEDS = (11, 12, 13)
 FLOOR_MODES = ("fp64",) + tuple(f"rays{s}" for s in RAY_SEEDS) + tuple(f"features{s}" for s in FEATURE_SEEDS)
-# Parameter gradients are REPORTED against their floors (every row carries err, floor_fp64, floor and `beyond_floors`) and
-# FAILED only beyond this fixed bound: see the `ceiling` argument of the margins fixture (tests/conftest.py).
-GRADIENT_CEILING = 5e-3
+# Round 4: there is no fixed gradient ceiling any more.  Rounds 2-3 passed ~90 perception-mode gradient rows on a 5e-3 bound
+# because every proposal-net gradient sat 2.3-2.9e-3 from the oracle; the cause was `1 - exp(-ds)` quantising tiny weights to
+# multiples of 2^-24 (device expf and torch's Sleef rounding to different neighbours) under the ds-nerf loss's 1 / (w + 1e-7)
+# -- fixed in the kernels (csrc: alpha_of).  Every gradient row is now held to max(1e-4, 2 x its own floors) like any other.
 
 
 def feature_seed(mode):
@@ -153,7 +154,7 @@ def test_action_mode_gradients_match_oracle_autograd(setup, margins):
         assert head[name].grad is not None and torch.isfinite(head[name].grad).all(), name
         # bound: twice the oracle's own movement under one-ulp rays (sample locations feed a 2*pi*512-gain encoding)
         margins("train.action[jacobian_mlp]", "grad " + name, head[name].grad, g_ref[name], floor=floor[name],
-                floor_fp64=floor64[name], ceiling=GRADIENT_CEILING)
+                floor_fp64=floor64[name])
     # frozen parameters received no gradient
     assert all(p.grad is None for n, p in model.named_parameters() if "jacobian_head" not in n)
 
@@ -284,7 +285,7 @@ def test_perception_mode_gradients_match_oracle_autograd(setup, margins, precisi
             try:
                 # (ref64: the float64 oracle gradient -- adds the truth-referenced element-wise row of this parameter)
                 margins(tag, "grad " + name, p.grad, g_ref, ref64=moved["fp64"][name],
-                        floor=f_all, floor_fp64=f64, ceiling=GRADIENT_CEILING)
+                        floor=f_all, floor_fp64=f64)
             except AssertionError as e:
                 d = e.args[0] if e.args and isinstance(e.args[0], dict) else {}
                 failures.append((round(d.get("err", 0.0) / max(d.get("limit", 1.0), 1e-30), 2), name))
@@ -428,8 +429,7 @@ def test_transformer_action_mode_gradients_match_oracle_autograd(setup, margins)
             floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES), floor_fp64=rel(losses["fp64"], losses[None]))
     named = dict(model.named_parameters())
     for k in trainable:
-        margins("train.action[jacobian_transformer]", "grad " + k, named[k].grad, g_ref[k], floor=floor[k], floor_fp64=floor64[k],
-                ceiling=GRADIENT_CEILING)
+        margins("train.action[jacobian_transformer]", "grad " + k, named[k].grad, g_ref[k], floor=floor[k], floor_fp64=floor64[k])
     assert all(p.grad is None for n, p in named.items() if n not in trainable)
 
 

@@ -43,7 +43,7 @@ stream)    # HBM table of the streaming kernels: HIP events with warm and with C
   TR=$(find $O/stream_trace -name '*kernel_trace.csv' | head -1)
   [ -n "$TR" ] && python tools/stream_kernels.py --trace $TR --json $O/stream_rocprof.json | tee $O/stream_rocprof.txt
   ST=$(find $O/stream_trace -name '*kernel_stats.csv' | head -1); [ -n "$ST" ] && cp $ST $O/stream_kernel_stats.csv
-  rm -rf $O/stream_trace ;;
+  [ -n "$TR" ] && cp $TR $O/stream_kernel_trace.csv; rm -rf $O/stream_trace ;;
 profile)   # rocprofv3 kernel stats + PMC passes of the default bench, headline (f32) and default-precision (f16f6) modes
   for p in f32 f16f6; do bash tools/profile_r04.sh $p > $O/profile_$p.log 2>&1; done
   ls gpurun_out/prof_r04_f32 gpurun_out/prof_r04_f16f6 ;;

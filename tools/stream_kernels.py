@@ -55,16 +55,6 @@ def workloads():
     }
 
 
-def expected_grid(name):
-    """Texels the projection kernel's launch covers for a project_f16x2 row (dispatches are told apart by grid size)."""
-    if name == "project_f16x2":
-        return HF * WF
-    if name.startswith("project_f16x2[level "):
-        _, h, w = PYRAMID[int(name[len("project_f16x2[level "):-1])]
-        return h * w
-    return None
-
-
 def run(launches: int, cold: bool = False):
     import torch
     import __graft_entry__ as entry
@@ -163,36 +153,39 @@ def from_stats(path):
 
 
 def from_trace(path):
-    """rocprofv3 --kernel-trace CSV (one row per dispatch) -> {workload: average seconds}, dispatches of one kernel name told
-    apart by their grid size -- the per-shape figures a --stats average cannot give."""
-    groups = {}
+    """rocprofv3 --kernel-trace CSV (one row per dispatch) -> {workload: average seconds}.  The projection kernel runs in two
+    roles with the same name (and, for level 0, the same grid): four times per njf_project_pyramid call (one per pyramid level,
+    inside the `upsample_add` workload) and once per full-map projection.  `run()` issues the workloads one after the other --
+    (3 warm-up + L timed) calls each -- so the dispatches are told apart by their ORDER: the first 4 (3 + L) projection
+    dispatches are the pyramid levels 0..3 in turn, the last 3 + L the full map (warm-up calls dropped from both)."""
+    per_kernel = {}
     with open(path) as f:
         for r in csv.DictReader(f):
             nm = r.get("Kernel_Name") or r.get("Name") or ""
             try:
-                dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
-                grid = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
-                wg = int(r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or 1)
+                t0, t1 = float(r["Start_Timestamp"]), float(r["End_Timestamp"])
             except (KeyError, ValueError):
                 continue
-            groups.setdefault((nm, grid, wg), []).append(dur)
+            per_kernel.setdefault(nm, []).append((t0, (t1 - t0) * 1e-9))
     out = {}
     for name, (kernel, _, _) in workloads().items():
-        cands = {k: v for k, v in groups.items() if kernel in k[0]}
-        if not cands:
+        rows = sorted(d for k, v in per_kernel.items() if kernel in k for d in v)
+        if not rows:
             continue
-        want = expected_grid(name)
-        if want is None:
-            key = max(cands, key=lambda k: len(cands[k]))
-        else:   # the launch whose grid covers `want` texels best: grids are texel tiles x threads, monotone in the texel count
-            order = sorted({k[1] for k in cands})
-            sizes = sorted({expected_grid(n) for n in workloads() if expected_grid(n)})
-            if len(order) != len(sizes):
-                continue
-            grid = order[sizes.index(want)]
-            key = max((k for k in cands if k[1] == grid), key=lambda k: len(cands[k]))
-        v = cands[key]
-        out[name] = sum(v) / len(v)
+        durs = [d for _, d in rows]
+        if not name.startswith("project_f16x2"):
+            warm = 3 if len(durs) > 6 else 0
+            out[name] = sum(durs[warm:]) / len(durs[warm:])
+            continue
+        calls = len(durs) // 5              # (3 + L) calls of each of the two workloads: 4 + 1 projection dispatches per pair
+        if calls < 4 or len(durs) != 5 * calls:
+            continue
+        if name == "project_f16x2":
+            sel = durs[4 * calls:][3:]
+        else:
+            lvl = int(name[len("project_f16x2[level "):-1])
+            sel = durs[: 4 * calls][lvl::4][3:]
+        out[name] = sum(sel) / len(sel)
     return out
 
 
