@@ -8,6 +8,8 @@ Reference: ``models/decoder/__init__.py:11-44`` (registries), ``action_decoder.p
 
 from __future__ import annotations
 
+import os
+
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -196,6 +198,15 @@ class DensityDecoderMlp(nn.Module):
             self._bz = torch.empty(hip.ZDIM, **f32)
             params = {k: p for k, p in self.named_parameters()}
             hip.pack_resnetfc(params, "density_head.", self._w, self._b, self._wz, 0, self._bz, precision=self.precision)
+            mix = int(os.environ.get("NJF_PROPOSAL_MIX", "0"))
+            if mix > 0 and self.precision == "f16x2":
+                # kernel A/B experiment only (tools/measure_r04.sh mix, with a -DNJF_PROPOSAL_MIX=<n> library): the first n wide
+                # layers' chunks (2 per layer, after the lin_in chunk) come from the f16f6 pack of the same weights
+                w6 = torch.empty_like(self._w)
+                hip.pack_resnetfc(params, "density_head.", w6, torch.empty_like(self._b), torch.empty_like(self._wz), 0,
+                                  torch.empty_like(self._bz), precision="f16f6")
+                c = hip.RESNET_W_FLOATS // 22
+                self._w[c: c * (1 + 2 * mix)] = w6[c: c * (1 + 2 * mix)]
             self._packed_version = v
         return self._w, self._b
 

@@ -56,6 +56,18 @@ ablate)    # experiment builds (build/libnjf_ablate_<v>.so, -DNJF_ABLATE_<V>): k
     done
   done | tee $O/ablate.txt
   unset NJF_HIP_LIB ;;
+mix)       # VERDICT r03 "next" #5: the first n wide layers of the (f16x2) proposal net on the fp6-corrected product form
+  for n in 0 2 3 5; do
+    if [ $n = 0 ]; then unset NJF_HIP_LIB NJF_PROPOSAL_MIX; else export NJF_HIP_LIB=$PWD/build/libnjf_mix$n.so NJF_PROPOSAL_MIX=$n; fi
+    timeout 300 python bench.py --precision f16f6 --no-other-precisions --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/mix$n.json
+    python - <<PY
+import json
+d = json.load(open('$O/mix$n.json')); p = d['parity_on_bench_frame']['f16f6']
+print('mix$n', 'ms', d['ms_per_step'], d['kernel_ms'], {k: (v['err'], v['limit'], v['ok'], v['truth']['ratio_max']) for k, v in p.items()})
+PY
+    NJF_MARGINS_OUT=$PWD/$O/mix${n}_margins.json timeout 600 python -m pytest tests/test_hip_parity.py tests/test_properties_gpu.py -m gpu -q -k "f16f6 or full_size or default" 2>&1 | tail -4
+  done 2>&1 | tee $O/mix.txt
+  unset NJF_HIP_LIB NJF_PROPOSAL_MIX ;;
 diag)
   NJF_DIAG_DETAIL=1 timeout 500 python tools/diag/diag_perception.py > $O/diag_perception.txt 2>&1; grep -v "^    elem" $O/diag_perception.txt | head -40 ;;
 *) echo "unknown step $STEP" ;;
