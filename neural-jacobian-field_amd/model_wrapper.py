@@ -80,10 +80,22 @@ def flow_loss(output: ModelOutput, target: ModelTarget) -> torch.Tensor:
     return err.mean()
 
 
+_SIGMA: Dict[tuple, torch.Tensor] = {}
+
+
+def _sigma_on(sigma: float, device) -> torch.Tensor:
+    """The loss's sigma as a one-element device tensor, uploaded once per (value, device): a per-step torch.tensor(...) is a
+    pageable host-to-device copy on the critical path, and illegal while a step is being recorded into a HIP graph."""
+    key = (sigma, str(device))
+    if key not in _SIGMA:
+        _SIGMA[key] = torch.tensor([sigma], device=device)
+    return _SIGMA[key]
+
+
 def depth_loss(output: ModelOutput, target: ModelTarget, sigma: float = 0.001) -> torch.Tensor:
     """model_wrapper.py:123-136: 0.08 x mean over levels of the ds-nerf loss."""
     wl, sl = output.training_output.weights_list, output.training_output.ray_samples_list
-    sig = torch.tensor([sigma], device=target.depth.device)
+    sig = _sigma_on(float(sigma), target.depth.device)
     total = 0.0
     for wts, smp in zip(wl, sl):
         total = total + ds_nerf_depth_loss(wts, target.depth, (smp.starts + smp.ends) / 2, smp.ends - smp.starts, sig) / len(wl)

@@ -108,6 +108,19 @@ class UniformSampler(Sampler):
         return ray_bundle.samples_from_bins(self.spacing_bins(ray_bundle, num_samples))
 
 
+_U_BASE: dict = {}
+
+
+def _train_u_base(nb: int, device) -> torch.Tensor:
+    """linspace(0, 1 - 1/nb, nb) of ray_samplers.py:391-394 on ``device``, computed once on the host and uploaded once per
+    (nb, device): same values as before, no host-to-device copy per training step (which a step recorded into a HIP graph
+    could not contain, training.GraphedTrainingStep)."""
+    key = (nb, str(device))
+    if key not in _U_BASE:
+        _U_BASE[key] = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb).to(device)
+    return _U_BASE[key]
+
+
 class PDFSampler(Sampler):
     """ray_samplers.py:326-451."""
 
@@ -124,7 +137,7 @@ class PDFSampler(Sampler):
         """ray_samplers.py:388-409."""
         nb = num_samples + 1
         if self.train_stratified and self.training:
-            u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb).to(device).expand((*batch_shape, nb))
+            u = _train_u_base(nb, device).expand((*batch_shape, nb))
             rand = torch.rand((*batch_shape, 1 if self.single_jitter else nb), device=device) / nb
             return (u + rand).contiguous()
         u = pdf_u_eval(num_samples, device)

@@ -319,6 +319,16 @@ def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
         assert r.returncode != 0 and not _json_lines(r.stdout) and "GPU(s) are visible" in r.stderr
 
 
+def test_bench_train_refuses_a_wrong_world_too():
+    """tools/bench_train.py (BASELINE config 4) launches through the same two calls: a launcher world that is not --gpus, or
+    fewer visible GPUs than ranks, ends without a JSON line and with a non-zero status."""
+    r = _run_bench(["--gpus", "8", "--mode", "action"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, script="tools/bench_train.py")
+    assert r.returncode != 0 and not _json_lines(r.stdout) and "WORLD_SIZE is 1" in r.stderr
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "2"], script="tools/bench_train.py")
+        assert r.returncode != 0 and not _json_lines(r.stdout) and "GPU(s) are visible" in r.stderr
+
+
 def test_line_gate_and_rank_evidence():
     """launch.check_line / launch.rank_evidence: a line whose n_gpus or evidence disagrees with --gpus is refused; a world
     of one without a process group still yields a well-formed record."""

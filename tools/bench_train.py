@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank")
+    ap.add_argument("--start-step", type=int, default=0,
+                    help="global step of the first iteration (20000: steady state -- anneal exponent 1, proposal nets updated every sixth step)")
     args = ap.parse_args()
     mode = args.mode or args.mode_pos or "action"
     launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -86,7 +88,7 @@ def main():
         return (mw.rgb_loss(out, ptarget) + mw.depth_loss(out, ptarget) + mw.interlevel_loss(tr.weights_list, tr.ray_samples_list)
                 + 0.01 * mw.distortion_loss(tr.weights_list, tr.ray_samples_list))
 
-    counter = [0]
+    counter = [args.start_step]
 
     def step():
         i = counter[0]
@@ -133,7 +135,7 @@ def main():
                 "value": round(world * B * R / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * dt, 3), "training_step_ms": round(1e3 * dt, 2), "higher_is_better": True, "scaling": "weak",
                 "rays_per_step": world * B * R, "samples": f"{S}+{S}", "train_rays_per_s": round(world * B * R / dt, 1),
-                "final_loss": float(loss), "gradient_bucket_bytes": bucket,
+                "final_loss": float(loss), "gradient_bucket_bytes": bucket, "start_step": args.start_step,
                 "mode": {"action": "action (Jacobian head only), encoder fwd included",
                          "perception": "perception (all parameters), encoder fwd+bwd included"}[mode],
                 "dtype": "forward: package default precision; backward chain: exact fp32 MFMA", "data": "synthetic",
