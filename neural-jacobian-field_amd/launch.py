@@ -115,7 +115,10 @@ def rank_evidence(dist, device: torch.device, local_step_ms: float, graph: bool 
     if [r["rank"] for r in recs] != list(range(world)):
         raise SystemExit(f"refusing to report: ranks present {[r['rank'] for r in recs]} != 0..{world - 1}")
     if device.type == "cuda":
-        ids = [(r["host"], r.get("uuid") or r.get("pci_bus_id") or r["device"]) for r in recs]
+        # two ranks sit on ONE device only if every hardware identifier they report coincides (bus id AND uuid): a partitioned
+        # GPU may share one of them between partitions, and a false refusal would cost the whole multi-GPU measurement
+        ids = [(r["host"], r.get("pci_bus_id"), r.get("uuid")) if (r.get("pci_bus_id") or r.get("uuid")) else (r["host"], r["device"])
+               for r in recs]
         if len(set(ids)) != world:
             raise SystemExit(f"refusing to report: {world} ranks on {len(set(ids))} distinct device(s): {ids}")
     steps = [r["step_ms"] for r in recs]

@@ -342,6 +342,38 @@ def test_line_gate_and_rank_evidence():
         launch.check_line({"n_gpus": 8, "rccl": ev}, 8)
 
 
+def test_rank_evidence_refuses_two_ranks_on_one_device(monkeypatch):
+    """Two ranks that report the SAME bus id and uuid are one physical device (a mis-set LOCAL_RANK): no line.  Ranks that
+    share only one of the two identifiers (partitions of one GPU) are distinct devices."""
+    from neural_jacobian_field_amd import launch
+
+    class Group:
+        def __init__(self, recs):
+            self.recs = recs
+
+        def get_world_size(self):
+            return len(self.recs)
+
+        def get_backend(self):
+            return "nccl"
+
+        def all_gather_object(self, out, mine):
+            for i, r in enumerate(self.recs):
+                out[i] = dict(r, step_ms=1.0 + i)
+
+    rec = lambda rank, bus, uuid: {"rank": rank, "local_rank": rank, "host": "node", "pid": 100 + rank, "device": f"cuda:{rank}",
+                                   "pci_bus_id": bus, "uuid": uuid}
+    monkeypatch.setattr(launch, "_device_record", lambda device: rec(0, "0000:05:00", "a"))
+    dev = torch.device("cuda", 0)
+    good = launch.rank_evidence(Group([rec(0, "0000:05:00", "a"), rec(1, "0000:15:00", "b")]), dev, 1.0)
+    assert good["world_size"] == 2 and good["rank_step_ms"] == {"min": 1.0, "max": 2.0, "per_rank": [1.0, 2.0]}
+    assert launch.rank_evidence(Group([rec(0, "0000:05:00", "a"), rec(1, "0000:05:00", "b")]), dev, 1.0)["world_size"] == 2
+    with pytest.raises(SystemExit, match="distinct device"):
+        launch.rank_evidence(Group([rec(0, "0000:05:00", "a"), rec(1, "0000:05:00", "a")]), dev, 1.0)
+    with pytest.raises(SystemExit, match="ranks present"):
+        launch.rank_evidence(Group([rec(0, "0000:05:00", "a"), rec(0, "0000:15:00", "b")]), dev, 1.0)
+
+
 def test_arm_head_registration_and_mode_switch():
     """use_arm_model (action_decoder_jacobian.py:306-313, 400-407): a second ResnetFC Jacobian head under the reference's
     parameter names, selected by switch_mode (:89-90) -- for both decoders; the names equal the ones the reference registers
