@@ -404,7 +404,12 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
     auto hfrag = [&](int i) { return __builtin_bit_cast(f16x8, u32x4{(unsigned)i, (unsigned)lane, 3u, 4u}); };
     auto f6frag = [&](int idx) { return i32x8{idx, lane, 2, 3, 4, 5, 0, 0}; };
 #else
+#ifdef NJF_ABLATE_AFRAG_HALF  // experiment builds only: every second hi fragment re-uses its neighbour's LDS read (half the
+                             // A-fragment traffic of the f16 MFMAs, same MFMA count; results are garbage)
+    auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + (i & ~1) * 1024); };
+#else
     auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + i * 1024); };                  // hi fp16 fragment (t, m): i = 4t + m
+#endif
     auto f6frag = [&](int idx) {                                                           // fp6 fragment idx = 2m + w
       const i32x4 a4 = *(NJF_LDS(i32x4))(p16 + F6_P1 + idx * 1024);
       // volatile: keeps the load-store optimiser from fusing the 8-byte tails of two fragments into one ds_read2st64_b64,
