@@ -108,7 +108,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
 
     # scratch by default (a partial run -- `pytest -k`, one file -- must never replace the committed table); the committed
-    # profiles/r03_parity_margins.json is written only when NJF_MARGINS_OUT names it (tools/measure_r03.sh: full suite)
+    # profiles/r04_parity_margins.json is written only when NJF_MARGINS_OUT names it (tools/measure_r04.sh tests: full suite)
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     path = os.environ.get("NJF_MARGINS_OUT", os.path.join(out_dir, "parity_margins_last_run.json"))
