@@ -1,16 +1,43 @@
 """Stand-ins for the two frame-level HIP kernels and for ``Model`` on CPU tensors (TEST INFRASTRUCTURE).
 
 Used by the world-size-2 ``gloo`` tests of ``parallel.ShardedFrameStep`` (tests/test_host_cpu.py) and, through
-``bench.py --dry-launch tests/frame_standins.py``, by the launcher test: the kernels are replaced by their tensor-op
-restatements (oracle/frame_reference.py; the GPU tests check the real kernels against the same restatements)."""
-import os
-import sys
-
+``bench.py --dry-launch tests/frame_standins.py``, by the launcher test.  Self-contained on purpose -- nothing under oracle/
+is imported, so the bench's dry-launch mode never executes oracle code: the two stand-in kernels below are plain tensor
+ops, and tests/test_host_cpu.py::test_frame_standins_equal_the_oracle_restatements ties them to oracle/frame_reference.py
+(which the GPU tests check the real kernels against)."""
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import frame_reference as fr  # noqa: E402
+
+def _shard_bounds(num_rays, world, rank):
+    q, r = divmod(num_rays, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def reduce_frame_partials(partials: torch.Tensor, out4: torch.Tensor) -> None:
+    """njf_reduce_frame_partials on CPU tensors: per-group (min t, max t, sum err_rgb^2, sum err_flow^2) -> one record."""
+    out4[0], out4[1] = partials[:, 0].min(), partials[:, 1].max()
+    out4[2], out4[3] = partials[:, 2].double().sum().float(), partials[:, 3].double().sum().float()
+
+
+def assemble_frame(packets, batch, rays, frame, scalars6, rgb_scale=0.0, flow_scale=0.0) -> None:
+    """njf_assemble_frame on CPU tensors: packets [world, 6 B cap + 4] -> frame [B,R,6] with the GLOBAL depth clip + losses."""
+    world, plen = packets.shape
+    cap = -(-rays // world)
+    rec = packets[:, plen - 4:]
+    mn, mx = rec[:, 0].min(), rec[:, 1].max()
+    s0, s1 = rec[:, 2].double().sum().float(), rec[:, 3].double().sum().float()
+    for k in range(world):
+        lo, hi = _shard_bounds(rays, world, k)
+        n = hi - lo
+        if n == 0:
+            continue
+        pk = packets[k]
+        frame[:, lo:hi, 0:3] = pk[: 3 * batch * n].view(batch, n, 3)
+        frame[:, lo:hi, 3] = torch.clamp(pk[3 * batch * cap: 3 * batch * cap + batch * n].view(batch, n), min=mn, max=mx)
+        frame[:, lo:hi, 4:6] = pk[4 * batch * cap: 4 * batch * cap + 2 * batch * n].view(batch, n, 2)
+    scalars6[0], scalars6[1], scalars6[2], scalars6[3] = mn, mx, s0, s1
+    scalars6[4], scalars6[5] = s0 * rgb_scale, s1 * flow_scale
 
 
 class FakeShardModel:
@@ -58,7 +85,7 @@ def make_frame_step(parallel, world: int, rank: int, batch: int = 2, rays: int =
     f = known_frame(batch, rays)
     lo, hi = parallel.shard_bounds(rays, world, rank)
     step = parallel.ShardedFrameStep(FakeShardModel(f["rgb"], f["depth"], f["flow"], f["tmin"], f["tmax"], lo, hi), batch, rays, "cpu",
-                                     world_size=world, rank=rank, reduce_fn=fr.reduce_frame_partials, assemble_fn=fr.assemble_frame)
+                                     world_size=world, rank=rank, reduce_fn=reduce_frame_partials, assemble_fn=assemble_frame)
     assert (step.lo, step.hi) == (lo, hi) and step.world == world
     step.set_targets(f["trg"][:, lo:hi], f["tflow"][:, lo:hi])
     mse = torch.nn.functional.mse_loss

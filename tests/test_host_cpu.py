@@ -288,6 +288,29 @@ def _json_lines(text):
     return rows
 
 
+def test_frame_standins_equal_the_oracle_restatements():
+    """tests/frame_standins.py (what bench.py --dry-launch and the gloo tests put in place of the two frame-level kernels) holds
+    its own tensor-op stand-ins so that the bench never executes oracle code; they must be the same functions as
+    oracle/frame_reference.py, the checker of the real kernels on the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frame_reference as fr
+    import frame_standins as st
+    g = torch.Generator().manual_seed(4)
+    world, batch, rays = 3, 2, 11                      # ragged: 4 + 4 + 3 rays
+    cap = -(-rays // world)
+    packets = torch.rand(world, 6 * batch * cap + 4, generator=g)
+    packets[:, -4] = torch.tensor([0.7, 0.5, 0.9])
+    packets[:, -3] = torch.tensor([8.0, 9.5, 9.0])
+    outs = []
+    for mod in (fr, st):
+        frame, scal = torch.zeros(batch, rays, 6), torch.zeros(6)
+        mod.assemble_frame(packets, batch, rays, frame, scal, 0.25, 0.125)
+        rec = torch.zeros(4)
+        mod.reduce_frame_partials(packets[:, :8].reshape(-1, 4), rec)
+        outs.append((frame, scal, rec))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
 def test_bench_self_launches_its_ranks_under_gloo():
     """`python bench.py --gpus 2` as a PLAIN process (no torchrun, no WORLD_SIZE) must spawn two ranks itself and print ONE
     line whose n_gpus is 2, with the evidence that two ranks really exchanged data: backend, world size, one device record
