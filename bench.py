@@ -229,7 +229,7 @@ def parity_on_bench_frame(models, cam, rob, z_near, z_far, origins, directions, 
 def dry_launch(args, dist, rank: int, world: int) -> None:
     """The launcher path without a GPU: same world check, barriers, max-over-ranks, rank evidence and line gate as a real
     run, with parallel.ShardedFrameStep on CPU tensors and the stand-in kernels of the file named by --dry-launch (the
-    tests' tensor-op restatements).  Nothing here is a measurement and the line says so."""
+    tests' self-contained stand-ins: no oracle code runs).  Nothing here is a measurement and the line says so."""
     from neural_jacobian_field_amd import launch, parallel
 
     spec = importlib.util.spec_from_file_location("njf_dry_standins", args.dry_launch)
