@@ -329,6 +329,20 @@ def test_bench_self_launches_its_ranks_under_gloo():
     assert len(ev["rank_step_ms"]["per_rank"]) == 2 and ev["rank_step_ms"]["max"] >= ev["rank_step_ms"]["min"] > 0
 
 
+def test_bench_self_launches_eight_ranks_under_gloo():
+    """The world size of BASELINE's multi-GPU configurations: `python bench.py --gpus 8` spawns eight ranks, the 101-ray frame
+    shards raggedly (13 x 5 + 12 x 3), ONE all_gather per step assembles it on every rank, the line reports eight device
+    records and eight step times."""
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-launch", os.path.join(ROOT, "tests", "frame_standins.py")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = _json_lines(r.stdout)
+    assert len(rows) == 1, r.stdout
+    line = rows[0]
+    assert line["n_gpus"] == 8 and line["frame_ok"] is True and line["rccl"]["world_size"] == 8
+    assert [d["rank"] for d in line["rccl"]["devices"]] == list(range(8)) and len({d["pid"] for d in line["rccl"]["devices"]}) == 8
+    assert len(line["rccl"]["rank_step_ms"]["per_rank"]) == 8
+
+
 def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
     """The case that used to print a one-GPU line for --gpus 8: a launcher environment with WORLD_SIZE=1.  Now: no JSON
     line, non-zero exit.  Same for a GPU run asked for more devices than are visible (none here)."""
