@@ -138,13 +138,17 @@ class _HoistCache:
 
 
 def _map_of(net, features, action=None):
-    """(hoisted map, first channel of `net`'s block in it) for a point query: the frame's JOINT map when the owning Model
-    has one for these features (``net.joint_source``, set by Model.__init__), else the network's own map."""
-    source = getattr(net, "joint_source", None)
+    """(hoisted map, first channel of `net`'s block in it) for a point query: the frame's JOINT map when the owning Model has
+    projected one for exactly these features and these weights (``net._joint_view``, written by Model._joint_hoist), else the
+    network's own map.  The record is plain data -- feature tensor (identity + version + shape), the network's packed-weights
+    version, the map, the channel base -- so a deep copy of a model never reads another model's map."""
+    view = getattr(net, "_joint_view", None)
+    if view is not None:
+        f, fver, fshape, wver, gmap, base = view
+        net.packed()
+        if f is features and fver == features._version and fshape == tuple(features.shape) and wver == net._packed_version:
+            return gmap, base
     # (flow_mlp adds a per-image action bias to its block: it never shares a map -- Model._joint_hoist returns None for it)
-    hit = source(features) if source is not None else None
-    if hit is not None:
-        return hit
     return (net.hoisted_map(features) if action is None else net.hoisted_map(features, action)), 0
 
 

@@ -127,13 +127,6 @@ class Model(nn.Module):
         self.proposal_networks = nn.ModuleList(
             [get_density_decoder(cfg.density_decoder, encoder_dim=self.encoder.get_output_dim()) for _ in range(n_prop)])
         self.density_fns = [net.get_density for net in self.proposal_networks]
-        # point queries of a network read its channel range of the frame's joint hoisted map when there is one
-        # (plain attributes holding a bound method of a weak proxy: the networks must not own the model)
-        import weakref
-        me = weakref.proxy(self)
-        for i, net in enumerate(self.proposal_networks):
-            net.joint_source = (lambda f, i=i: (lambda j: None if j is None else (j[0], j[1][i]))(me._joint_lookup(f)))
-        self.decoder.joint_source = lambda f: (lambda j: None if j is None else (j[0], j[2]))(me._joint_lookup(f))
         r = cfg.rendering
         update_schedule = lambda step: np.clip(np.interp(step, [0, r.proposal_warmup], [0, r.proposal_update_every]), 1,
                                                r.proposal_update_every)
@@ -220,6 +213,7 @@ class Model(nn.Module):
         a benchmark that must include the per-image projection in every step, calls this first."""
         for m in [self.decoder, *self.proposal_networks]:
             m._hoist.key = None
+            m._joint_view = None
         self._joint["features"] = None
         return self
 
@@ -257,6 +251,11 @@ class Model(nn.Module):
             else:
                 hip.project_features(features.contiguous(), c["wz"], c["bz"], gmap, precision=self.decoder.precision)
             c["features"], c["key"], c["gmap"] = features, key, gmap
+            # point queries of a network (decoder.forward / compute_density / get_density, called directly as in the reference)
+            # read ITS channel range of this map instead of projecting one of their own: each network gets a plain record
+            # (no back-reference to the model: a deep copy of the model or of a network must not see this model's maps)
+            for n, base in zip(nets, c["bases"]):
+                n._joint_view = (features, features._version, tuple(features.shape), n._packed_version, gmap, base)
         return c["gmap"], c["bases"][:-1], c["bases"][-1]
 
     def _joint_lookup(self, features):

@@ -419,6 +419,16 @@ def test_joint_hoist_equals_the_per_network_maps(dev):
         shared = (model.compute_density(xyz.reshape(2, 35, 3), enc)[0].density, model.proposal_networks[1].get_density(xyz, enc))
         assert all(net._hoist.gmap is None for net in (model.decoder, *model.proposal_networks))   # nothing projected again
         assert torch.equal(own[0], shared[0]) and torch.equal(own[1], shared[1])
+        # ... and a DEEP COPY of the model with other weights never reads this model's map (the record a network holds is plain
+        # data keyed on the feature tensor's identity and on the network's own packed-weights version, not a back-reference)
+        import copy
+        other = copy.deepcopy(model)
+        with torch.no_grad():
+            for prm in other.decoder.density_head.parameters():
+                prm.mul_(1.5)
+        theirs = other.compute_density(xyz.reshape(2, 35, 3), enc)[0].density
+        assert not torch.equal(theirs, shared[0])
+        assert torch.equal(model.compute_density(xyz.reshape(2, 35, 3), enc)[0].density, shared[0])
 
 
 def test_sharded_frame_step_equals_the_unsharded_forward(dev):
