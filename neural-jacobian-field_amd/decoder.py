@@ -516,6 +516,9 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
 
     def __init__(self, cfg: ActionDecoderFlowMlpCfg, action_dim: int, encoder_dim: int):
         super().__init__(cfg)
+        if cfg.use_arm_model:   # flow_head_arm (action_decoder_flow.py:109-116): part of an ablation decoder no config ships
+            raise NotImplementedError("flow_mlp with use_arm_model (flow_head_arm) is not part of the fused path; the Jacobian "
+                                      "decoders implement their arm head (jacobian_head_arm)")
         self._init_common(cfg, action_dim, encoder_dim, 1 << 16)  # the kernel sees one channel, any A works
         self.flow_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim, extra_latent=action_dim)
         self.flow_head.apply(initialize_flow_weights)

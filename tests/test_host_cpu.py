@@ -451,6 +451,9 @@ def test_arm_head_registration_and_mode_switch():
             other.decoder.switch_mode("arm")
         with pytest.raises(ValueError):
             Model(cfg(use_arm_model=True))
+    with pytest.raises(NotImplementedError, match="flow_head_arm"):      # the ablation decoder's arm head stays out of scope, loudly
+        Model(model_cfg_from_dict({"action_dim": 5, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                                   "action_decoder": {"name": "flow_mlp", "use_arm_model": True, "arm_action_dim": 5}}))
 
 
 def _synthetic_linearization(device="cpu"):
