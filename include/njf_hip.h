@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 15
+#define NJF_ABI_VERSION 16
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -44,6 +44,7 @@ extern "C" {
 
 /* floats in one packed ResnetFC blob (weights) and its bias blob */
 #define NJF_RESNET_CHUNKS 22
+#define NJF_RESNET_CHUNKS_F16 12  /* NJF_PRECISION_F16 fills the first 12 chunk slots of the same NJF_RESNET_W_FLOATS blob */
 #define NJF_CHUNK_FLOATS 8192
 #define NJF_RESNET_W_FLOATS (NJF_RESNET_CHUNKS * NJF_CHUNK_FLOATS)
 #define NJF_RESNET_B_FLOATS (10 * 128 + 32)
@@ -66,8 +67,22 @@ extern "C" {
                                   128-wide layers; the narrow layers (lin_out, colour head, transformer head) and
                                   the feature projection keep the F16X2 form */
 
+#define NJF_PRECISION_F16 3    /* PLAIN fp16 products (BASELINE config 5: "fp16 MFMA fused-MLP"): weights packed once as single
+                                  fp16, layer inputs rounded to fp16 behind the ReLU, v_mfma_f32_32x32x16_f16 with fp32
+                                  accumulation and fp32 biases / residuals -- no hi/lo split, no correction products (issue
+                                  factor 1).  A REDUCED-precision mode with its own stated tolerance (every matrix operand is
+                                  rounded to 11 significant bits: ~1e-3 norm-wise per network output),
+                                  never the default.  Differences at the boundary: (a) the hoisted map such a network reads is
+                                  a map of HALVES -- njf_project_features* / njf_project_pyramid with this precision write
+                                  `out` as _Float16 [B, Hf*Wf, N] (the projection itself stays error-compensated, its fp32
+                                  result is rounded once), NjfFeatureMap.data points to halves and NjfFeatureMap.stride / the
+                                  gmap offsets count halves (multiples of 8); (b) a whole 128 x 128 layer is one weight chunk:
+                                  the packed ResnetFC keeps its NJF_RESNET_W_FLOATS extent and fills the first
+                                  NJF_RESNET_CHUNKS_F16 chunk slots; (c) inference only: the training forwards (activation
+                                  dumps) return the "unknown mode" error; (d) never part of a MIXED code */
+
 /* njf_render_forward / njf_points_forward: density + colour networks in precision `d`, Jacobian head in `j` (both one of
- * the values above; mixed forms exist for the two split precisions).  A plain NJF_PRECISION_* value means d = j. */
+ * F32 / F16X2 / F16F6; mixed forms exist for the two split precisions).  A plain NJF_PRECISION_* value means d = j. */
 #define NJF_PRECISION_MIXED(d, j) ((d) | (((j) + 1) << 4))
 
 #define NJF_JACOBIAN_NONE 0
@@ -163,7 +178,9 @@ int njf_project_features_ld(const float* feats, const float* wz, int wz_ld, cons
  * Given the latents themselves (NCHW, level 0 at the output resolution, channel counts summing to 512 in
  * concatenation order) this computes the same hoisted map G = F . wz + bz without ever forming F: every level is
  * projected at its own resolution, the coarser ones are bilinearly up-sampled and added.  `workspace` (caller-owned)
- * holds the projected coarser levels: sum over l >= 1 of batch * height_l * width_l * n floats. */
+ * holds the projected coarser levels: sum over l >= 1 of batch * height_l * width_l * n floats.  NJF_PRECISION_F16 with more
+ * than one level: the sum is formed in fp32 and rounded once into `out` (halves); the workspace then holds the fp32 level-0
+ * map IN FRONT of the coarser levels (batch * height_0 * width_0 * n more floats). */
 typedef struct NjfPyramidLevel {
   const float* feats; /* [B, channels, height, width] */
   int channels;       /* multiple of 16 */
@@ -187,9 +204,10 @@ int njf_upsample_concat_backward(const float* grad, const NjfPyramidLevel* level
 /* Channel order of the hoisted map.  Inside every block of `block_channels` channels (128 for a ResnetFC's lin_z layer,
  * 64 for the transformer head's query projection) logical feature f of the layer is stored at position
  * njf_hoisted_channel(f, block_channels, precision) -- the order in which the fused kernels' gather reads it, which
- * follows the MFMA precision (NJF_PRECISION_F32 / _F16X2 / _F16F6, not a MIXED code) the network that owns the block is
- * packed for: F32 and F16X2 networks fetch per lane (the two lanes that own a point read adjacent 16-byte pieces),
- * F16F6 networks per quad of lanes (csrc/njf_device.h: add_hoisted_latent).  The njf_pack_* entry points apply it
+ * follows the MFMA precision (NJF_PRECISION_F32 / _F16X2 / _F16F6 / _F16, not a MIXED code) the network that owns the block
+ * is packed for: F32 and F16X2 networks fetch per lane (the two lanes that own a point read adjacent 16-byte pieces), F16
+ * networks likewise from a map of halves (8-channel pieces), F16F6 networks per quad of lanes (csrc/njf_device.h:
+ * add_hoisted_latent).  The njf_pack_* entry points apply it
  * themselves.  Host function, no GPU work; for callers that write hoisted channels directly (flow_mlp's per-image action
  * bias, the transformer head's folded query weights).  Returns a negative error code for an invalid argument. */
 int njf_hoisted_channel(int feature, int block_channels, int precision);

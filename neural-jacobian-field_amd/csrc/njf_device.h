@@ -34,9 +34,16 @@ typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 //                by v_mfma_scale_f32_32x32x64_f8f6f4 -- K = 64 in the issue time of ONE K = 16 f16 instruction (35 vs 34
 //                clocks measured, profiles/r02_probe_mx.txt): 24 matrix instructions per 128x64 weight chunk instead of
 //                48.  Only the 128-wide layers (MBO = 4, NKB = 2 chunks) take this form; the narrow ones stay F16X2.
+//   PREC_F16   : plain fp16 products (round 5; BASELINE config 5 "fp16 MFMA fused-MLP"): weights packed ONCE as single fp16,
+//                activations rounded to fp16 behind the ReLU (one v_cvt_pk_f16_f32 + one packed integer max per PAIR),
+//                v_mfma_f32_32x32x16_f16 with fp32 accumulation -- issue factor 1, no hi/lo split, no correction products.
+//                A reduced-precision mode with its OWN stated tolerance (2^-12 relative rounding of every operand); never the
+//                default, never the headline.  A whole 128x128 layer is ONE 32 KiB chunk (half the barriers), and the hoisted
+//                map it gathers from is stored in fp16 (half the gather traffic).
 #define PREC_F32 0
 #define PREC_F16X2 1
 #define PREC_F16F6 2
+#define PREC_F16 3
 
 // Workgroup = 4 waves (one per SIMD), two workgroups resident per CU: the two waves sharing a SIMD's
 // MFMA pipe belong to DIFFERENT workgroups, so one workgroup's barrier / gather / encoding phases are
@@ -81,7 +88,11 @@ __device__ __forceinline__ float mfma_step(float a, float b, f32x16& c) {
 // `per_pass` chunks.  step() = one barrier: after it the current chunk is resident, and the DMA
 // for the next one has been issued into the other buffer (whose readers all passed the barrier).
 // ------------------------------------------------------------------------------------------
-struct WeightStream {
+// GAP_AT / GAP (compile time: as run-time fields they cost the fp6-corrected kernels, which run at the register limit, 54
+// spilled VGPRs): PREC_F16 networks use the first NJF_RESNET_CHUNKS_F16 chunk slots of their NJF_RESNET_CHUNKS-slot blob (the
+// host-side offsets of the blobs are the same in every precision); chunks at position >= GAP_AT of a pass sit GAP slots
+// further on in the blob.
+struct WeightStreamState {
   __amdgpu_buffer_rsrc_t rsrc;  // the packed blob as a raw buffer (stride 0)
   int per_pass;    // chunks per tile pass
   int total;       // chunks over the whole workgroup lifetime
@@ -103,6 +114,11 @@ struct WeightStream {
   int stamp_i;     // next free slot of this wave's time-stamp log in LDS (-1: this wave does not log)
 #endif
 };
+template <int GAP_AT_, int GAP_>
+struct WeightStreamT : WeightStreamState {
+  static constexpr int GAP_AT = GAP_AT_, GAP = GAP_;
+};
+typedef WeightStreamT<0x7fffffff, 0> WeightStream;
 // Timeline instrumentation of ONE wave (experiment builds only, -DNJF_STAMPS; tools/stamps.py): (tag << 24 | low 24
 // bits of s_memtime) words, logged to a spare LDS area and copied out by the render kernel when the wave retires.
 #ifdef NJF_STAMPS
@@ -126,7 +142,7 @@ __device__ unsigned njf_stamp_out[NJF_STAMP_SLOTS];
 #endif
 #define NJF_DMA_ROUNDS (NJF_CHUNK / (NJF_THREADS * 4))
 
-__device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
+__device__ __forceinline__ void dma_issue(const WeightStreamState& st, int r) {
   // 256 threads x 16 B = 4 KiB per round.  LDS destination is wave-uniform base + lane*16 (hardware), the source is
   // buffer base + wave-uniform byte offset (SGPR) + lane*16 (VGPR).  The MUBUF form (buffer_load_dwordx4 ... lds) is
   // used instead of global_load_lds_dwordx4 on purpose: the latter is FLAT-encoded, and while a FLAT instruction that
@@ -142,7 +158,7 @@ __device__ __forceinline__ void dma_issue(const WeightStream& st, int r) {
 
 // Issue the whole pending job at once (chunk shapes that do not interleave; start of the kernel).
 #ifndef NJF_ASYNC_STREAM
-__device__ __forceinline__ void stream_flush(WeightStream& st) {
+__device__ __forceinline__ void stream_flush(WeightStreamState& st) {
   if (st.dma_next == 0) {
 #pragma unroll
     for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
@@ -151,14 +167,19 @@ __device__ __forceinline__ void stream_flush(WeightStream& st) {
 }
 #endif
 
-__device__ __forceinline__ void dma_job(WeightStream& st, int chunk, int buf, int wave) {
+template <class ST>
+__device__ __forceinline__ void dma_job(ST& st, int chunk, int buf, int wave) {
+  if constexpr (ST::GAP != 0) {
+    if (chunk >= ST::GAP_AT) chunk += ST::GAP;   // (wave-uniform: scalar compare + add)
+  }
   st.dma_soff = chunk * (NJF_CHUNK * 4) + wave * 1024;
   st.dma_dst = njf_lds + buf * NJF_CHUNK + wave * 256;
   st.dma_next = 0;
 }
 
 #ifndef NJF_ASYNC_STREAM
-__device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
+template <class ST>
+__device__ __forceinline__ void stream_begin(ST& st, const float* g, int per_pass, int passes, int wave,
                                              int lane) {
   // raw buffer descriptor: stride 0, num_records in bytes (range check far above any blob), dword 3 = 32-bit data format
   st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7ffffff0, 0x00020000);
@@ -176,7 +197,8 @@ __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, i
 
 // One barrier: after it the current chunk is resident and the other buffer is free (all of its readers passed the
 // barrier); the job that refills it is set up here and issued by the consumer of the current chunk, round by round.
-__device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, int lane) {
+template <class ST>
+__device__ __forceinline__ const float* stream_step(ST& st, int wave, int lane) {
 #ifdef NJF_ABLATE_BARRIER  // experiment builds only: weights stay whatever is in LDS (results are garbage)
   return njf_lds + (st.idx++ & 1) * NJF_CHUNK;
 #endif
@@ -213,15 +235,17 @@ __device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, 
 //      so the bursts do not collide the way they did behind a barrier).
 // Counter k & 7 is reused every eight steps: its value after step k is NJF_WAVES * (k / 8 + 1).
 typedef __attribute__((address_space(3))) unsigned lds_u32;
-__device__ __forceinline__ void stream_issue(WeightStream& st, int in_pass, int buf, int wave) {
+template <class ST>
+__device__ __forceinline__ void stream_issue(ST& st, int in_pass, int buf, int wave) {
   dma_job(st, in_pass, buf, wave);
 #pragma unroll
   for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
   st.dma_next = NJF_DMA_ROUNDS;
 }
-__device__ __forceinline__ void stream_flush(WeightStream&) {}
+__device__ __forceinline__ void stream_flush(WeightStreamState&) {}
 
-__device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, int per_pass, int passes, int wave,
+template <class ST>
+__device__ __forceinline__ void stream_begin(ST& st, const float* g, int per_pass, int passes, int wave,
                                              int lane, int ctr_index = LDS_FLOATS_RENDER - LDS_CTR_FLOATS) {
   st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7ffffff0, 0x00020000);
   st.per_pass = per_pass;
@@ -241,7 +265,8 @@ __device__ __forceinline__ void stream_begin(WeightStream& st, const float* g, i
   __syncthreads();  // chunks 0 and 1 resident, counters zeroed, the bias block the caller loaded is published
 }
 
-__device__ __forceinline__ const float* stream_step(WeightStream& st, int wave, int lane) {
+template <class ST>
+__device__ __forceinline__ const float* stream_step(ST& st, int wave, int lane) {
   const int k = st.idx;
   NJF_STAMP(st, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of chunk k+1 (issued one chunk ago)
@@ -328,6 +353,23 @@ __device__ __forceinline__ void split_pair_u(float x0, float x1, unsigned& hu, u
   asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "v"(x1));
 }
 
+// PREC_F16: two fp32 activations -> one dword of two fp16 (round to nearest even), ReLU'd on request on the PACKED halves:
+// negative fp16 bit patterns are negative 16-bit integers, so one v_pk_max_i16 with 0 clamps both (-0.0 -> +0.0; a NaN
+// with the sign bit set becomes 0, as with relu_bits).  One conversion + one max per PAIR of values.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+template <bool RELU>
+__device__ __forceinline__ unsigned pack_pair_f16(float x0, float x1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 xp = {x0, x1};
+  const f16x2 hp = __builtin_convertvector(xp, f16x2);   // ONE v_cvt_pk_f16_f32 (two scalar casts become 2 v_cvt + v_perm)
+  if constexpr (RELU) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, hp), z));
+  } else {
+    return __builtin_bit_cast(unsigned, hp);
+  }
+}
+
 // Layout of one PREC_F16F6 weight chunk (K = 64 inputs x 128 outputs, NJF_CHUNK floats = 32 KiB, byte offsets):
 //   [F6_HI   , +16 KiB) : hi fp16 A fragments [t][m][lane][8 x f16]   (t = K-step of 16, m = output block of 32)
 //   [F6_P1   , + 8 KiB) : fp6 fragments, bytes 0..15 of each lane's 24  [m][w][lane][16 B]   w = 0: fp6(hi), 1: fp6(lo)
@@ -345,13 +387,13 @@ __device__ __forceinline__ void split_pair_u(float x0, float x1, unsigned& hu, u
 // out[MBO] += W[:, kb range] * in   for the (kb,q) groups stored at `wl` (LDS, packed
 // [kb][q][mb][lane][e]).  RELU applies max(.,0) to the B operand on the fly.
 // ------------------------------------------------------------------------------------------
-template <int PREC, int MBO, int NKB, int KB0, bool RELU, int KBI>
-__device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restrict__ wl, int lane,
+template <int PREC, int MBO, int NKB, int KB0, bool RELU, int KBI, class ST>
+__device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, int lane,
                                           const f32x16 (&in)[KBI], f32x16 (&out)[MBO]) {
   // DMA rounds of the next chunk ride between the MFMA groups of this one (the 128-wide layers: MBO = 4, NKB = 2, eight
   // groups): two rounds behind each of the first four groups, so the last round still has half a chunk to land before
   // the next barrier's vmcnt(0).  Every other shape issues the job up front.
-  constexpr bool SPREAD = MBO == 4 && NKB == 2 && NJF_DMA_ROUNDS == 8;
+  constexpr bool SPREAD = MBO == 4 && (NKB == 2 || (PREC == PREC_F16 && NKB == 4)) && NJF_DMA_ROUNDS == 8;
   if constexpr (!SPREAD) stream_flush(st);
   if constexpr (PREC == PREC_F32) {
     // hipcc schedules this fully unrolled body as groups of 4*MBO MFMAs and re-issues each group's ds_read_b128s
@@ -512,6 +554,71 @@ __device__ __forceinline__ void mma_chunk(WeightStream& st, const float* __restr
     NJF_MFMA6(out[3], wh6_3, bl6, 3, s_w0, sb_l);
 #undef NJF_MFMA6
     __builtin_amdgcn_sched_barrier(0);  // the matrix work of a chunk stays in front of the next chunk's barrier
+  } else if constexpr (PREC == PREC_F16) {
+    // packed [t][m][lane][8 x f16], t = K-step of 16 (lane half kh supplies the 8 k-values 16*KBI*kh + 8*t + i): one MFMA
+    // per (K-step, output block).  Software pipeline per K-step: the MBO A fragments of step t+1 are requested from LDS
+    // (and pinned there with sched_barrier) before the MFMAs of step t; the conversion of step t+1's B operand -- one
+    // v_cvt_pk_f16_f32 and one packed max per pair, 8 VALU instructions per step -- is spread behind them (2 per MFMA: a
+    // 32-clock MFMA hides ~5 single-issue instructions, MI355X_MICROARCH.md).
+    const f16x8* base = (const f16x8*)wl + lane;
+    constexpr int T = NKB * 2;
+    unsigned bc[4], bn[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) bc[p] = pack_pair_f16<RELU>(in[KB0][2 * p], in[KB0][2 * p + 1]);
+    auto op8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], v[2], v[3]}); };
+    if constexpr (MBO == 4) {
+      f16x8 a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f16x8 n[4] = {a[0], a[1], a[2], a[3]};
+        if (t + 1 < T) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
+        }
+        if constexpr (SPREAD) {  // the next chunk's 8 DMA rounds, two behind each of the first four steps
+          if (t < 4) {
+            dma_issue(st, 2 * t);
+            dma_issue(st, 2 * t + 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#ifdef NJF_ABLATE_MFMA
+          asm volatile("" :: "v"(a[m]), "v"(op8(bc)));
+#else
+          out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], op8(bc), out[m], 0, 0, 0);
+#endif
+          if (t + 1 < T) {
+            const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
+            bn[m] = pack_pair_f16<RELU>(in[KB0 + kb2][8 * tt2 + 2 * m], in[KB0 + kb2][8 * tt2 + 2 * m + 1]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = n[i];
+          bc[i] = bn[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f16x8 a[MBO];
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) a[m] = base[(t * MBO + m) * 64];
+        if (t + 1 < T) {
+          const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) bn[p] = pack_pair_f16<RELU>(in[KB0 + kb2][8 * tt2 + 2 * p], in[KB0 + kb2][8 * tt2 + 2 * p + 1]);
+        }
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], op8(bc), out[m], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) bc[p] = bn[p];
+      }
+    }
   } else {
     // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
     // Lane (j,hh) supplies its own registers 8*tt .. 8*tt+7 of block kb as the 8 k-values of step t = 2*kb + tt.
@@ -621,7 +728,7 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
 #else
   // the MFMA form only where the matrix pipe has the headroom (the fp6-corrected chunks); the f16x2 chunks are bound by
   // their 48 matrix instructions (proposal pass: -0.5...1 % with v_add, profiles/r02_ab_variants.txt)
-  constexpr bool VALU = ASSIGN || PREC != PREC_F16F6;
+  constexpr bool VALU = ASSIGN || (PREC != PREC_F16F6 && PREC != PREC_F16);
 #endif
   if constexpr (VALU) {
     const float* b = bl + 16 * MB * hh;
@@ -888,6 +995,47 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
   }
 }
 
+// The fp16-map form (PREC_F16 networks): the hoisted map itself is stored in fp16 (njf_project_* with NJF_PRECISION_F16
+// round the projection's fp32 result once), so a point's footprint is half the bytes and half the load instructions -- the
+// gathers are bound by the texture addresser's request rate (see above).  Within a block of 32*MB channels logical feature
+// f = 16*MB*hh + 16*m + 8*q + e sits at position 32*m + 16*q + 8*hh + e (njf_hoist_position, layout 2): the two lanes that
+// own a point read ADJACENT 16-byte pieces (8 channels each) in the same instruction.  Each value is folded with ONE
+// v_fma_mix_f32 (fp16 source, fp32 weight and accumulator): the bilinear interpolation itself is carried out in fp32.
+template <int MB, int DEPTH = 8>
+__device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restrict__ gz, const PointGeom& g, int hh,
+                                                       f32x16 (&h)[MB]) {
+#ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
+  return;
+#endif
+  Footprint f;
+  point_footprint(g, f);
+  const _Float16* gb = gz + (size_t)g.gofs + 8 * hh;
+  const _Float16* p[4] = {gb + f.t00, gb + f.t01, gb + f.t10, gb + f.t11};
+  const float w[4] = {f.w00, f.w01, f.w10, f.w11};
+  // a batch = (texel t, block m) = 2 loads of 16 bytes (16 channels); DEPTH batches in flight, refilled as they are consumed
+  constexpr int NB = 4 * MB;
+  constexpr int D = DEPTH < NB ? DEPTH : NB;
+  f16x8 v[D][2];
+  auto issue = [&](int b) {
+    const _Float16* src = p[b / MB] + 32 * (b % MB);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v[b % D][q] = *(const f16x8*)(src + 16 * q);
+  };
+#pragma unroll
+  for (int b = 0; b < D; ++b) issue(b);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int t = b / MB, m = b % MB;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[m][8 * q + e] = fmaf((float)v[b % D][q][e], w[t], h[m][8 * q + e]);
+    asm volatile("" : "+v"(h[m]) : : "memory");  // the fmas retire into h before the batch's registers are reloaded
+    if (b + D < NB) issue(b + D);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Which form a network uses follows its MFMA precision (and so does the layout its lin_z columns are packed in,
 // njf_hoist_layout): the quad/MFMA form where the matrix pipe has headroom -- the fp6-corrected networks, measured
 // -3.8 % on the C2 final pass -- and the half/VALU form where it is the busier pipe (F16X2: the proposal pass measured
@@ -900,9 +1048,18 @@ __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz,
 #elif defined(NJF_GATHER_ALWAYS_QUAD)
   add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
 #else
-  if constexpr (PREC == PREC_F16F6) add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
+  if constexpr (PREC == PREC_F16) add_hoisted_latent_f16<MB>((const _Float16*)gz, g, lane >> 5, h);
+  else if constexpr (PREC == PREC_F16F6) add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
   else add_hoisted_latent_half<MB, DEPTH>(gz, g, lane >> 5, h);
 #endif
+}
+
+// Address arithmetic on a hoisted map in ELEMENTS (fp32 maps: floats; PREC_F16 maps: halves).  The fused kernels carry map
+// pointers as `const float*` whatever the element type; every offset goes through here.
+template <int PREC>
+__device__ __forceinline__ const float* map_at(const float* base, size_t elements) {
+  if constexpr (PREC == PREC_F16) return (const float*)((const _Float16*)base + elements);
+  else return base + elements;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1015,8 +1172,8 @@ __device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x1
     }
 }
 
-template <int PREC, bool DUMP = false>
-__device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __restrict__ bias,
+template <int PREC, bool DUMP = false, class ST>
+__device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bias,
                                             const float* __restrict__ gz, const PointGeom& g,
                                             const f32x16 (&pe)[2], int wave, int lane, f32x16 (&out)[1],
                                             ActDump dump = ActDump{nullptr, nullptr, 0}) {
@@ -1080,6 +1237,28 @@ __device__ __forceinline__ void resnet_tile(WeightStream& st, const float* __res
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
+  if constexpr (PREC == PREC_F16) {
+    // 12 chunks: lin_in | (fc_0, fc_1) x 5, a whole 128 x 128 layer per chunk | lin_out
+    static_assert(!DUMP, "the plain-fp16 mode is an inference mode (training forwards dump fp32-class activations)");
+    for (int blk = 0; blk < 5; ++blk) {
+      if (blk < 3) {
+        NJF_STAMP(st, 4);
+        add_hoisted_latent<4, PREC>(map_at<PREC>(gz, blk * 128), g, lane, h);
+        NJF_STAMP(st, 5);
+      }
+      const float* bl = bias + blk * 256;
+      bias_init<4, true, PREC>(bl, hh, net);
+      {
+        const float* wl = stream_step(st, wave, lane);
+        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, h, net);
+      }
+      bias_init<4, false, PREC>(bl + 128, hh, h);
+      {
+        const float* wl = stream_step(st, wave, lane);
+        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
+      }
+    }
+  } else
   for (int blk = 0; blk < 5; ++blk) {
     if (blk < 3) {
       NJF_STAMP(st, 4);  // gather begins (the stamp's own lgkmcnt(0) also ends the previous chunk's MFMA issue)
@@ -1159,8 +1338,8 @@ __device__ __forceinline__ void dump_vec32(float* __restrict__ dst, const f32x16
 
 // colour head (action_decoder_jacobian.py:315-322): one chunk [L0 2048 | L1 4096 | L2 2048],
 // bias (LDS): [L1 (64) | L2 (32)].  cin: hh=0 -> [geo(15), 1], hh=1 -> sh(16).
-template <int PREC, bool DUMP = false>
-__device__ __forceinline__ void color_tile(WeightStream& st, const float* __restrict__ bias, const f32x16 (&cin)[1],
+template <int PREC, bool DUMP = false, class ST>
+__device__ __forceinline__ void color_tile(ST& st, const float* __restrict__ bias, const f32x16 (&cin)[1],
                                            int wave, int lane, f32x16 (&rgb)[1],
                                            ColorDump dump = ColorDump{nullptr, nullptr, 0}) {
   const int hh = lane >> 5;
@@ -1222,8 +1401,8 @@ __device__ __forceinline__ void norm64(const f32x16 (&x)[2], f32x16 (&n)[2]) {
     for (int r = 0; r < 16; ++r) n[m][r] = (x[m][r] - mean) * rstd;
 }
 
-template <int PREC>
-__device__ __forceinline__ void transformer_tile(WeightStream& st, const float* __restrict__ bias,
+template <int PREC, class ST>
+__device__ __forceinline__ void transformer_tile(ST& st, const float* __restrict__ bias,
                                                  const float* __restrict__ gq, const PointGeom& g,
                                                  const f32x16 (&pe)[2], int keys, int wave, int lane, f32x16 (&out)[1]) {
   const int hh = lane >> 5;

@@ -44,7 +44,7 @@ extern "C" const char* njf_error_string(int code) {
 }
 
 static inline bool valid_base_precision(int p) {
-  return p == NJF_PRECISION_F32 || p == NJF_PRECISION_F16X2 || p == NJF_PRECISION_F16F6;
+  return p == NJF_PRECISION_F32 || p == NJF_PRECISION_F16X2 || p == NJF_PRECISION_F16F6 || p == NJF_PRECISION_F16;
 }
 // `precision` of the decoder entry points may name a second precision for the Jacobian head: NJF_PRECISION_MIXED(d, j)
 static inline int density_precision(int p) { return p & 15; }
@@ -52,8 +52,8 @@ static inline int jacobian_precision(int p) { return (p >> 4) ? (p >> 4) - 1 : (
 static inline bool valid_precision(int p) {
   if (p < 0 || p > 0xff || !valid_base_precision(density_precision(p)) || !valid_base_precision(jacobian_precision(p))) return false;
   const int d = density_precision(p), j = jacobian_precision(p);
-  // mixed forms: the two split-precision modes in either order
-  return d == j || (d != NJF_PRECISION_F32 && j != NJF_PRECISION_F32);
+  // mixed forms: the two split-precision modes in either order (the plain-fp16 mode reads an fp16 map: never mixed)
+  return d == j || (d != NJF_PRECISION_F32 && j != NJF_PRECISION_F32 && d != NJF_PRECISION_F16 && j != NJF_PRECISION_F16);
 }
 
 static inline int launch_status() {
@@ -193,6 +193,19 @@ __global__ void pack_layer_kernel(PackLayer L) {
       const int k = 16 * L.kb * kh + 16 * kb + 4 * q + e;                              // logical input slot
       L.dst[i] = pack_source(L, f, k);
     }
+  } else if (L.prec == NJF_PRECISION_F16) {
+    // [t][m][lane][8 x f16]: ONE fp16 per weight (half the bytes of the other forms; the rest of the layer's slot is unused)
+    _Float16* dst = (_Float16*)L.dst;
+    const int n = L.kb * 2 * L.mb * 512;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int i8 = i & 7, lane = (i >> 3) & 63;
+      const int rest = i >> 9;
+      const int m = rest % L.mb, t = rest / L.mb;
+      const int ip = lane & 31, kh = lane >> 5;
+      const int f = 16 * L.mb * ((ip >> 2) & 1) + 16 * m + (ip & 3) + 4 * (ip >> 3);
+      const int k = 16 * L.kb * kh + 8 * t + i8;
+      dst[(size_t)(t * L.mb + m) * 512 + lane * 8 + i8] = (_Float16)pack_source(L, f, k);
+    }
   } else {
     // [t][m][hi|lo][lane][8 x f16]; lane half kh supplies the 8 k-values 16*KB*kh + 8*t + i of K-step t
     _Float16* dst = (_Float16*)L.dst;
@@ -225,12 +238,15 @@ __global__ void fill_kernel(float* p, int n, float v) {
 // add_hoisted_latent (njf_device.h); a network's layout follows its MFMA precision:
 //   0 "half" (F32, F16X2): the two lanes that own a point read adjacent 16-byte pieces
 //   1 "quad" (F16F6): the 16*MB floats of a lane are contiguous, accumulator register 4*e + i <-> piece i, dword e
+//   2 "half, fp16 map" (F16): as 0 with 8-channel pieces
 #if defined(NJF_GATHER_ALWAYS_HALF)  // A/B builds only (tools/ablate.sh)
 __host__ __device__ inline int njf_hoist_layout(int) { return 0; }
 #elif defined(NJF_GATHER_ALWAYS_QUAD)
 __host__ __device__ inline int njf_hoist_layout(int) { return 1; }
 #else
-__host__ __device__ inline int njf_hoist_layout(int precision) { return precision == NJF_PRECISION_F16F6 ? 1 : 0; }
+__host__ __device__ inline int njf_hoist_layout(int precision) {
+  return precision == NJF_PRECISION_F16F6 ? 1 : (precision == NJF_PRECISION_F16 ? 2 : 0);
+}
 #endif
 __host__ __device__ inline int njf_hoist_position(int f, int mb_count, int layout) {
   const int hh = f / (16 * mb_count), r = f % (16 * mb_count);
@@ -238,6 +254,10 @@ __host__ __device__ inline int njf_hoist_position(int f, int mb_count, int layou
   if (layout == 0) {
     const int q = (r >> 2) & 3, e = r & 3;
     return 32 * m + 8 * q + 4 * hh + e;
+  }
+  if (layout == 2) {  // fp16 map: 16-byte pieces of 8 channels, the two lane halves adjacent (add_hoisted_latent_f16)
+    const int q = (r >> 3) & 1, e = r & 7;
+    return 32 * m + 16 * q + 8 * hh + e;
   }
   const int e = (r >> 2) & 3, i = r & 3;
   return 16 * mb_count * hh + 16 * m + 4 * i + e;
@@ -294,12 +314,14 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
   hipStream_t s = (hipStream_t)stream;
   // chunk 0: lin_in 63(+bias) -> 128
   launch_pack(src->lin_in_w, src->lin_in_b, 128, NJF_PE_DIM, 4, 2, 1, P, w_out, nullptr, s);
+  // a 128 x 128 layer is two chunks (K = 64 each), one in the plain-fp16 form: NJF_RESNET_CHUNKS_F16 = 12 of the blob's 22 slots
+  const int per_layer = P == NJF_PRECISION_F16 ? 1 : 2;
   for (int i = 0; i < 5; ++i) {
-    float* base = w_out + (size_t)(1 + 4 * i) * NJF_CHUNK_FLOATS;
+    float* base = w_out + (size_t)(1 + 2 * per_layer * i) * NJF_CHUNK_FLOATS;
     launch_pack(src->fc0_w[i], src->fc0_b[i], 128, 128, 4, 4, 0, P, base, b_out + 256 * i, s);
-    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, P, base + 2 * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s);
+    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, P, base + per_layer * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s);
   }
-  float* last = w_out + (size_t)21 * NJF_CHUNK_FLOATS;
+  float* last = w_out + (size_t)(1 + 10 * per_layer) * NJF_CHUNK_FLOATS;
   launch_pack(src->lin_out_w, src->lin_out_b, src->d_out, 128, 1, 4, 0, P, last, b_out + 1280, s);
   fill_kernel<<<16, 256, 0, s>>>(last + 4096, 4096, 0.f);
   if (wz_out) {
@@ -410,7 +432,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo
 typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
 // KS = k-values per step: 16 is shipped (C2, both maps of a frame: 0.127 -> 0.102 ms against the round-1 form; a 32-wide
 // step, twice the LDS and half the barriers, measured 0.117 ms).
-template <int KS>
+// OUT16: the result (bias added in fp32) is rounded ONCE to fp16 and stored as a [.., n] map of halves -- the hoisted map of
+// the plain-fp16 networks (NJF_PRECISION_F16); the products themselves stay error-compensated.
+template <int KS, bool OUT16 = false>
 __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __restrict__ feats, const float* __restrict__ wz,
                                                             const float* __restrict__ bz, int hw, int n, int ld, int K,
                                                             float* __restrict__ out) {
@@ -492,16 +516,20 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = p0 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < hw) out[((size_t)b * hw + row) * n + c] = acc[a][t][r] + bias;
+        if (row < hw) {
+          if constexpr (OUT16) ((_Float16*)out)[((size_t)b * hw + row) * n + c] = (_Float16)(acc[a][t][r] + bias);
+          else out[((size_t)b * hw + row) * n + c] = acc[a][t][r] + bias;
+        }
       }
   }
 }
 
 static void launch_project(const float* feats, int K, const float* wz, int ld, const float* bz, int batch, int hw, int n,
-                           float* out, int precision, hipStream_t s) {
-  if (precision != NJF_PRECISION_F32) {  // F16X2 and F16F6: both operands split on the fly
+                           float* out, int precision, hipStream_t s, bool out16 = false) {
+  if (precision != NJF_PRECISION_F32) {  // F16X2, F16F6, F16: both operands split on the fly
     dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
-    project_kernel_f16x2<16><<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+    if (out16) project_kernel_f16x2<16, true><<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+    else project_kernel_f16x2<16><<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
   } else {
     dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
     project_kernel<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
@@ -513,7 +541,8 @@ extern "C" int njf_project_features_ld(const float* feats, const float* wz, int 
   if (!feats || !wz || !bz || !out) return NJF_E_NULL;
   if (batch < 1 || hw < 1 || n < 1 || wz_ld < n) return NJF_E_SHAPE;
   if (!valid_base_precision(precision)) return NJF_E_MODE;
-  launch_project(feats, 512, wz, wz_ld, bz, batch, hw, n, out, precision, (hipStream_t)stream);
+  // NJF_PRECISION_F16: `out` is a map of HALVES [batch, hw, n] (include/njf_hip.h)
+  launch_project(feats, 512, wz, wz_ld, bz, batch, hw, n, out, precision, (hipStream_t)stream, precision == NJF_PRECISION_F16);
   return launch_status();
 }
 
@@ -644,6 +673,16 @@ __global__ void __launch_bounds__(256) upsample_add_block_kernel(UpsampleBlockAr
     for (int jx = 0; jx < 4; ++jx) *(f32x4*)(out + ((size_t)jy * a.width + jx) * a.n) = acc[jy][jx];
 }
 
+// fp32 map -> fp16 map (the pyramid route of the plain-fp16 mode: the levels are summed in fp32 and rounded once)
+__global__ void __launch_bounds__(256) map_to_f16_kernel(const float* __restrict__ src, long long quads, _Float16* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= quads) return;
+  const f32x4 v = *(const f32x4*)(src + 4 * i);
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  *(f16x4*)(dst + 4 * i) = o;
+}
+
 // shift s with (h << s, w << s) == (height, width), or 0 if the level is not an exact 2^-s image
 static int pyramid_shift(int h, int w, int height, int width) {
   for (int s = 1; s < 16; ++s)
@@ -674,11 +713,20 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
   u.out = out;
   int row0 = 0;
   float* ws = workspace;
+  // plain-fp16 map: one level is projected straight into the map of halves; a pyramid is summed in fp32 in the FIRST
+  // batch * H0 * W0 * n floats of the workspace (which the caller sizes accordingly, include/njf_hip.h) and rounded once
+  const bool f16map = precision == NJF_PRECISION_F16;
+  float* level0 = out;
+  if (f16map && num_levels > 1) {
+    level0 = ws;
+    ws += (size_t)batch * u.height * u.width * n;
+    u.out = level0;
+  }
   for (int l = 0; l < num_levels; ++l) {
     const int hw = levels[l].height * levels[l].width;
-    float* dst = l == 0 ? out : ws;
+    float* dst = l == 0 ? level0 : ws;
     launch_project(levels[l].feats, levels[l].channels, wz + (size_t)row0 * wz_ld, wz_ld, l == 0 ? bz : nullptr, batch, hw, n,
-                   dst, precision, s);
+                   dst, precision, s, f16map && num_levels == 1);
     if (l > 0) {
       u.src[l - 1] = ws;
       u.h[l - 1] = levels[l].height;
@@ -704,6 +752,10 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
     } else {
       const long long total = (long long)batch * u.height * u.width * (n >> 2);
       upsample_add_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(u);
+    }
+    if (f16map) {
+      const long long quads = (long long)batch * u.height * u.width * (n >> 2);
+      map_to_f16_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, s>>>(level0, quads, (_Float16*)out);
     }
   }
   return launch_status();
@@ -1015,6 +1067,16 @@ extern "C" int njf_generate_rays(const float* coords, int height, int width, con
 // =============================================================================================
 // shared pieces of the fused ray kernels
 // =============================================================================================
+// chunks of a ResnetFC a kernel streams per tile: the plain-fp16 form holds a whole 128 x 128 layer per chunk
+template <int PREC>
+constexpr int resnet_chunks() { return PREC == PREC_F16 ? NJF_RESNET_CHUNKS_F16 : NJF_RESNET_CHUNKS; }
+// ... and where the stream skips the unused slots of the FIRST network's blob (WeightStreamT<GAP_AT, GAP>; the blobs keep
+// their NJF_RESNET_CHUNKS-slot extent in every precision)
+template <int PREC>
+constexpr int resnet_gap_at() { return PREC == PREC_F16 ? NJF_RESNET_CHUNKS_F16 : 0x7fffffff; }
+template <int PREC>
+constexpr int resnet_gap() { return PREC == PREC_F16 ? NJF_RESNET_CHUNKS - NJF_RESNET_CHUNKS_F16 : 0; }
+
 struct RayCommon {
   const float* origins;
   const float* directions;
@@ -1171,7 +1233,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
 #ifdef NJF_ASYNC_STREAM
   stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane, LDS_FLOATS_PROPOSAL - LDS_CTR_FLOATS);
 #else
-  stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane);
+  stream_begin(st, a.w_pack, resnet_chunks<PREC>(), tiles, wave, lane);
 #endif
 #ifdef NJF_STAMPS_PROPOSAL
   const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
@@ -1186,7 +1248,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
               oz = a.rc.origins[3 * (size_t)rayc + 2];
   const float dx = a.rc.directions[3 * (size_t)rayc], dy = a.rc.directions[3 * (size_t)rayc + 1],
               dz = a.rc.directions[3 * (size_t)rayc + 2];
-  const float* gz = a.rc.gmap.data + (size_t)b * a.rc.gmap.height * a.rc.gmap.width * a.rc.gmap.stride + a.gmap_offset;
+  const float* gz = map_at<PREC>(a.rc.gmap.data, (size_t)b * a.rc.gmap.height * a.rc.gmap.width * a.rc.gmap.stride + a.gmap_offset);
   const float* bins = a.bins_in + (a.bins_per_ray ? (size_t)rayc * (a.s_in + 1) : 0);
   float* sc = njf_lds + LDS_SCRATCH_PROPOSAL + wave * LDS_SCRATCH_PER_WAVE;
   const float* bias = njf_lds + LDS_BIAS;
@@ -1254,8 +1316,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
 // JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
 // DUMP: 0 = inference, 1 = dump the Jacobian ResnetFC (action-mode training), 2 = dump the density ResnetFC and the
 // colour head (perception-mode training); `dump` addresses the dumped net, `cdump` the colour head.
-template <int PREC, int DUMP>
-__device__ __forceinline__ float density_stage(WeightStream& st, const float* __restrict__ gz_d, const PointGeom& g, int wave,
+template <int PREC, int DUMP, class ST>
+__device__ __forceinline__ float density_stage(ST& st, const float* __restrict__ gz_d, const PointGeom& g, int wave,
                                                int lane, f32x16 (&geo)[1], ActDump dump) {
   const int j = lane & 31, hh = lane >> 5;
   f32x16 pe[2];
@@ -1264,8 +1326,8 @@ __device__ __forceinline__ float density_stage(WeightStream& st, const float* __
   return expf(__shfl(geo[0][15], j, 64) - 1.0f);
 }
 
-template <int PREC, int DUMP>
-__device__ __forceinline__ void color_stage(WeightStream& st, const f32x16 (&geo)[1], float dirx, float diry, float dirz,
+template <int PREC, int DUMP, class ST>
+__device__ __forceinline__ void color_stage(ST& st, const f32x16 (&geo)[1], float dirx, float diry, float dirz,
                                             int wave, int lane, float (&rgb)[3], ColorDump cdump) {
   const int j = lane & 31, hh = lane >> 5;
   // The harmonics depend on the ray only, so the compiler computes them once in front of the tile loop -- and, with every
@@ -1286,8 +1348,8 @@ __device__ __forceinline__ void color_stage(WeightStream& st, const f32x16 (&geo
   }
 }
 
-template <int JKIND, int PREC, int DUMP>
-__device__ __forceinline__ void jacobian_stage(WeightStream& st, const float* __restrict__ gz_j, const PointGeom& g,
+template <int JKIND, int PREC, int DUMP, class ST>
+__device__ __forceinline__ void jacobian_stage(ST& st, const float* __restrict__ gz_j, const PointGeom& g,
                                                const float* __restrict__ action, int action_dim, int wave, int lane,
                                                f32x16 (&jac)[1], float (&flow)[3], ActDump dump) {
   const int hh = lane >> 5;
@@ -1381,7 +1443,7 @@ __device__ __forceinline__ void place_sample(float b0, float b1, float near, flo
 template <int JKIND, int PREC, int DUMP = 0, bool AF = true, int PRECJ = PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   constexpr bool WITH_J = JKIND != 0;
-  constexpr int J_CHUNKS = JKIND == 1 ? NJF_RESNET_CHUNKS : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
+  constexpr int J_CHUNKS = JKIND == 1 ? resnet_chunks<PRECJ>() : (JKIND == 2 ? NJF_TRANSFORMER_CHUNKS : 0);
   constexpr int J_BIAS = JKIND == 1 ? NJF_RESNET_B_FLOATS : NJF_TRANSFORMER_B_FLOATS;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1397,8 +1459,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   load_bias_block(a.b_c, NJF_COLOR_B_FLOATS, NJF_RESNET_B_FLOATS);
   if (WITH_J) load_bias_block(a.b_j, J_BIAS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
   const int tiles = (S + 31) >> 5;
-  WeightStream st;
-  stream_begin(st, a.w_all, NJF_RESNET_CHUNKS + 1 + J_CHUNKS, tiles, wave, lane);
+  WeightStreamT<resnet_gap_at<PREC>(), resnet_gap<PREC>()> st;
+  stream_begin(st, a.w_all, resnet_chunks<PREC>() + 1 + J_CHUNKS, tiles, wave, lane);
 #ifdef NJF_STAMPS
 #ifdef NJF_STAMPS_PROPOSAL
   const bool stamping = false;  // that build logs a wave of the proposal kernel instead
@@ -1417,8 +1479,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   const float dx = a.rc.directions[3 * (size_t)rayc], dy = a.rc.directions[3 * (size_t)rayc + 1],
               dz = a.rc.directions[3 * (size_t)rayc + 2];
   const size_t gbase = (size_t)b * a.rc.gmap.height * a.rc.gmap.width * a.rc.gmap.stride;
-  const float* gz_d = a.rc.gmap.data + gbase + a.goff_d;
-  const float* gz_j = a.rc.gmap.data + gbase + a.goff_j;
+  const float* gz_d = map_at<PREC>(a.rc.gmap.data, gbase + a.goff_d);
+  const float* gz_j = map_at<PRECJ>(a.rc.gmap.data, gbase + a.goff_j);
   const float* bins = a.bins + (size_t)rayc * (S + 1);
   const int A = a.rc.cams.action_dim;
   const float* action = a.rc.cams.action ? a.rc.cams.action + (size_t)b * A : nullptr;
@@ -1786,10 +1848,10 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   if (MODE >= 1) load_bias_block(a.b_c, NJF_COLOR_B_FLOATS, NJF_RESNET_B_FLOATS);
   if (MODE == 2) load_bias_block(a.b_j, NJF_RESNET_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
   if (MODE == 3) load_bias_block(a.b_j, NJF_TRANSFORMER_B_FLOATS, NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS);
-  WeightStream st;
+  WeightStreamT<resnet_gap_at<PREC>(), resnet_gap<PREC>()> st;
   stream_begin(st, a.w_all,
-               MODE == 0 ? NJF_RESNET_CHUNKS
-                         : NJF_RESNET_CHUNKS + 1 + (MODE == 2 ? NJF_RESNET_CHUNKS : (MODE == 3 ? NJF_TRANSFORMER_CHUNKS : 0)),
+               MODE == 0 ? resnet_chunks<PREC>()
+                         : resnet_chunks<PREC>() + 1 + (MODE == 2 ? resnet_chunks<PRECJ>() : (MODE == 3 ? NJF_TRANSFORMER_CHUNKS : 0)),
                1, wave, lane);
   CamCtx cam;
   load_ctx(a.cams.ctxt_w2c, a.cams.ctxt_k, b, cam);
@@ -1802,7 +1864,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   if (MODE == 0) {
     f32x16 pe[2], out[1];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-    resnet_tile<PREC>(st, bias, a.gmap.data + a.goff_d, g, pe, wave, lane, out);
+    resnet_tile<PREC>(st, bias, map_at<PREC>(a.gmap.data, a.goff_d), g, pe, wave, lane, out);
     if (ok && hh == 0 && a.density) a.density[p] = expf(out[0][0] - 1.0f);
   } else {
     float dx = 0.f, dy = 0.f, dz = 1.f;
@@ -1817,7 +1879,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
     const ActDump nodump{nullptr, nullptr, 0};
     // stage by stage, each result stored before the next network starts (nothing but the point itself stays live)
     f32x16 geo[1];
-    const float sigma = density_stage<PREC, 0>(st, a.gmap.data + a.goff_d, g, wave, lane, geo, nodump);
+    const float sigma = density_stage<PREC, 0>(st, map_at<PREC>(a.gmap.data, a.goff_d), g, wave, lane, geo, nodump);
     if (ok && hh == 0) {
       if (a.density) a.density[p] = sigma;
       if (a.geo) {
@@ -1838,7 +1900,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
       f32x16 jac[1];
       float flow[3];
       // NOTE: `action` is per lane here (tiles may straddle batch elements)
-      jacobian_stage<JK, PRECJ, 0>(st, a.gmap.data + a.goff_j, g, action, A, wave, lane, jac, flow, nodump);
+      jacobian_stage<JK, PRECJ, 0>(st, map_at<PRECJ>(a.gmap.data, a.goff_j), g, action, A, wave, lane, jac, flow, nodump);
       if (ok) {
         if (hh == 0 && a.flow) {
           a.flow[3 * (size_t)p] = flow[0];
@@ -2510,8 +2572,10 @@ static int check_common(const float* origins, const float* directions, int rays_
   return NJF_OK;
 }
 
-static int check_gmap(const NjfFeatureMap* gmap, int off, int channels = NJF_ZDIM) {
-  if (off < 0 || (off & 3) || (gmap->stride & 3) || off + channels > gmap->stride) return NJF_E_GMAP;
+// `precision`: of the network that reads the block (a plain-fp16 network reads a map of halves: 16-byte pieces = 8 elements)
+static int check_gmap(const NjfFeatureMap* gmap, int off, int channels = NJF_ZDIM, int precision = NJF_PRECISION_F32) {
+  const int mask = precision == NJF_PRECISION_F16 ? 7 : 3;
+  if (off < 0 || (off & mask) || (gmap->stride & mask) || off + channels > gmap->stride) return NJF_E_GMAP;
   return NJF_OK;
 }
 
@@ -2572,25 +2636,31 @@ static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, 
   return launch_status();
 }
 
-// run `f(std::integral_constant<int, PREC_*>)` for the MFMA precision selected at run time
-template <typename F>
+// run `f(std::integral_constant<int, PREC_*>)` for the MFMA precision selected at run time.  TRAIN: the dispatch of the
+// training forwards (activation dumps), which do not exist in the plain-fp16 mode -- NJF_E_MODE there.
+template <bool TRAIN = false, typename F>
 static int with_precision(int precision, F&& f) {
 #ifdef NJF_DEV_ONLY_PREC  // development builds only (static ISA checks of one precision: a third of the compile time)
-  return f(std::integral_constant<int, NJF_DEV_ONLY_PREC>{});
+  if constexpr (TRAIN && NJF_DEV_ONLY_PREC == PREC_F16) return NJF_E_MODE;
+  else return f(std::integral_constant<int, NJF_DEV_ONLY_PREC>{});
 #else
   if (precision == NJF_PRECISION_F16X2) return f(std::integral_constant<int, PREC_F16X2>{});
   if (precision == NJF_PRECISION_F16F6) return f(std::integral_constant<int, PREC_F16F6>{});
+  if (precision == NJF_PRECISION_F16) {
+    if constexpr (TRAIN) return NJF_E_MODE;
+    else return f(std::integral_constant<int, PREC_F16>{});
+  }
   return f(std::integral_constant<int, PREC_F32>{});
 #endif
 }
 // ... and `f(P_density, P_jacobian)` for the decoder kernels, whose Jacobian head may run in the other split precision
-template <typename F>
+template <bool TRAIN = false, typename F>
 static int with_precisions(int precision, F&& f) {
   const int d = density_precision(precision), j = jacobian_precision(precision);
 #ifdef NJF_DEV_ONLY_PREC
-  return f(std::integral_constant<int, NJF_DEV_ONLY_PREC>{}, std::integral_constant<int, NJF_DEV_ONLY_PREC>{});
+  return with_precision<TRAIN>(d, [&](auto P) { return f(P, P); });
 #else
-  if (d == j) return with_precision(d, [&](auto P) { return f(P, P); });
+  if (d == j) return with_precision<TRAIN>(d, [&](auto P) { return f(P, P); });
   if (d == NJF_PRECISION_F16F6) return f(std::integral_constant<int, PREC_F16F6>{}, std::integral_constant<int, PREC_F16X2>{});
   return f(std::integral_constant<int, PREC_F16X2>{}, std::integral_constant<int, PREC_F16F6>{});
 #endif
@@ -2609,7 +2679,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   if (!w_pack || !b_pack || !bins_in || !u || !bins_out) return NJF_E_NULL;
   if (s_in < 1 || s_in > 256 || s_out < 1) return NJF_E_SAMPLES;
   if (!valid_base_precision(precision)) return NJF_E_MODE;
-  if ((rc = check_gmap(gmap, gmap_offset))) return rc;
+  if ((rc = check_gmap(gmap, gmap_offset, NJF_ZDIM, precision))) return rc;
   ProposalArgs a;
   a.rc = RayCommon{origins, directions, rays_per_batch, rays_per_batch * cams->batch, *cams, *gmap};
   a.gmap_offset = gmap_offset;
@@ -2629,7 +2699,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   if (dump != nullptr && dump->act != nullptr) {  // training forward: inputs of the proposal net's backward pass
     if (!dump->pe || !dump->foot_idx || !dump->foot_w) return NJF_E_NULL;
     a.dump = *dump;
-    return with_precision(precision, [&](auto P) {
+    return with_precision<true>(precision, [&](auto P) {
       return launch_fused(proposal_kernel<NJF_P, true>, a, a.rc.total_rays, (hipStream_t)stream, LDS_FLOATS_PROPOSAL);
     });
   }
@@ -2641,13 +2711,13 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
 // The decoder blobs must be one allocation laid out [density | colour | jacobian] (what
 // njf_pack_* write when given consecutive destinations); the launcher verifies contiguity.
 static int check_jacobian(int kind, const NjfCameras* cams, const NjfFeatureMap* gmap, int goff_j, const float* w_j,
-                          const float* b_j) {
+                          const float* b_j, int precision) {
   if (kind == NJF_JACOBIAN_NONE) return NJF_OK;
   if (kind != NJF_JACOBIAN_MLP && kind != NJF_JACOBIAN_TRANSFORMER) return NJF_E_MODE;
   if (!w_j || !b_j) return NJF_E_NULL;
   const int max_a = kind == NJF_JACOBIAN_MLP ? NJF_MAX_ACTION_DIM : 8;  // transformer: 8 key slots per head
   if (cams->action_dim < 1 || cams->action_dim > max_a) return NJF_E_ACTION_DIM;
-  return check_gmap(gmap, goff_j, kind == NJF_JACOBIAN_MLP ? NJF_ZDIM : NJF_QDIM);
+  return check_gmap(gmap, goff_j, kind == NJF_JACOBIAN_MLP ? NJF_ZDIM : NJF_QDIM, jacobian_precision(precision));
 }
 
 static int check_contiguous(const float* w_d, const float* w_c, const float* w_j, bool with_j) {
@@ -2667,8 +2737,8 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   if (!w_density || !b_density || !w_color || !b_color || !bins || !out) return NJF_E_NULL;
   if (samples < 1) return NJF_E_SAMPLES;
   if (!valid_precision(precision)) return NJF_E_MODE;
-  if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
-  if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
+  if ((rc = check_gmap(gmap, gmap_offset_density, NJF_ZDIM, density_precision(precision)))) return rc;
+  if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian, precision))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
   RenderArgs a;
@@ -2691,16 +2761,16 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
     if (!out->jac_pe || !out->foot_idx || !out->foot_w) return NJF_E_NULL;
     if (jacobian_kind == NJF_JACOBIAN_MLP) {
       if (!out->jac_act) return NJF_E_NULL;
-      return with_precisions(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<1, NJF_P, 1, true, NJF_PJ>, a, n, s); });
+      return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<1, NJF_P, 1, true, NJF_PJ>, a, n, s); });
     }
     if (out->jac_act) return NJF_E_MODE;
-    return with_precisions(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<2, NJF_P, 1, true, NJF_PJ>, a, n, s); });
+    return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<2, NJF_P, 1, true, NJF_PJ>, a, n, s); });
   }
   if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
     if (!out->jac_pe || !out->foot_idx || !out->foot_w || !out->col_in || !out->col_act) return NJF_E_NULL;
     if (jacobian_kind == NJF_JACOBIAN_NONE)
-      return with_precision(density_precision(precision), [&](auto P) { return launch_fused(render_kernel<0, NJF_P, 2>, a, n, s); });
-    return with_precisions(precision, [&](auto P, auto PJ) {
+      return with_precision<true>(density_precision(precision), [&](auto P) { return launch_fused(render_kernel<0, NJF_P, 2>, a, n, s); });
+    return with_precisions<true>(precision, [&](auto P, auto PJ) {
       if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, NJF_P, 2, true, NJF_PJ>, a, n, s);
       return launch_fused(render_kernel<2, NJF_P, 2, true, NJF_PJ>, a, n, s);
     });
@@ -2726,7 +2796,7 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   if (mode != 0 && mode != 1) return NJF_E_MODE;
   if (!valid_precision(precision)) return NJF_E_MODE;
   int rc;
-  if ((rc = check_gmap(gmap, gmap_offset_density))) return rc;
+  if ((rc = check_gmap(gmap, gmap_offset_density, NJF_ZDIM, density_precision(precision)))) return rc;
   // a point carries the float index of its batch element in 32 bits (PointGeom::gofs): maps up to 16 GiB
   if ((long long)cams->batch * gmap->height * gmap->width * gmap->stride > 0xffffffffLL) return NJF_E_SHAPE;
   PointsArgs a;
@@ -2752,7 +2822,7 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   if (mode == 0)
     return with_precision(density_precision(precision), [&](auto P) { return launch_fused(points_kernel<0, NJF_P>, a, tiles, s); });
   if (!w_color || !b_color) return NJF_E_NULL;
-  if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian))) return rc;
+  if ((rc = check_jacobian(jacobian_kind, cams, gmap, gmap_offset_jacobian, w_jacobian, b_jacobian, precision))) return rc;
   const bool with_j = jacobian_kind != NJF_JACOBIAN_NONE;
   if ((rc = check_contiguous(w_density, w_color, w_jacobian, with_j))) return rc;
   if (!with_j)

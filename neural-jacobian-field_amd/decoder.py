@@ -128,7 +128,7 @@ class _HoistCache:
         key = (features._version, tuple(features.shape), wversion, precision)
         if features is not self.features or key != self.key:
             b, _, hf, wf = features.shape
-            gmap = torch.empty(b, hf, wf, wz.shape[1], dtype=torch.float32, device=features.device)
+            gmap = torch.empty(b, hf, wf, wz.shape[1], dtype=hip.map_dtype(precision), device=features.device)
             if isinstance(features, FeaturePyramid):
                 hip.project_pyramid(features.levels, wz, bz, gmap, precision=precision)
             else:

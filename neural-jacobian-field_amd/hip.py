@@ -29,7 +29,11 @@ JACOBIAN_NONE, JACOBIAN_MLP, JACOBIAN_TRANSFORMER = 0, 1, 2
 # MFMA precision of the fused MLPs (include/njf_hip.h: NJF_PRECISION_*).  "f16x2" = fp32 operands split into two
 # fp16 (hi+lo), three f16 MFMAs per product block, fp32 accumulation: fp32-class accuracy, ~5x less matrix time.
 # "f16f6" = the same hi*hi product, the two 2^-11-sized correction products in block-scaled fp6 (4x the f16 MFMA rate).
-PRECISIONS = {"f32": 0, "f16x2": 1, "f16f6": 2}
+# "f16" = PLAIN fp16 products (round 5; BASELINE config 5's "fp16 MFMA fused-MLP"): weights and layer inputs rounded to fp16, fp32
+# accumulation, hoisted maps stored in fp16 -- a reduced-precision inference mode with its own stated tolerance (DESIGN.md
+# section 5), selectable, never the default.
+PRECISIONS = {"f32": 0, "f16x2": 1, "f16f6": 2, "f16": 3}
+REDUCED_PRECISIONS = ("f16",)   # modes that are NOT held to the fp32 parity bound
 # Default: "f16f6" for the final pass with the proposal networks on "f16x2" (Model.set_precision's policy).  It passes the
 # same parity suite as the exact-fp32 path with the same bounds (profiles/r02_parity_margins.json).
 DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16f6")
@@ -53,7 +57,7 @@ def precision_code(precision: Optional[str], jacobian_precision: Optional[str] =
     if jacobian_precision is not None and jacobian_precision != name:
         if jacobian_precision not in PRECISIONS:
             raise ValueError(f"njf_hip: unknown precision {jacobian_precision!r}; choose from {sorted(PRECISIONS)}")
-        if "f32" in (name, jacobian_precision):
+        if "f32" in (name, jacobian_precision) or "f16" in (name, jacobian_precision):
             raise ValueError("njf_hip: mixed decoder precisions exist for the two split-precision modes only")
         code |= (PRECISIONS[jacobian_precision] + 1) << 4
     return code
@@ -204,14 +208,19 @@ class _RecordScope:
         return False
 
 
-def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
+def map_dtype(precision: Optional[str]) -> torch.dtype:
+    """Element type of the hoisted map a network of MFMA ``precision`` reads (include/njf_hip.h: NJF_PRECISION_F16)."""
+    return torch.float16 if (DEFAULT_PRECISION if precision is None else precision) == "f16" else torch.float32
+
+
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype: torch.dtype = torch.float32) -> Optional[int]:
     if t is None:
         return None
     problem = None
     if not t.is_cuda:
         problem = f"njf_hip: {name} must live on the GPU (got {t.device}); there is no CPU path"
-    elif t.dtype != torch.float32:
-        problem = f"njf_hip: {name} must be float32 (got {t.dtype})"
+    elif t.dtype != dtype:
+        problem = f"njf_hip: {name} must be {str(dtype).replace('torch.', '')} (got {t.dtype})"
     elif not t.is_contiguous():
         problem = f"njf_hip: {name} must be contiguous"
     if problem is not None:
@@ -282,9 +291,12 @@ def make_cameras(ctxt_w2c, ctxt_k, z_near, z_far, trgt_w2c=None, trgt_k=None, ac
 
 
 def make_feature_map(gmap: torch.Tensor) -> FeatureMap:
-    """gmap: [B, Hf, Wf, C] channels-last hoisted map."""
+    """gmap: [B, Hf, Wf, C] channels-last hoisted map (float32; float16 for the networks of the plain-fp16 mode -- the
+    precision of the forward call that reads it must agree, which the callers below guarantee by construction)."""
+    if gmap.dtype not in (torch.float32, torch.float16):
+        raise ValueError(f"njf_hip: gmap must be float32 or float16 (got {gmap.dtype})")
     with _RecordScope() as scope:
-        fm = FeatureMap(_ptr(gmap, "gmap"), gmap.shape[1], gmap.shape[2], gmap.shape[3])
+        fm = FeatureMap(_ptr(gmap, "gmap", gmap.dtype), gmap.shape[1], gmap.shape[2], gmap.shape[3])
         scope.close(fm)
     fm._keep = gmap
     return fm
@@ -343,13 +355,13 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], kind: int, w
 
 def project_features(feats: torch.Tensor, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor,
                      precision: Optional[str] = None) -> None:
-    """feats [B,512,Hf,Wf]; wz [512,N]; bz [N]; out [B,Hf,Wf,N]."""
+    """feats [B,512,Hf,Wf]; wz [512,N]; bz [N]; out [B,Hf,Wf,N] (float16 for precision "f16": ``map_dtype``)."""
     b, k, hf, wf = feats.shape
     n = wz.shape[1]
     if k != 512 or wz.shape[0] != 512 or tuple(out.shape) != (b, hf, wf, n):
         raise ValueError("njf_hip: project_features shape mismatch")
-    _launch("njf_project_features_ld", load_library().njf_project_features_ld, _ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n, _ptr(out),
-                                                  precision_code(precision))
+    _launch("njf_project_features_ld", load_library().njf_project_features_ld, _ptr(feats), _ptr(wz), n, _ptr(bz), b, hf * wf, n,
+            _ptr(out, "out", map_dtype(precision)), precision_code(precision))
 
 
 def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tensor, precision: Optional[str] = None) -> None:
@@ -367,11 +379,12 @@ def project_pyramid(levels, wz: torch.Tensor, bz: torch.Tensor, out: torch.Tenso
         lv = lv.contiguous()
         keep.append(lv)
         arr[i] = PyramidLevel(_ptr(lv), lv.shape[1], lv.shape[2], lv.shape[3])
-        if i > 0:
+        if i > 0 or (map_dtype(precision) == torch.float16 and len(levels) > 1):
+            # (plain-fp16 map of a pyramid: the levels are summed in fp32 in the workspace and rounded once)
             ws_floats += b * lv.shape[2] * lv.shape[3] * n
     workspace = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=out.device)
-    _launch("njf_project_pyramid", load_library().njf_project_pyramid, arr, len(levels), _ptr(wz), n, _ptr(bz), b, n, _ptr(out), _ptr(workspace),
-                                              precision_code(precision))
+    _launch("njf_project_pyramid", load_library().njf_project_pyramid, arr, len(levels), _ptr(wz), n, _ptr(bz), b, n,
+            _ptr(out, "out", map_dtype(precision)), _ptr(workspace), precision_code(precision))
 
 
 _hoist_order_cache: Dict[tuple, torch.Tensor] = {}

@@ -229,7 +229,7 @@ class Model(nn.Module):
         if type(self.decoder).hoisted_map is not ActionDecoderJacobian.hoisted_map:
             return None
         precs = {n.precision for n in nets}
-        if "f32" in precs and len(precs) > 1:
+        if ("f32" in precs or "f16" in precs) and len(precs) > 1:   # (another projection kernel / another map element type)
             return None
         for n in nets:
             n.packed()
@@ -245,7 +245,7 @@ class Model(nn.Module):
         if c["features"] is not features or c.get("key") != key:
             from .encoder import FeaturePyramid
             b, _, hf, wf = features.shape
-            gmap = torch.empty(b, hf, wf, c["wz"].shape[1], dtype=torch.float32, device=c["wz"].device)
+            gmap = torch.empty(b, hf, wf, c["wz"].shape[1], dtype=hip.map_dtype(self.decoder.precision), device=c["wz"].device)
             if isinstance(features, FeaturePyramid):
                 hip.project_pyramid(features.levels, c["wz"], c["bz"], gmap, precision=self.decoder.precision)
             else:
@@ -281,7 +281,11 @@ class Model(nn.Module):
         * ``"f32"``   exact fp32 products (v_mfma_f32_32x32x2_f32);
         * ``"f16x2"`` fp32 operands split into fp16 hi + lo, hi*hi + hi*lo + lo*hi, fp32 accumulate;
         * ``"f16f6"`` the same hi*hi, the two 2^-11-sized correction products in block-scaled fp6 -- half the matrix time
-          of f16x2 at ~1.5e-5 relative error per network.
+          of f16x2 at ~1.5e-5 relative error per network;
+        * ``"f16"``   PLAIN fp16 products (weights and layer inputs rounded to fp16, fp32 accumulation, fp16 hoisted maps):
+          a reduced-precision INFERENCE mode with its own stated tolerance (~1e-3 norm-wise per network output, DESIGN.md
+          section 5; BASELINE config 5), proposal networks included unless ``proposal_precision`` says otherwise.  Never
+          the default; training forwards refuse it.
 
         ``precision`` applies to the networks of the final pass (density, colour, Jacobian / flow head; the head can be
         given its own split precision through ``jacobian_precision``).  ``proposal_precision`` applies to the proposal
@@ -532,6 +536,11 @@ class Model(nn.Module):
         self._maybe_check_range(camera_input, rendering_input, robot_input)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training
+            reduced = [m.precision for m in (self.decoder, *self.proposal_networks) if m.precision in hip.REDUCED_PRECISIONS]
+            if reduced:
+                raise RuntimeError(f"the {reduced[0]!r} MFMA precision is an inference mode (no training forward exists for it: "
+                                   "activations rounded to fp16 are not the inputs a backward pass may use); call "
+                                   "model.set_precision('f16f6') / ('f32') for training, or run under torch.no_grad()")
             if self.cfg.action_decoder.name == "flow_mlp" and any(
                     n.startswith("decoder.flow_head") for n in training.trainable_names(self)):
                 raise NotImplementedError("flow_mlp is an inference-only decoder on the fused path: its flow head has no "

@@ -45,8 +45,46 @@ def _sub(params: Params, prefix: str) -> Params:
     return {k[n:]: v for k, v in params.items() if k.startswith(prefix)}
 
 
+# Operand-rounding MODEL of the build's plain-fp16 MFMA mode (NJF_PRECISION_F16) -- test infrastructure like the rest of this
+# file, NOT part of the reference's algorithm: with ``operand_rounding("f16")`` every Linear rounds its input and its weight to
+# fp16 (round to nearest even) and accumulates / adds the bias in the working precision, exactly the roundings that mode
+# performs; the three ``lin_z`` layers instead round their OUTPUT (the hoisted map G = lin_z(F) is what the build stores in
+# fp16), and the two layers whose bias the build folds into a weight column (lin_in, colour layer 0) round that bias too.  Its
+# distance from the float64 evaluation is the error level a CORRECT plain-fp16 evaluation has on a given case: the yardstick
+# ("floor") of the reduced-precision parity rows (oracle/parity_harness.py).
+_OPERAND_ROUNDING: Optional[str] = None
+
+
+class operand_rounding:
+    def __init__(self, mode: Optional[str]):
+        if mode not in (None, "f16"):
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        global _OPERAND_ROUNDING
+        self.prev, _OPERAND_ROUNDING = _OPERAND_ROUNDING, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_ROUNDING
+        _OPERAND_ROUNDING = self.prev
+        return False
+
+
+def _r16(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else t.to(torch.float16).to(t.dtype)
+
+
 def _affine(params: Params, name: str, x: Tensor) -> Tensor:
-    return F.linear(x, params[name + ".weight"], params.get(name + ".bias"))
+    w, b = params[name + ".weight"], params.get(name + ".bias")
+    if _OPERAND_ROUNDING == "f16":
+        if name.startswith("lin_z."):
+            return _r16(F.linear(x, w, b))
+        if name == "lin_in" or name == "color_head.0":
+            b = _r16(b)
+        return F.linear(_r16(x), _r16(w), b)
+    return F.linear(x, w, b)
 
 
 def _with_one(p: Tensor) -> Tensor:

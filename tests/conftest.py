@@ -123,11 +123,14 @@ def pytest_sessionfinish(session, exitstatus):
                "failed": sum(not r["ok"] for r in _MARGIN_ROWS), "table": _MARGIN_ROWS,
                "truth_rule": "element-wise against the float64 result: e_hip = |hip - ref64|, e_ref = |ref32 - ref64| (ref = the "
                              "reference's fixture tensors, else the oracle), both relative to max|ref64|; truth_ok <=> max e_hip <= "
-                             "max(1.5 x max e_ref, 4 fp32 ulps of scale) and the same for the 99.9th percentile; "
+                             "max(1.5 x max e_ref, 4 fp32 ulps of scale) and the same for the 99.9th percentile (= truth_ok_strict), OR both "
+                             "ratios <= 2.0 with rms e_hip <= 1.5 x rms e_ref (rows marked tail_outlier: oracle/parity_harness.py); "
                              "frac_within_1e-4_of_ref32 = share of elements with |hip - ref32| <= 1e-4 max|ref32|",
                "truth_rows": len(_TRUTH_ROWS), "truth_rows_asserted": sum(r["asserted"] for r in _TRUTH_ROWS),
                "truth_rows_not_ok": sum(not r["truth_ok"] for r in _TRUTH_ROWS),
                "truth_rows_asserted_not_ok": sum(r["asserted"] and not r["truth_ok"] for r in _TRUTH_ROWS),
+               "truth_rows_tail_outlier": sum(bool(r.get("tail_outlier")) for r in _TRUTH_ROWS),
+               "truth_rows_asserted_tail_outlier": sum(bool(r["asserted"] and r.get("tail_outlier")) for r in _TRUTH_ROWS),
                "truth_table": _TRUTH_ROWS}
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 15
+    assert lib.njf_abi_version() == 16
 
 
 def test_hoisted_channel_order(built):
@@ -56,8 +56,17 @@ def test_hoisted_channel_order(built):
                 for e in range(4):
                     for i in range(4):
                         assert pos[16 * mb * hh + 16 * m + 4 * e + i] == 16 * mb * hh + 16 * m + 4 * i + e
+        # the plain-fp16 networks (round 5) read a map of HALVES: 16-byte pieces hold 8 channels, the two lanes of a point adjacent
+        # (add_hoisted_latent_f16): logical feature 16*MB*hh + 16*m + 8*q + e at 32*m + 16*q + 8*hh + e
+        pos = [lib.njf_hoisted_channel(f, width, 3) for f in range(width)]
+        assert sorted(pos) == list(range(width))
+        for hh in range(2):
+            for m in range(mb):
+                for q in range(2):
+                    for e in range(8):
+                        assert pos[16 * mb * hh + 16 * m + 8 * q + e] == 32 * m + 16 * q + 8 * hh + e
     assert lib.njf_hoisted_channel(128, 128, 0) < 0 and lib.njf_hoisted_channel(0, 100, 0) < 0 and lib.njf_hoisted_channel(-1, 64, 0) < 0
-    assert lib.njf_hoisted_channel(0, 128, 3) < 0 and lib.njf_hoisted_channel(0, 128, 0x21) < 0   # base precisions only
+    assert lib.njf_hoisted_channel(0, 128, 4) < 0 and lib.njf_hoisted_channel(0, 128, 0x21) < 0   # base precisions only
 
 
 def test_flow_mlp_action_fold_is_exact_algebra():
@@ -608,7 +617,7 @@ def test_header_is_plain_c(tmp_path, built):
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == len(names) and int(out[1]) == 15
+    assert int(out[0]) == len(names) and int(out[1]) == 16
 
 
 def test_static_isa_properties_of_the_fused_kernels():
