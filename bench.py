@@ -235,7 +235,8 @@ def parity_on_bench_frame(models, cam, rob, z_near, z_far, origins, directions, 
             err, floor = ph.rel_err(a.reshape(b.shape), b), floors[k]
             if reduced:
                 mfloor = ph.rel_err(model16[k], b)
-                limit = max(ph.REDUCED_TOL, (ph.REDUCED_FACTOR if b.numel() >= ph.TRUTH_MIN_ELEMENTS else ph.REDUCED_FACTOR_SMALL) * mfloor)
+                small = b.numel() < ph.TRUTH_MIN_ELEMENTS or k in ("rgb", "depth", "optical_flow")   # (oracle/parity_harness.py)
+                limit = max(ph.REDUCED_TOL, (ph.REDUCED_FACTOR_SMALL if small else ph.REDUCED_FACTOR) * mfloor)
                 rows[k] = {"err": float(f"{err:.3e}"), "floor": float(f"{mfloor:.3e}"), "floor_fp64": float(f"{floor:.3e}"),
                            "limit": float(f"{limit:.3e}"), "ok": bool(err <= limit), "reduced_precision_model_floor": True,
                            "truth": ph.truth_columns(a.reshape(b.shape), model16[k].reshape(b.shape), b64)}

@@ -714,7 +714,7 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
 // replaces, on the matrix pipe instead of the VALU (the chunk phases of the fused kernels are issue-bound on VALU work;
 // A/B in profiles/r02_ab_variants.txt).  Row i of block m holds logical feature 16*MB*hh' + 16*m + 4*(i>>3) + (i&3) with
 // hh' = (i>>2)&1 (the accumulator layout of the 32x32 MFMAs: lane half hh owns rows 8*(r>>2) + 4*hh + (r&3)).
-template <int MB, bool ASSIGN, int PREC = PREC_F16F6>
+template <int MB, bool ASSIGN, int PREC = PREC_F16F6, bool SPLIT = false>
 __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, f32x16 (&acc)[MB]) {
 #ifdef NJF_ABLATE_BIAS  // experiment builds only
   if (ASSIGN)
@@ -730,7 +730,20 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
   // their 48 matrix instructions (proposal pass: -0.5...1 % with v_add, profiles/r02_ab_variants.txt)
   constexpr bool VALU = ASSIGN || (PREC != PREC_F16F6 && PREC != PREC_F16);
 #endif
-  if constexpr (VALU) {
+  if constexpr (!ASSIGN && PREC == PREC_F16 && SPLIT) {   // (whatever the A/B flags above say: the table holds bit patterns)
+    // plain-fp16 networks: the accumulated biases are packed as {fp16 hi, fp16 lo} pairs (njf_pack_resnetfc: bias = hi + lo to
+    // 22 bits) and added by ONE f16 MFMA per output block -- A = [hi, lo, 0 ...] for k = 0, 1 (lane half 0), B = [1, 1, 0 ...]:
+    // hi * 1 + lo * 1 accumulated in fp32, 32 clocks instead of the 64 of the exact-fp32 form below (the chunk phases of these
+    // kernels run at the matrix pipe's rate: tools/stamps.py, profiles/r05_stamps_f16.txt)
+    const int i = threadIdx.x & 31;
+    const float* b = bl + 16 * MB * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+    const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{hh == 0 ? 0x3c003c00u : 0u, 0u, 0u, 0u});
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const unsigned u = hh == 0 ? __float_as_uint(b[16 * m]) : 0u;
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u32x4{u, 0u, 0u, 0u}), ones, acc[m], 0, 0, 0);
+    }
+  } else if constexpr (VALU) {
     const float* b = bl + 16 * MB * hh;
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -1001,7 +1014,10 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
 // f = 16*MB*hh + 16*m + 8*q + e sits at position 32*m + 16*q + 8*hh + e (njf_hoist_position, layout 2): the two lanes that
 // own a point read ADJACENT 16-byte pieces (8 channels each) in the same instruction.  Each value is folded with ONE
 // v_fma_mix_f32 (fp16 source, fp32 weight and accumulator): the bilinear interpolation itself is carried out in fp32.
-template <int MB, int DEPTH = 8>
+#ifndef NJF_F16_GATHER_DEPTH
+#define NJF_F16_GATHER_DEPTH 8
+#endif
+template <int MB, int DEPTH = NJF_F16_GATHER_DEPTH>
 __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restrict__ gz, const PointGeom& g, int hh,
                                                        f32x16 (&h)[MB]) {
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
@@ -1252,7 +1268,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         const float* wl = stream_step(st, wave, lane);
         mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, h, net);
       }
-      bias_init<4, false, PREC>(bl + 128, hh, h);
+      if (blk >= 2) bias_init<4, false, PREC, true>(bl + 128, hh, h);   // (blocks 0, 1: folded into the next latent, njf_pack_resnetfc)
       {
         const float* wl = stream_step(st, wave, lane);
         mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);

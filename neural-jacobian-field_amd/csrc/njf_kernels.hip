@@ -73,6 +73,8 @@ struct PackLayer {
   int prec;    // NJF_PRECISION_*
   float* dst;  // kb*4*mb*256 floats (same byte count in both precisions)
   float* bdst;  // 32*mb floats (logical order, zero padded) or NULL
+  int bias_form;  // 0: fp32 values; 1: each entry the bit pattern of {fp16 hi, fp16 lo} of the bias (bias = hi + lo to 22 bits):
+                  //    the A operand of the plain-fp16 networks' bias MFMA (njf_device.h: bias_init); 2: zeros (the bias lives elsewhere)
 };
 
 // logical (row f, input slot k) -> source value
@@ -94,6 +96,18 @@ __device__ __forceinline__ float pack_source(const PackLayer& L, int f, int k) {
   if (k < 15) return L.w[f * L.d_in + k];
   if (k == 15) return L.b[f];
   return L.w[f * L.d_in + (k - 1)];
+}
+
+
+__device__ __forceinline__ float pack_bias_entry(const PackLayer& L, int f) {
+  const float b = (f < L.d_out && L.b) ? L.b[f] : 0.f;
+  if (L.bias_form == 2) return 0.f;
+  if (L.bias_form == 1) {
+    const _Float16 hi = (_Float16)b;
+    const _Float16 lo = (_Float16)(b - (float)hi);
+    return __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16));
+  }
+  return b;
 }
 
 // fp6 e2m3 (1 sign, 2 exponent bits with bias 1, 3 mantissa bits; max 7.5, subnormal step 1/8), round to nearest even,
@@ -175,7 +189,7 @@ __global__ void pack_layer_f16f6_kernel(PackLayer L) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < chunks * tail; i += gridDim.x * blockDim.x)
     ((unsigned*)((char*)L.dst + (size_t)(i / tail) * (NJF_CHUNK_FLOATS * 4) + F6_SCALE + 512))[i % tail] = 0u;
   if (L.bdst != nullptr && blockIdx.x == 0) {
-    for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = (f < L.d_out && L.b) ? L.b[f] : 0.f;
+    for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = pack_bias_entry(L, f);
   }
 }
 
@@ -226,7 +240,7 @@ __global__ void pack_layer_kernel(PackLayer L) {
     }
   }
   if (L.bdst != nullptr && blockIdx.x == 0) {
-    for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = (f < L.d_out && L.b) ? L.b[f] : 0.f;
+    for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = pack_bias_entry(L, f);
   }
 }
 
@@ -271,8 +285,12 @@ extern "C" int njf_hoisted_channel(int feature, int block_channels, int precisio
 }
 
 // lin_z.{0,1,2}.weight [128,512] -> wz[k * ld + 128*i + pos(f)]  (k-major: coalesced B operand of the projection)
+// fold0 / fold1 (plain-fp16 networks): fc_1.bias of blocks 0 / 1, added to the map bias of blocks 1 / 2 -- the latent of block
+// k + 1 is added to h right behind block k's  h += fc_1(...) + b_1, and the bilinear weights of a footprint sum to 1, so
+// bilerp(G + b_1) = bilerp(G) + b_1: those two bias additions cost nothing in the kernel
 __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
-                                 const float* b2, float* wz, int ld, float* bz, int layout) {
+                                 const float* b2, float* wz, int ld, float* bz, int layout, const float* fold0,
+                                 const float* fold1) {
   const int n = 3 * 128 * 512;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int c = i % 384, k = i / 384;
@@ -283,13 +301,14 @@ __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* 
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < 384; c += blockDim.x) {
       const int l = c >> 7, f = c & 127;
-      bz[128 * l + njf_hoist_position(f, 4, layout)] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f];
+      const float extra = l == 1 ? (fold0 ? fold0[f] : 0.f) : (l == 2 ? (fold1 ? fold1[f] : 0.f) : 0.f);
+      bz[128 * l + njf_hoist_position(f, 4, layout)] = (l == 0 ? b0 : (l == 1 ? b1 : b2))[f] + extra;
     }
 }
 
 static void launch_pack(const float* w, const float* b, int d_out, int d_in, int mb, int kb, int kind, int prec, float* dst,
-                        float* bdst, hipStream_t s) {
-  PackLayer L{w, b, d_out, d_in, mb, kb, kind, prec, dst, bdst};
+                        float* bdst, hipStream_t s, int bias_form = 0) {
+  PackLayer L{w, b, d_out, d_in, mb, kb, kind, prec, dst, bdst, bias_form};
   const int n = kb * 4 * mb * 256;
   if (prec == NJF_PRECISION_F16F6) {
     // the 128-wide layers take the fp6-corrected chunk form; narrow layers keep the F16X2 form (njf_device.h: mma_chunk)
@@ -319,17 +338,24 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
   for (int i = 0; i < 5; ++i) {
     float* base = w_out + (size_t)(1 + 2 * per_layer * i) * NJF_CHUNK_FLOATS;
     launch_pack(src->fc0_w[i], src->fc0_b[i], 128, 128, 4, 4, 0, P, base, b_out + 256 * i, s);
-    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, P, base + per_layer * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s);
+    // plain-fp16 networks: fc_1.bias of blocks 0, 1 is folded into the hoisted map (pack_linz_kernel), the others are stored
+    // as {hi, lo} fp16 pairs for the bias MFMA
+    const int bias_form = P == NJF_PRECISION_F16 ? (i < 2 ? 2 : 1) : 0;
+    launch_pack(src->fc1_w[i], src->fc1_b[i], 128, 128, 4, 4, 0, P, base + per_layer * NJF_CHUNK_FLOATS, b_out + 256 * i + 128, s,
+                bias_form);
   }
   float* last = w_out + (size_t)(1 + 10 * per_layer) * NJF_CHUNK_FLOATS;
   launch_pack(src->lin_out_w, src->lin_out_b, src->d_out, 128, 1, 4, 0, P, last, b_out + 1280, s);
   fill_kernel<<<16, 256, 0, s>>>(last + 4096, 4096, 0.f);
+  if (P == NJF_PRECISION_F16 && !wz_out) return NJF_E_NULL;  // two of its biases live in the map
   if (wz_out) {
     if (!bz_out || wz_ld < 384) return NJF_E_SHAPE;
     for (int i = 0; i < 3; ++i)
       if (!src->lin_z_w[i] || !src->lin_z_b[i]) return NJF_E_NULL;
     pack_linz_kernel<<<256, 256, 0, s>>>(src->lin_z_w[0], src->lin_z_w[1], src->lin_z_w[2], src->lin_z_b[0],
-                                         src->lin_z_b[1], src->lin_z_b[2], wz_out, wz_ld, bz_out, njf_hoist_layout(P));
+                                         src->lin_z_b[1], src->lin_z_b[2], wz_out, wz_ld, bz_out, njf_hoist_layout(P),
+                                         P == NJF_PRECISION_F16 ? src->fc1_b[0] : nullptr,
+                                         P == NJF_PRECISION_F16 ? src->fc1_b[1] : nullptr);
   }
   return launch_status();
 }

@@ -13,6 +13,7 @@ Jacobian head; perception mode: gradients to encoder, density / colour heads and
 from __future__ import annotations
 
 import functools
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -149,7 +150,7 @@ class Model(nn.Module):
         self._inverse_cache: Dict[str, tuple] = {}
         self.inverse_cache_enabled = True
         self._joint: Dict[str, object] = {"features": None}   # ONE per-image projection for all networks of a frame (_joint_hoist)
-        self.auto_range_check = True
+        self.auto_range_check = os.environ.get("NJF_AUTO_RANGE_CHECK", "1") != "0"   # (off: single-precision experiment libraries)
         self.range_check_interval = 100
         self._range_checked = None      # weights signature of the last check
         self._range_pending = True      # weights replaced wholesale (construction, load_state_dict)

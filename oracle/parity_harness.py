@@ -202,7 +202,7 @@ def oracle_forward_fp64(case, s_prop, s_final, anneal: float = 1.0):
 # with ``operand_rounding("f16")`` (njf_oracle.py: every Linear input and weight rounded to fp16, the hoisted lin_z outputs
 # rounded to fp16, accumulation and everything else in fp32).  Per compared quantity
 #     model[k]  = rel_err(oracle_f16model[k], oracle_fp32[k])          (norm-wise, like every other row)
-#     limit[k]  = max(REDUCED_TOL, f x model[k]),   f = 2 on tensors of >= 1,024 elements, 4 below
+#     limit[k]  = max(REDUCED_TOL, f x model[k]),   f = 2 on tensors of >= 1,024 elements, 4 below and on the end-to-end pixels
 #                 (HIP and model are two independent DRAWS of the same rounding noise -- different accumulation orders round
 #                 different values -- and the maximum over a few hundred elements of noise that sample placement pushes through
 #                 the positional encoding's 2*pi*512 gain is an extreme value of one or two rays: measured ratios 0.8 ... 2.2 on
@@ -438,7 +438,10 @@ def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32
             mk = model.get(k, 0.0)
             base_key = k[4:] if k.startswith("ref_") else k
             n_el = truth_in[base_key][1].numel() if base_key in truth_in else 0
-            limit = max(REDUCED_TOL, (REDUCED_FACTOR if n_el >= TRUTH_MIN_ELEMENTS else REDUCED_FACTOR_SMALL) * mk)
+            # end-to-end pixels depend on where the inverse CDF PLACES samples: their error is placement noise through the
+            # positional encoding's gain, an extreme value of a few rays at any frame size (REDUCED_FACTOR_SMALL, see above)
+            e2e = base_key in ("rgb", "depth", "optical_flow")
+            limit = max(REDUCED_TOL, (REDUCED_FACTOR if (n_el >= TRUTH_MIN_ELEMENTS and not e2e) else REDUCED_FACTOR_SMALL) * mk)
             good = math.isfinite(v) and v <= limit
             ok = ok and good
             rows.append({"key": k, "err": float(f"{v:.3e}"), "floor": float(f"{mk:.3e}"), "floor_fp64": float(f"{f64:.3e}"),
