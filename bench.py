@@ -254,7 +254,10 @@ def dry_launch(args, dist, rank: int, world: int) -> None:
     tests' self-contained stand-ins: no oracle code runs).  Nothing here is a measurement and the line says so."""
     from neural_jacobian_field_amd import launch, parallel
 
-    spec = importlib.util.spec_from_file_location("njf_dry_standins", args.dry_launch)
+    standins = os.path.realpath(args.dry_launch)
+    if not standins.startswith(os.path.join(ROOT, "tests") + os.sep):   # (ADVICE r04: this flag executes the file it names)
+        raise SystemExit(f"--dry-launch only runs stand-in files under {os.path.join(ROOT, 'tests')}{os.sep}")
+    spec = importlib.util.spec_from_file_location("njf_dry_standins", standins)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     step, check = mod.make_frame_step(parallel, world, rank)
@@ -421,6 +424,14 @@ def main():
             hip.set_profile_sink(launches)   # per-launch HIP events on the launch stream (roofline.achieved)
         elapsed, local = timed_loop(lambda: step(model), steps, dist, sync)
         hip.set_profile_sink(None)
+        digest_hex = None
+        if use_frame_step:   # one more UNTIMED step through the same (possibly graph-replayed) step function, on every rank
+            import hashlib
+            _, scalars_d, frame_d = step(model)
+            sync()
+            if frame_d is not None:
+                digest_hex = hashlib.sha256(frame_d.detach().float().cpu().numpy().tobytes()
+                                            + scalars_d.detach().float().cpu().numpy().tobytes()).hexdigest()
         timing_note = "mean njf_render_forward launch duration over the timed steps, HIP events on the launch stream"
         if graphed:   # events cannot be read back from inside a replayed graph: an eager pass of the same step, not part of `value`
             frame_steps[prec]._graph = None
@@ -433,7 +444,7 @@ def main():
                            "(graph-replayed) loop, HIP events on the launch stream")
         return {"elapsed": max_over_ranks(dist, elapsed, device), "local_ms": 1e3 * local / steps, "steps": steps, "warmup": warmup,
                 "kernel_ms": kernel_ms(launches, steps), "launches_per_step": len(launches) / max(steps, 1), "graphed": graphed,
-                "timing_note": timing_note}
+                "timing_note": timing_note, "digest": digest_hex}
 
     # headline first; the package's default precision with the SAME steps / warm-up / barriers; any remaining mode briefly
     runs = {precision: measure(precision, args.steps, args.warmup)}
@@ -443,6 +454,15 @@ def main():
             runs[prec] = measure(prec, args.steps if full else max(2, args.steps // 4), args.warmup if full else 1)
     head = runs[precision]
     evidence = launch.rank_evidence(dist, device, head["local_ms"], graph=head["graphed"])
+    # One more UNTIMED step of the headline mode on every rank: the digest of what it produced (assembled frame + the six clip /
+    # loss scalars).  The kernels are bit-reproducible, so a one-rank run WITH the collective (--force-dist, eager or --graph)
+    # must print the digest of the plain run (tests/test_rccl_gpu.py).
+    digest = None
+    if head.get("digest") is not None:
+        digest = {"sha256": head["digest"],
+                  "of": "assembled frame [B,R,6] (rgb | clipped depth | flow) + [depth-clip min, max, sum sq rgb, sum sq flow, rgb loss, "
+                        "flow loss] of one extra untimed step in the headline precision, taken right after the timed loop through the "
+                        "SAME step function (graph replay included when the step was captured)"}
 
     total_rays = local_rays if sim_world else (frame_rays if strong else world * frame_rays)
     render_flop = 2.0 * local_rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
@@ -495,6 +515,7 @@ def main():
                      "c_abi_launches_per_step": round(head["launches_per_step"], 2), "hip_graph": head["graphed"]},
             "roofline": roofline(precision, head),
             "rccl": evidence,
+            "frame_digest": digest,
         }
         if sim_world:
             out["simulated"] = f"rank 0's shard of a {sim_world}-way strong split rendered on ONE GPU, no collectives: value counts only these rays"

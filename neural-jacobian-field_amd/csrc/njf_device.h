@@ -1284,15 +1284,6 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
     if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
     const float* bl = bias + blk * 256;
     bias_init<4, true, PREC>(bl, hh, net);
-#ifdef NJF_PROPOSAL_MIX
-    // Experiment (VERDICT r03 "next" #5, tools/measure_r04.sh mix): in an F16X2 network the first NJF_PROPOSAL_MIX wide layers
-    // (layer 2 blk = fc_0, 2 blk + 1 = fc_1 of block blk) take the fp6-corrected product form; the host splices the chunks
-    // of those layers from the F16F6 pack into the F16X2 blob (decoder.py, env NJF_PROPOSAL_MIX).  A wave-uniform branch.
-    if (PREC == PREC_F16X2 && 2 * blk < NJF_PROPOSAL_MIX) {
-      { const float* wl = stream_step(st, wave, lane); mma_chunk<PREC_F16F6, 4, 2, 0, true, 4>(st, wl, lane, h, net); }
-      { const float* wl = stream_step(st, wave, lane); mma_chunk<PREC_F16F6, 4, 2, 2, true, 4>(st, wl, lane, h, net); }
-    } else
-#endif
     {
       {
         const float* wl = stream_step(st, wave, lane);
@@ -1305,12 +1296,6 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
     }
     if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
     bias_init<4, false, PREC>(bl + 128, hh, h);
-#ifdef NJF_PROPOSAL_MIX
-    if (PREC == PREC_F16X2 && 2 * blk + 1 < NJF_PROPOSAL_MIX) {
-      { const float* wl = stream_step(st, wave, lane); mma_chunk<PREC_F16F6, 4, 2, 0, true, 4>(st, wl, lane, net, h); }
-      { const float* wl = stream_step(st, wave, lane); mma_chunk<PREC_F16F6, 4, 2, 2, true, 4>(st, wl, lane, net, h); }
-    } else
-#endif
     {
       {
         const float* wl = stream_step(st, wave, lane);

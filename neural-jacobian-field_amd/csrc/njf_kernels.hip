@@ -2780,6 +2780,16 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.out = *out;
   hipStream_t s = (hipStream_t)stream;
   const int n = a.rc.total_rays;
+#ifdef NJF_TRAIN_AF   // A/B builds only (tools/measure_r05.sh spills): the round-4 training instantiations, with the 16 accumulators
+  constexpr bool TRAIN_AF = true;
+#else
+  constexpr bool TRAIN_AF = false;
+#endif
+  const bool training_forward = out->jac_act != nullptr || out->jac_pe != nullptr || out->den_act != nullptr;
+  // Training forwards never composite the action features (sum_s w J: 16 more live accumulators per lane cost the dump
+  // instantiations ~80 spilled VGPRs, and no loss reads them): a caller that wants them next to a training forward renders
+  // them with an inference call at the same bins (model.py does)
+  if (!TRAIN_AF && training_forward && out->action_features != nullptr) return NJF_E_MODE;
   if (out->jac_act != nullptr || (out->jac_pe != nullptr && out->den_act == nullptr)) {
     // action-mode training forward: dump the Jacobian head's backward-pass inputs (ResnetFC head: activations +
     // encoding + footprint; transformer head: encoding + footprint, the head is recomputed by the backward pass)
@@ -2787,18 +2797,18 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
     if (!out->jac_pe || !out->foot_idx || !out->foot_w) return NJF_E_NULL;
     if (jacobian_kind == NJF_JACOBIAN_MLP) {
       if (!out->jac_act) return NJF_E_NULL;
-      return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<1, NJF_P, 1, true, NJF_PJ>, a, n, s); });
+      return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<1, NJF_P, 1, TRAIN_AF, NJF_PJ>, a, n, s); });
     }
     if (out->jac_act) return NJF_E_MODE;
-    return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<2, NJF_P, 1, true, NJF_PJ>, a, n, s); });
+    return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<2, NJF_P, 1, TRAIN_AF, NJF_PJ>, a, n, s); });
   }
   if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
     if (!out->jac_pe || !out->foot_idx || !out->foot_w || !out->col_in || !out->col_act) return NJF_E_NULL;
     if (jacobian_kind == NJF_JACOBIAN_NONE)
-      return with_precision<true>(density_precision(precision), [&](auto P) { return launch_fused(render_kernel<0, NJF_P, 2>, a, n, s); });
+      return with_precision<true>(density_precision(precision), [&](auto P) { return launch_fused(render_kernel<0, NJF_P, 2, TRAIN_AF>, a, n, s); });
     return with_precisions<true>(precision, [&](auto P, auto PJ) {
-      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, NJF_P, 2, true, NJF_PJ>, a, n, s);
-      return launch_fused(render_kernel<2, NJF_P, 2, true, NJF_PJ>, a, n, s);
+      if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(render_kernel<1, NJF_P, 2, TRAIN_AF, NJF_PJ>, a, n, s);
+      return launch_fused(render_kernel<2, NJF_P, 2, TRAIN_AF, NJF_PJ>, a, n, s);
     });
   }
   const bool af = with_j && out->action_features != nullptr;

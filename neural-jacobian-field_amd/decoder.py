@@ -162,11 +162,11 @@ def _cameras(enc: PixelEncoding, with_action: bool, z_near=None, z_far=None, trg
     dev = enc.extrinsics.device
     zeros = None
     if z_near is None or z_far is None:
-        zeros = _ZEROS.get((b, str(dev)))
+        zeros = _ZEROS.get((b, hip.device_key(dev)))
         if zeros is None:   # a constant: filled once per (batch, device), not per call
             zeros = torch.zeros(b, dtype=torch.float32, device=dev)
             if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):   # (a fill captured into a graph has not run yet)
-                _ZEROS[(b, str(dev))] = zeros
+                _ZEROS[(b, hip.device_key(dev))] = zeros
     if action is None:
         action = enc.action
     w2c = hip.inverse(enc.extrinsics) if enc.extrinsics_inv is None else enc.extrinsics_inv
@@ -202,15 +202,6 @@ class DensityDecoderMlp(nn.Module):
             self._bz = torch.empty(hip.ZDIM, **f32)
             params = {k: p for k, p in self.named_parameters()}
             hip.pack_resnetfc(params, "density_head.", self._w, self._b, self._wz, 0, self._bz, precision=self.precision)
-            mix = int(os.environ.get("NJF_PROPOSAL_MIX", "0"))
-            if mix > 0 and self.precision == "f16x2":
-                # kernel A/B experiment only (tools/measure_r04.sh mix, with a -DNJF_PROPOSAL_MIX=<n> library): the first n wide
-                # layers' chunks (2 per layer, after the lin_in chunk) come from the f16f6 pack of the same weights
-                w6 = torch.empty_like(self._w)
-                hip.pack_resnetfc(params, "density_head.", w6, torch.empty_like(self._b), torch.empty_like(self._wz), 0,
-                                  torch.empty_like(self._bz), precision="f16f6")
-                c = hip.RESNET_W_FLOATS // 22
-                self._w[c: c * (1 + 2 * mix)] = w6[c: c * (1 + 2 * mix)]
             self._packed_version = v
         return self._w, self._b
 

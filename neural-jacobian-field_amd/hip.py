@@ -208,6 +208,30 @@ class _RecordScope:
         return False
 
 
+def device_key(device) -> tuple:
+    """Cache key of a device: (type, index) with an index-less ``torch.device('cuda')`` resolved to the CURRENT device -- a
+    plain ``str(device)`` would give every GPU of a process the same key."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        return ("cuda", torch.cuda.current_device())
+    return (d.type, d.index)
+
+
+def cached_device_constant(cache: dict, key: tuple, device, make) -> torch.Tensor:
+    """``cache[key]`` (key must end with ``device_key(device)``), built by ``make()`` -- a host tensor -- and uploaded ONCE.  A
+    first use inside a HIP-graph capture would be a pageable host-to-device copy inside the capture: refused with a message that
+    says what to do (every capture path here warms up with eager steps first, so this only fires on a mis-ordered caller)."""
+    t = cache.get(key)
+    if t is None:
+        d = torch.device(device)
+        if d.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("njf: a device constant would be uploaded inside a HIP-graph capture; run one eager step of the same "
+                               "shape before capturing (the constant caches are filled on first use)")
+        t = make().to(d)
+        cache[key] = t
+    return t
+
+
 def map_dtype(precision: Optional[str]) -> torch.dtype:
     """Element type of the hoisted map a network of MFMA ``precision`` reads (include/njf_hip.h: NJF_PRECISION_F16)."""
     return torch.float16 if (DEFAULT_PRECISION if precision is None else precision) == "f16" else torch.float32
@@ -394,7 +418,7 @@ def hoisted_channel_order(block_channels: int, device, precision: str) -> torch.
     """pos[f] = position of logical feature f inside a block of ``block_channels`` hoisted-map channels of a network
     packed for MFMA ``precision`` (njf_hoisted_channel: the single definition of that order), as an index tensor on
     ``device``."""
-    key = (block_channels, str(device), precision)
+    key = (block_channels, device_key(device), precision)
     if key not in _hoist_order_cache:
         lib = load_library()
         code = PRECISIONS[precision]

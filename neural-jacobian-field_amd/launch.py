@@ -31,12 +31,6 @@ def env_world() -> Optional[int]:
     return None
 
 
-def free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def ensure_world(gpus: int, script: str, argv: Sequence[str], need_devices: bool = True) -> None:
     """Make the process that continues past this call one rank of a world of exactly ``gpus``.
 
@@ -60,8 +54,9 @@ def ensure_world(gpus: int, script: str, argv: Sequence[str], need_devices: bool
     env[LAUNCH_MARK] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (no bind-close-reuse race of a port picked here)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={gpus}", script, *argv]
     print("[launch]", " ".join(cmd), file=sys.stderr, flush=True)
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
@@ -71,13 +66,16 @@ def init_process_group(backend: str, device: Optional[torch.device] = None):
     of one on 127.0.0.1.  Returns the ``torch.distributed`` module."""
     import torch.distributed as dist
 
-    if "MASTER_ADDR" not in os.environ:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    kw = {}
+    if "MASTER_ADDR" not in os.environ or "RANK" not in os.environ:
+        # a plain process: a world of one whose store binds an ephemeral port itself (port 0: nothing to race for)
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        kw = dict(store=dist.TCPStore("127.0.0.1", 0, 1, is_master=True), rank=0, world_size=1)
     if backend == "nccl":
         os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's banner would precede the one JSON line on stdout
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, **kw)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, **kw)
     return dist
 
 

@@ -147,6 +147,11 @@ class Model(nn.Module):
         # rank contributes to the step's one collective -- and the loss targets; the render kernel then also writes the
         # per-workgroup partials of the frame-level reductions and the depth clip is deferred to njf_assemble_frame.
         self.frame_io: Optional[Dict[str, torch.Tensor]] = None
+        # Training forwards at GIVEN final bins ([B,R,S+1] spacing bins; None = the proposal sampler places them, as in the
+        # reference): the proposal levels are skipped and exactly these samples are rendered and differentiated.  For gradient
+        # tests that must not inherit the inverse CDF's placement noise (tests/test_training_fixed_bins_gpu.py); the reference
+        # has no such switch.
+        self.training_final_bins: Optional[torch.Tensor] = None
         self._inverse_cache: Dict[str, tuple] = {}
         self.inverse_cache_enabled = True
         self._joint: Dict[str, object] = {"features": None}   # ONE per-image projection for all networks of a frame (_joint_hoist)
@@ -485,7 +490,8 @@ class Model(nn.Module):
         if want_vis:
             outs["pos"] = torch.empty(b, r, 3, **f32)
             outs["pos_warped"] = torch.empty(b, r, 3, **f32)
-            outs["action_features"] = torch.empty(b, r, a3, **f32)
+            if not (dump_jacobian or dump_perception):   # (the training instantiations do not composite them: _vis_at_bins)
+                outs["action_features"] = torch.empty(b, r, a3, **f32)
         if want_samples:
             outs["density"] = torch.empty(b, r, s, 1, **f32)
             outs["jacobian"] = torch.empty(b, r, s, a3, **f32)
@@ -569,13 +575,15 @@ class Model(nn.Module):
         def run():
             with torch.no_grad():
                 outs, bins, wl, bl, rb = self._fused_render(camera_input, rendering_input, robot_input, detached,
-                                                            want_lists=True, want_vis=compute_vis_features,
-                                                            want_samples=False, dump_perception=True, clip_depth=False)
+                                                            want_lists=True, want_vis=False,
+                                                            want_samples=False, dump_perception=True, clip_depth=False,
+                                                            final_bins=self.training_final_bins)
             box.update(outs=outs, bins=bins, bins_list=bl, weights_list=wl, ray_bundle=rb)
             return outs
 
         params = training.perception_params(self)
-        sigma, color, *sigma_prop = training.FieldFunction.apply(run, len(levels), len(self.proposal_networks), *levels, *params)
+        n_prop = 0 if self.training_final_bins is not None else len(self.proposal_networks)   # (given bins: no proposal level runs)
+        sigma, color, *sigma_prop = training.FieldFunction.apply(run, len(levels), n_prop, *levels, *params)
         outs, ray_bundle = box["outs"], box["ray_bundle"]
         # compositing of model.py:257-279 on the differentiable fields: the values are the fused kernels' own (weights, rgb,
         # un-clipped depth), the backward pass is one njf_composite_backward launch per level (training.CompositeFunction)
@@ -598,10 +606,18 @@ class Model(nn.Module):
             out.training_output = ModelTrainingOutput(weights_list=weights_list + [weights],
                                                       ray_samples_list=samples_list + [smp])
         if compute_vis_features:
-            out.vis_output = ModelVisOutput(
-                action_features=outs["action_features"], steps=((smp.starts + smp.ends) / 2).squeeze(-1),
-                weights=outs["weights"], ray_positions=outs["pos"], ray_positions_warped=outs["pos_warped"])
+            out.vis_output = self._vis_at_bins(camera_input, rendering_input, robot_input, detached, box["bins"], smp)
         return out
+
+    def _vis_at_bins(self, camera_input, rendering_input, robot_input, features, bins, smp) -> "ModelVisOutput":
+        """ModelVisOutput of a TRAINING forward (model.py:381-394): an inference render of the same samples (``bins``) -- the
+        training instantiations of the render kernel carry the activation dumps instead of the 16 action-feature accumulators
+        (which cost them ~60 spilled VGPRs each for an output no loss reads)."""
+        with torch.no_grad():
+            vis, *_ = self._fused_render(camera_input, rendering_input, robot_input, features, want_lists=False, want_vis=True,
+                                         want_samples=False, final_bins=bins)
+        return ModelVisOutput(action_features=vis["action_features"], steps=((smp.starts + smp.ends) / 2).squeeze(-1),
+                              weights=vis["weights"], ray_positions=vis["pos"], ray_positions_warped=vis["pos_warped"])
 
     @staticmethod
     def _weights_from_density(deltas: torch.Tensor, densities: torch.Tensor) -> torch.Tensor:
@@ -623,8 +639,8 @@ class Model(nn.Module):
         def run():
             with torch.no_grad():
                 outs, bins, wl, bl, rb = self._fused_render(camera_input, rendering_input, robot_input, features,
-                                                            want_lists=self.training, want_vis=True, want_samples=False,
-                                                            dump_jacobian=True)
+                                                            want_lists=self.training, want_vis=False, want_samples=False,
+                                                            dump_jacobian=True, final_bins=self.training_final_bins)
             box.update(outs=outs, bins=bins, weights_list=wl, bins_list=bl, ray_bundle=rb)
             return outs
 
@@ -633,8 +649,10 @@ class Model(nn.Module):
                                                  training.action_kind(self), *jparams)
         outs = box["outs"]
         out = ModelOutput(ModelStandardOutput(rgb=outs["rgb"], depth=outs["depth"], optical_flow=flow), None, None)
-        self._attach_optional_outputs(out, outs, box["bins"], box["weights_list"], box["bins_list"], box["ray_bundle"],
-                                      compute_vis_features)
+        self._attach_optional_outputs(out, outs, box["bins"], box["weights_list"], box["bins_list"], box["ray_bundle"], False)
+        if compute_vis_features:
+            out.vis_output = self._vis_at_bins(camera_input, rendering_input, robot_input, features, box["bins"],
+                                               box["ray_bundle"].samples_from_bins(box["bins"]))
         return out
 
     def _attach_optional_outputs(self, out, outs, bins, weights_list, bins_list, ray_bundle, compute_vis_features):

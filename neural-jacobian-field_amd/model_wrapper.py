@@ -86,10 +86,8 @@ _SIGMA: Dict[tuple, torch.Tensor] = {}
 def _sigma_on(sigma: float, device) -> torch.Tensor:
     """The loss's sigma as a one-element device tensor, uploaded once per (value, device): a per-step torch.tensor(...) is a
     pageable host-to-device copy on the critical path, and illegal while a step is being recorded into a HIP graph."""
-    key = (sigma, str(device))
-    if key not in _SIGMA:
-        _SIGMA[key] = torch.tensor([sigma], device=device)
-    return _SIGMA[key]
+    from . import hip
+    return hip.cached_device_constant(_SIGMA, (sigma, hip.device_key(device)), device, lambda: torch.tensor([sigma]))
 
 
 def depth_loss(output: ModelOutput, target: ModelTarget, sigma: float = 0.001) -> torch.Tensor:

@@ -255,10 +255,9 @@ _constants: Dict[tuple, torch.Tensor] = {}
 def _device_constant(values: Tuple[float, ...], device) -> torch.Tensor:
     """A small constant vector on the device, uploaded once (per-step host-to-device copies of element counts are
     launch latency on the critical path of a 2 ms step)."""
-    key = (values, str(device))
-    if key not in _constants:
-        _constants[key] = torch.tensor(values, dtype=torch.float32, device=device)
-    return _constants[key]
+    from . import hip
+    return hip.cached_device_constant(_constants, (values, hip.device_key(device)), device,
+                                      lambda: torch.tensor(values, dtype=torch.float32))
 
 
 def allreduce_gradients(parameters, average: bool = True) -> None:

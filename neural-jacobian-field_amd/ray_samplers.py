@@ -114,11 +114,9 @@ _U_BASE: dict = {}
 def _train_u_base(nb: int, device) -> torch.Tensor:
     """linspace(0, 1 - 1/nb, nb) of ray_samplers.py:391-394 on ``device``, computed once on the host and uploaded once per
     (nb, device): same values as before, no host-to-device copy per training step (which a step recorded into a HIP graph
-    could not contain, training.GraphedTrainingStep)."""
-    key = (nb, str(device))
-    if key not in _U_BASE:
-        _U_BASE[key] = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb).to(device)
-    return _U_BASE[key]
+    could not contain)."""
+    return hip.cached_device_constant(_U_BASE, (nb, hip.device_key(device)), device,
+                                      lambda: torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb))
 
 
 class PDFSampler(Sampler):

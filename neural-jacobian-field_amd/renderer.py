@@ -40,7 +40,7 @@ _CONST_CACHE: Dict[tuple, torch.Tensor] = {}
 
 def uniform_bins(num_samples: int, device) -> torch.Tensor:
     """``torch.linspace(0, 1, S+1)`` evaluated on the CPU (bit-identical to the reference path), cached on device."""
-    key = ("bins", num_samples, str(device))
+    key = ("bins", num_samples, hip.device_key(device))
     if key not in _CONST_CACHE:
         _CONST_CACHE[key] = torch.linspace(0.0, 1.0, num_samples + 1).to(device)
     return _CONST_CACHE[key]
@@ -48,7 +48,7 @@ def uniform_bins(num_samples: int, device) -> torch.Tensor:
 
 def pdf_u_eval(num_samples: int, device) -> torch.Tensor:
     """Eval-mode ``u`` of PDFSampler (ray_samplers.py:402-408)."""
-    key = ("u", num_samples, str(device))
+    key = ("u", num_samples, hip.device_key(device))
     if key not in _CONST_CACHE:
         nb = num_samples + 1
         u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb)

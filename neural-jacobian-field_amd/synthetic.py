@@ -241,3 +241,38 @@ def synthetic_training_batch(batch: int, height: int, width: int, rays: int, act
         "target_depth": (torch.rand(batch, rays, 1, generator=g) + 0.5).to(device),
         "target_flow": torch.randn(batch, rays, 2, generator=g).to(device),
     }
+
+
+def general_pose(seed: int, batch: int, scale: float = 0.15) -> torch.Tensor:
+    """A seeded non-identity camera pose [B,4,4] (rotation exp(scale * skew), translation 0.1 * N(0,1))."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(batch, 3, 3, generator=g)
+    m = torch.eye(4)[None].repeat(batch, 1, 1)
+    m[:, :3, :3] = torch.matrix_exp(scale * (a - a.transpose(1, 2)))
+    m[:, :3, 3] = 0.1 * torch.randn(batch, 3, generator=g)
+    return m.contiguous()
+
+
+def synthetic_case(batch: int, height: int, width: int, rays: Optional[int], action_dim: int, seed: int = 0, device="cpu",
+                   identity_context: bool = True, decoder: str = "jacobian_mlp") -> Dict[str, object]:
+    """One seeded frame for tools and benches that need INPUTS only (the same recipe as the parity suite's cases,
+    built from the package alone so such tools travel without oracle/): weights (no encoder), feature map, cameras, the rays of
+    ``rays`` randomly chosen pixels (None = the whole frame) from the HIP ray-generation kernel, pixel intrinsics, command."""
+    from . import geometry
+
+    dev = torch.device(device)
+    cams = synthetic_cameras(batch)
+    if not identity_context:
+        cams["ctxt_c2w"] = general_pose(seed + 5, batch)
+    cams = {k: v.to(dev) for k, v in cams.items()}
+    coords, _ = geometry.get_pixel_coordinates(height, width)
+    xy = coords.reshape(1, -1, 2)
+    if rays is not None and rays < height * width:
+        xy = xy[:, torch.randperm(height * width, generator=torch.Generator().manual_seed(seed + 3))[:rays]]
+    xy = xy.repeat(batch, 1, 1).contiguous().to(dev)
+    origins, directions, _ = geometry.get_world_rays_with_z(xy, cams["trgt_k_norm"], cams["trgt_c2w"])
+    return {"params": {k: v.to(dev) for k, v in seeded_state_dict(model_shapes(decoder, action_dim, with_encoder=False), seed).items()},
+            "feats": synthetic_features(batch, height, width, seed=seed + 1).to(dev), "cams": cams,
+            "origins": origins.contiguous(), "directions": directions.contiguous(),
+            "k_pix": geometry.denormalize_intrinsics(cams["trgt_k_norm"], width, height),
+            "action": synthetic_action(batch, action_dim, seed + 2).to(dev)}

@@ -46,6 +46,10 @@ def test_fused_forward_matches_oracle(device, case_id, precision, margins):
     assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
     if asserted:
         assert rep["truth_ok"], [r for r in rep["truth_rows"] if not r["truth_ok"]]
+    # the accelerated modes (incl. the package default): their own asserted criterion on EVERY tensor of >= 1,024 elements of
+    # EVERY case (oracle/parity_harness.py::truth_asserted: rms <= max(1.5 x fp32 noise, 5e-6), max <= max(2 x, 5e-5))
+    if precision != "f32":
+        assert rep["truth_asserted_ok"], [r for r in rep["truth_rows"] if r["asserted_ok"] is False]
 
 
 @pytest.mark.parametrize("case_id", range(len(_ph.PARITY_CASES)))
@@ -140,6 +144,10 @@ def test_reference_initialisation_of_the_jacobian_head(device, precision, margin
     margins.record(f"parity[reference-init:{precision}]", rep["rows"])
     margins.record_truth(f"parity[reference-init:{precision}]", rep["truth_rows"], asserted=False)
     assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
+    # the regime every action-mode run starts in: fp16's subnormals cut the lo halves of N(0, 1e-4) weights, the split modes are
+    # ~9 x noisier than fp32 arithmetic there -- at 1.4e-6 (rms) of the Jacobian's scale, inside their asserted criterion; what
+    # that does to TRAINING from this initialisation is measured by tools/ab_reference_init.py (profiles/r05_ab_reference_init.json)
+    assert rep["truth_asserted_ok"], [r for r in rep["truth_rows"] if r["asserted_ok"] is False]
     assert rep["errors"]["s_jacobian"] < 2e-5, rep["errors"]
 
 

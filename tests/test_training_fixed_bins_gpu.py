@@ -1,0 +1,380 @@
+"""Training gradients WITHOUT the inverse CDF's placement noise, the whole perception loss, and the reference batch shape
+(VERDICT r04 "next" #2).  Run with -m gpu.
+
+(b) Gradients at GIVEN final bins and on IDENTICAL encoder features: the HIP training forwards render exactly the oracle's
+    final samples (Model.training_final_bins) from a 'precomputed' encoder that returns the oracle's feature tensor, so the two
+    sides differ by fp32 arithmetic alone -- every row is held to max(1e-4, 2 x its float64 floor); no self-noise floor is
+    offered to the margins rule (rows_on_self_noise_floor of these cases is 0 by construction).
+(a) The reference's WHOLE perception loss -- rgb + 0.08 ds-nerf + 1.0 interlevel + 0.01 distortion (models/model_wrapper.py:
+    117-141) -- through ModelWrapper.training_step on the HIP side and through the oracle's loss restatements on the other.
+(c) One gradient case at the reference batch shape (7 scenes x 256 rays, 64 + 64 samples, configurations/config.yaml:18-20):
+    the HIP step processes all 1,792 rays; the loss reads a 256-ray subset (the other rays get a zero upstream gradient), which
+    is what the oracle evaluates and differentiates on the CPU."""
+import pytest
+import torch
+
+from test_training_gpu import FLOOR_MODES, as_dtype, feature_seed, moved_rays, noisy, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _bins_of(samples):
+    return torch.cat([samples.spacing_starts[..., 0], samples.spacing_ends[..., -1:, 0]], -1)
+
+
+@pytest.fixture(scope="module")
+def fixed():
+    """A model on the 'precomputed' encoder (both sides see the SAME feature tensor) and the oracle's final bins."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import __graft_entry__ as g
+    g.build()
+    import parity_harness as ph
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    dev = torch.device("cuda:0")
+    B, H, W, R, S = 2, 16, 16, 40, 32
+    case = ph.make_case(B, H, W, R, 8, seed=4, identity_context=False)
+    model = Model(model_cfg_from_dict({"action_dim": 8, "encoder": {"name": "precomputed"},
+                                       "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                                       "action_decoder": {"name": "jacobian_mlp"}}))
+    model.load_state_dict(case["params"], strict=True)
+    model.to(dev).eval()
+    model.encoder.set_features(case["feats"].to(dev))
+    ref = ph.oracle_forward(case, S, S)
+    bins = _bins_of(ref.samples_list[1])
+    c = case["cams"]
+    d = lambda t: t.to(dev)
+    cam = CameraInput(None, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+    rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
+    return dict(model=model, case=case, bins=bins, cam=cam, rin=rin, rob=RobotInput(d(case["action"])), dev=dev, S=S, B=B, R=R)
+
+
+def _oracle_final_stage(case, params, bins, cv):
+    import njf_oracle as orc
+    c = case["cams"]
+    enc = orc.PixelEncoding(cv(case["feats"]), cv(c["ctxt_c2w"]), cv(c["ctxt_k_norm"]), cv(case["action"]))
+    smp = orc.samples_from_bins(cv(case["origins"]), cv(case["directions"]), cv(c["z_near"]), cv(c["z_far"]), cv(bins))
+    return orc.final_stage(params, smp, cv(case["directions"]), enc, cv(c["trgt_c2w"]), cv(case["k_pix"])), smp
+
+
+@pytest.mark.parametrize("precision", ["f32", "default"])
+def test_action_mode_gradients_at_given_bins(fixed, margins, precision):
+    """Action mode (only the Jacobian head trains, model_wrapper.py:75-85, flow loss :148-160) at the oracle's final bins."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import hip
+    from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
+    f = fixed
+    model, case, dev = f["model"], f["case"], f["dev"]
+    model.set_precision("f32" if precision == "f32" else hip.DEFAULT_PRECISION)
+    req = {n: p.requires_grad for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.requires_grad = False
+    for n, p in model.named_parameters():
+        if n.startswith("decoder.jacobian_head."):
+            p.requires_grad = True
+    target = torch.randn(f["B"], f["R"], 2, generator=torch.Generator().manual_seed(9)) * 3
+    tag = f"train.action@bins[{precision}]"
+    try:
+        model.zero_grad(set_to_none=True)
+        model.training_final_bins = f["bins"].to(dev)
+        out = model.forward(f["cam"], f["rin"], f["rob"])
+        loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, target.to(dev))
+        loss.backward()
+        losses = {}
+
+        def oracle_backward(mode):
+            cv = as_dtype(mode)
+            params = {k: cv(v.clone()) for k, v in case["params"].items()}
+            for k in params:
+                if k.startswith("decoder.jacobian_head."):
+                    params[k].requires_grad_(True)
+            res, _ = _oracle_final_stage(case, params, f["bins"], cv)
+            l = orc.flow_loss(res.optical_flow, cv(target))
+            l.backward()
+            losses[mode] = l.detach().reshape(1)
+            return {n: params["decoder.jacobian_head." + n].grad for n in JACOBIAN_PARAM_ORDER}
+
+        g32, g64 = oracle_backward(None), oracle_backward("fp64")
+        margins(tag, "loss", loss.reshape(1), losses[None], floor=rel(losses["fp64"], losses[None]))
+        head = dict(model.decoder.jacobian_head.named_parameters())
+        failures = []
+        for name in JACOBIAN_PARAM_ORDER:
+            assert head[name].grad is not None and torch.isfinite(head[name].grad).all(), name
+            try:   # the float64 floor ONLY (no self_noise / floor_fp64 pair: the rule cannot fall back on anything else)
+                margins(tag, "grad " + name, head[name].grad, g32[name], ref64=g64[name])
+            except AssertionError as e:
+                failures.append((name, e.args[0] if e.args else None))
+        assert not failures, failures[:4]
+    finally:
+        model.training_final_bins = None
+        for n, p in model.named_parameters():
+            p.requires_grad = req[n]
+        model.zero_grad(set_to_none=True)
+        model.set_precision(hip.DEFAULT_PRECISION)
+
+
+@pytest.mark.parametrize("precision", ["f32", "default"])
+def test_perception_mode_gradients_at_given_bins(fixed, margins, precision):
+    """Perception losses on the final level (rgb mse + L1 depth + 0.08 ds-nerf + 0.01 distortion) at the oracle's final bins:
+    gradients of the density head and the colour head (the proposal nets do not run at given bins; the encoder is the
+    'precomputed' entry here -- its gradient path is covered by test_training_gpu.py)."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import hip
+    from neural_jacobian_field_amd.model_wrapper import distortion_loss
+    f = fixed
+    model, case, dev = f["model"], f["case"], f["dev"]
+    model.set_precision("f32" if precision == "f32" else hip.DEFAULT_PRECISION)
+    req = {n: p.requires_grad for n, p in model.named_parameters()}
+    trainable = ("decoder.density_head.", "decoder.color_head.")
+    for n, p in model.named_parameters():
+        p.requires_grad = n.startswith(trainable)
+    g2 = torch.Generator().manual_seed(21)
+    t_rgb = torch.rand(f["B"], f["R"], 3, generator=g2)
+    t_depth = torch.rand(f["B"], f["R"], 1, generator=g2) * 0.5 + 0.6
+    sigma = torch.tensor([0.05])
+    tag = f"train.perception@bins[{precision}]"
+
+    def loss_fn(rgb, depth, w, starts, ends, edges, dist, to):
+        return (torch.nn.functional.mse_loss(rgb, to(t_rgb)) + 0.1 * (depth - to(t_depth)).abs().mean()
+                + 0.08 * orc.ds_nerf_depth_loss(w, to(t_depth), (starts + ends) / 2, ends - starts, to(sigma)) + 0.01 * dist(w, edges))
+
+    try:
+        model.zero_grad(set_to_none=True)
+        model.train()
+        model.training_final_bins = f["bins"].to(dev)
+        out = model.forward(f["cam"], f["rin"], f["rob"])
+        tr = out.training_output
+        assert len(tr.weights_list) == 1 and tr.weights_list[0].requires_grad
+        smp = tr.ray_samples_list[0]
+        loss = loss_fn(out.standard_output.rgb, out.standard_output.depth, tr.weights_list[0], smp.starts, smp.ends, None,
+                       lambda w, e: distortion_loss(tr.weights_list, tr.ray_samples_list), lambda t: t.to(dev))
+        loss.backward()
+        losses = {}
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+        def oracle_backward(mode):
+            cv = as_dtype(mode)
+            params = {k: cv(v.clone()) for k, v in case["params"].items()}
+            for k in names:
+                params[k].requires_grad_(True)
+            res, s_ = _oracle_final_stage(case, params, f["bins"], cv)
+            w = res.weights_list[0]
+            l = loss_fn(res.rgb, res.depth, w, s_.starts, s_.ends, cv(f["bins"]),
+                        lambda w_, e: orc.distortion_loss(w_[..., 0].reshape(-1, w_.shape[-2]), e.reshape(-1, e.shape[-1])), cv)
+            l.backward()
+            losses[mode] = l.detach().reshape(1)
+            return {n: params[n].grad for n in names}
+
+        g32, g64 = oracle_backward(None), oracle_backward("fp64")
+        margins(tag, "loss", loss.reshape(1), losses[None], floor=rel(losses["fp64"], losses[None]))
+        failures = []
+        own = dict(model.named_parameters())
+        for name in names:
+            assert own[name].grad is not None and torch.isfinite(own[name].grad).all(), name
+            try:
+                margins(tag, "grad " + name, own[name].grad, g32[name], ref64=g64[name])
+            except AssertionError as e:
+                failures.append((name, e.args[0] if e.args else None))
+        assert not failures, failures[:4]
+    finally:
+        model.training_final_bins = None
+        model.eval()
+        for n, p in model.named_parameters():
+            p.requires_grad = req[n]
+        model.zero_grad(set_to_none=True)
+        model.set_precision(hip.DEFAULT_PRECISION)
+
+
+from test_training_gpu import setup  # noqa: E402,F401  (the fixture: a Model on the ResNet encoder, seeded weights, B = 2, 40 rays, 32 + 32)
+
+
+@pytest.mark.parametrize("precision", ["f32", "default"])
+def test_wrapper_perception_step_whole_loss_gradients(setup, margins, precision):  # noqa: F811
+    """(a) ModelWrapper.training_step in perception mode differentiates the reference's WHOLE loss -- rgb + 0.08 ds-nerf (mean
+    over levels, sigma = 1e-3) + 1.0 interlevel + 0.01 distortion (models/model_wrapper.py:117-141; the last two act on
+    weights_list, i.e. on the proposal net) -- and every parameter's gradient is held to its own floors against autograd
+    through the CPU oracle's restatements of the same four terms.  Step 500 of the anneal schedule (anneal = 0.909)."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import hip
+    from neural_jacobian_field_amd.geometry import get_pixel_coordinates
+    from neural_jacobian_field_amd.model_wrapper import ModelWrapper, random_sample_ray_yx_indices
+    s = setup
+    model, case, dev = s["model"], s["case"], s["dev"]
+    model.set_precision("f32" if precision == "f32" else hip.DEFAULT_PRECISION)
+    tag = f"train.wrapper.perception[{precision}]"
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    req = {n: p.requires_grad for n, p in model.named_parameters()}
+    B, H, W, R = 2, 16, 16, 40
+    c = case["cams"]
+    g2 = torch.Generator().manual_seed(31)
+    t_rgb_img = torch.rand(B, 3, H, W, generator=g2)
+    t_depth_img = torch.rand(B, 1, H, W, generator=g2) * 0.6 + 0.7
+    coords_dev, _ = get_pixel_coordinates(H, W, dev)
+    coords_cpu, _ = orc.pixel_grid(H, W)
+    samplers = (model.proposal_sampler.initial_sampler, model.proposal_sampler.pdf_sampler)
+    rcfg = model.cfg.rendering
+    step = 500
+    anneal = orc.anneal_value(step, rcfg.proposal_weights_anneal_max_num_iters, rcfg.proposal_weights_anneal_slope)
+    try:
+        for p in model.parameters():
+            p.requires_grad = True
+        model.zero_grad(set_to_none=True)
+        wrapper = ModelWrapper("perception", R, model).train()
+        model.encoder.eval()   # BatchNorm on running statistics, as the oracle's encoder restatement
+        for smp in samplers:
+            smp.train_stratified = False   # deterministic placement on both sides
+        wrapper.global_step = step
+        batch = {"context": {"rgb": s["image"].to(dev), "extrinsics": c["ctxt_c2w"].to(dev), "intrinsics": c["ctxt_k_norm"].to(dev),
+                             "robot_action": case["action"].to(dev)},
+                 "target": {"rgb": t_rgb_img.to(dev), "depth": t_depth_img.to(dev), "extrinsics": c["trgt_c2w"].to(dev),
+                            "intrinsics": c["trgt_k_norm"].to(dev)},
+                 "scene": {"near": c["z_near"].to(dev), "far": c["z_far"].to(dev), "coordinates": coords_dev[None].expand(B, -1, -1, -1)}}
+        wrapper.on_train_batch_start(batch)   # the anneal of step 500 (training_step's bracket; the sampler's update schedule stays
+        torch.manual_seed(77)                 # at its first step: `updated` = True, the proposal net receives gradient)
+        terms = wrapper.evaluate_losses(batch)
+        assert set(terms) == {"loss/rgb", "loss/depth", "loss/interlevel", "loss/distortion"}
+        loss = sum(terms.values())
+        loss.backward()
+        torch.manual_seed(77)
+        y, x = random_sample_ray_yx_indices(H, W, R)   # the same draw the wrapper made (host logic, pinned by wrapper.npz)
+        xy = coords_cpu[y, x][None].expand(B, -1, -1).contiguous()
+        o0, d0, z = orc.world_rays_with_z(xy, c["trgt_k_norm"], c["trgt_c2w"])
+        t_rgb = t_rgb_img[:, :, y, x].transpose(1, 2)
+        t_depth = t_depth_img[:, :, y, x].transpose(1, 2) / z.reshape(B, R, 1)
+        k_pix = orc.denormalize_intrinsics(c["trgt_k_norm"], W, H)
+        losses, parts = {}, {}
+        names = [n for n, _ in model.named_parameters()]
+        sigma = torch.tensor([0.001])
+
+        def oracle_backward(mode):
+            cv = as_dtype(mode)
+            params = {k: cv(v.clone()) for k, v in s["full"].items()}
+            for k, v in params.items():
+                if v.is_floating_point() and "running_" not in k:
+                    v.requires_grad_(True)
+            origins, directions = moved_rays(o0, d0, mode)
+            source = dict(input_image=cv(s["image"]))
+            if feature_seed(mode) is not None:
+                enc = {k[len("encoder."):]: v for k, v in params.items() if k.startswith("encoder.")}
+                source = dict(features=noisy(orc.encoder_features(enc, cv(s["image"])), seed=feature_seed(mode)))
+            ref = orc.model_forward(params, **source, ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
+                                    trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(k_pix), origins=cv(origins), directions=cv(directions),
+                                    z_near=cv(c["z_near"]), z_far=cv(c["z_far"]), action=cv(case["action"]),
+                                    num_proposal_samples=[s["S"]], num_nerf_samples=s["S"], decoder_kind="jacobian_mlp", anneal=anneal)
+            wl, sl = ref.weights_list, ref.samples_list
+            depth_term = sum(orc.ds_nerf_depth_loss(w, cv(t_depth), (sm.starts + sm.ends) / 2, sm.ends - sm.starts, cv(sigma))
+                             for w, sm in zip(wl, sl)) / len(wl)
+            flat_w = [w[..., 0].reshape(-1, w.shape[-2]) for w in wl]
+            edges = [_bins_of(sm).reshape(-1, sm.spacing_starts.shape[-2] + 1) for sm in sl]
+            t = {"loss/rgb": orc.rgb_loss(ref.rgb, cv(t_rgb)), "loss/depth": 0.08 * depth_term,
+                 "loss/interlevel": 1.0 * orc.interlevel_loss(flat_w, edges), "loss/distortion": 0.01 * orc.distortion_loss(flat_w[-1], edges[-1])}
+            total = sum(t.values())
+            total.backward()
+            losses[mode] = total.detach().reshape(1)
+            parts[mode] = {k: v.detach().reshape(1) for k, v in t.items()}
+            return {n: params[n].grad for n in names}
+
+        base = oracle_backward(None)
+        moved = {mode: oracle_backward(mode) for mode in FLOOR_MODES}
+        for k in terms:   # the four terms individually, then their sum
+            margins(tag, k, terms[k].reshape(1), parts[None][k], floor=max(rel(parts[m][k], parts[None][k]) for m in FLOOR_MODES),
+                    floor_fp64=rel(parts["fp64"][k], parts[None][k]))
+        margins(tag, "loss", loss.reshape(1), losses[None], floor=max(rel(losses[m], losses[None]) for m in FLOOR_MODES),
+                floor_fp64=rel(losses["fp64"], losses[None]))
+        failures = []
+        for name, p in model.named_parameters():
+            g_ref = base[name]
+            if g_ref is None or name.startswith("decoder.jacobian_head."):
+                assert p.grad is None and (g_ref is None or g_ref.abs().max() == 0), name
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            f64 = rel(moved["fp64"][name], g_ref)
+            f_all = max(rel(m[name], g_ref) for m in moved.values())
+            try:
+                margins(tag, "grad " + name, p.grad, g_ref, ref64=moved["fp64"][name], floor=f_all, floor_fp64=f64)
+            except AssertionError as e:
+                d = e.args[0] if e.args and isinstance(e.args[0], dict) else {}
+                failures.append((round(d.get("err", 0.0) / max(d.get("limit", 1.0), 1e-30), 2), name))
+        assert not failures, (len(failures), sorted(failures, reverse=True)[:6])
+    finally:
+        model.load_state_dict(state)
+        for n, p in model.named_parameters():
+            p.requires_grad = req[n]
+        for smp in samplers:
+            smp.train_stratified = True
+        model.proposal_sampler.set_anneal(1.0)
+        model.zero_grad(set_to_none=True)
+        model.eval()
+        model.set_precision(hip.DEFAULT_PRECISION)
+
+
+def test_action_gradients_at_the_reference_batch_shape(margins):
+    """(c) 7 scenes x 256 rays, 64 + 64 samples (configurations/config.yaml:18-20 and the Allegro rendering config): the HIP
+    action-mode step renders and back-propagates through all 1,792 rays; the flow loss reads 37 rays per scene (259 rays: the
+    others receive a zero upstream gradient), which is the batch the CPU oracle evaluates and differentiates."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import njf_oracle as orc
+    import parity_harness as ph
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
+    dev = torch.device("cuda:0")
+    B, H, W, R, S, SUB = 7, 32, 32, 256, 64, 37
+    case = ph.make_case(B, H, W, R, 8, seed=12, identity_context=False)
+    model = Model(model_cfg_from_dict({"action_dim": 8, "encoder": {"name": "precomputed"},
+                                       "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                                       "action_decoder": {"name": "jacobian_mlp"}}))
+    model.load_state_dict(case["params"], strict=True)
+    model.to(dev).eval()
+    model.encoder.set_features(case["feats"].to(dev))
+    model.decoder.freeze_non_action_parameters()
+    for n, p in model.named_parameters():
+        if "decoder" not in n:
+            p.requires_grad = False
+    idx = torch.randperm(R, generator=torch.Generator().manual_seed(5))[:SUB].sort().values
+    target = torch.randn(B, SUB, 2, generator=torch.Generator().manual_seed(6)) * 3
+    c = case["cams"]
+    d = lambda t: t.to(dev)
+    cam = CameraInput(None, d(c["ctxt_c2w"]), d(c["ctxt_k_norm"]), d(c["trgt_c2w"]), d(case["k_pix"]))
+    rin = RenderingInput(d(case["origins"]), d(case["directions"]), d(c["z_near"]), d(c["z_far"]))
+    out = model.forward(cam, rin, RobotInput(d(case["action"])))
+    flow = out.standard_output.optical_flow
+    assert flow.shape == (B, R, 2) and flow.requires_grad
+    loss = 0.01 * torch.nn.functional.mse_loss(flow[:, idx.to(dev)], target.to(dev))
+    loss.backward()
+    losses = {}
+    modes = ("fp64",) + tuple(f"rays{k}" for k in (1, 2))   # (the features are identical on both sides: no feature floors)
+
+    def oracle_backward(mode):
+        cv = as_dtype(mode)
+        params = {k: cv(v.clone()) for k, v in case["params"].items()}
+        for k in params:
+            if k.startswith("decoder.jacobian_head."):
+                params[k].requires_grad_(True)
+        origins, directions = moved_rays(case["origins"][:, idx].contiguous(), case["directions"][:, idx].contiguous(), mode)
+        ref = orc.model_forward(params, features=cv(case["feats"]), ctxt_c2w=cv(c["ctxt_c2w"]), ctxt_k_norm=cv(c["ctxt_k_norm"]),
+                                trgt_c2w=cv(c["trgt_c2w"]), trgt_k_pix=cv(case["k_pix"]), origins=cv(origins), directions=cv(directions),
+                                z_near=cv(c["z_near"]), z_far=cv(c["z_far"]), action=cv(case["action"]),
+                                num_proposal_samples=[S], num_nerf_samples=S, decoder_kind="jacobian_mlp")
+        l = orc.flow_loss(ref.optical_flow, cv(target))
+        l.backward()
+        losses[mode] = l.detach().reshape(1)
+        return {n: params["decoder.jacobian_head." + n].grad for n in JACOBIAN_PARAM_ORDER}
+
+    base = oracle_backward(None)
+    moved = {m: oracle_backward(m) for m in modes}
+    tag = "train.action@reference-shape[7x256, 64+64]"
+    margins(tag, "loss", loss.reshape(1), losses[None], floor=max(rel(losses[m], losses[None]) for m in modes),
+            floor_fp64=rel(losses["fp64"], losses[None]))
+    head = dict(model.decoder.jacobian_head.named_parameters())
+    failures = []
+    for name in JACOBIAN_PARAM_ORDER:
+        assert head[name].grad is not None and torch.isfinite(head[name].grad).all(), name
+        try:
+            margins(tag, "grad " + name, head[name].grad, base[name], ref64=moved["fp64"][name],
+                    floor=max(rel(m[name], base[name]) for m in moved.values()), floor_fp64=rel(moved["fp64"][name], base[name]))
+        except AssertionError as e:
+            failures.append((name, e.args[0] if e.args else None))
+    assert not failures, failures[:4]

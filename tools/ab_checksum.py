@@ -11,15 +11,19 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
-import parity_harness as ph  # noqa: E402
-from neural_jacobian_field_amd.renderer import RenderRequest  # noqa: E402
+sys.path.insert(0, ROOT)
+from neural_jacobian_field_amd import hip, synthetic  # noqa: E402
+from neural_jacobian_field_amd.renderer import FusedRenderer, RenderRequest  # noqa: E402
 
 dev = torch.device("cuda:0")
-case = ph.make_case(2, 32, 48, 700, 8, seed=7, identity_context=False)
+case = synthetic.synthetic_case(2, 32, 48, 700, 8, seed=7, device=dev, identity_context=False)   # package-only inputs: no oracle/
+c = case["cams"]
 req = RenderRequest(vis=True, sample_weights=True, per_sample=True)
 for prec in ("f16x2", "f32"):
-    res, _, _ = ph.hip_forward(case, 64, 64, dev, request=req, precision=prec)
+    fr = FusedRenderer(dev, 1, 8, precision=prec)
+    fr.load_weights(case["params"])
+    res = fr.render(case["feats"], case["origins"], case["directions"], c["ctxt_c2w"], c["ctxt_k_norm"], c["z_near"], c["z_far"],
+                    [64], 64, trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], action=case["action"], request=req)
     torch.cuda.synchronize()
     h = hashlib.sha256()
     for t in [res.rgb, res.depth, res.optical_flow, res.bins_list[-1]] + [res.extras[k] for k in sorted(res.extras)]:

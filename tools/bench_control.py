@@ -6,8 +6,7 @@ infer_optical_flow (notebooks/real_world/2_inverse_dynamics.ipynb cells 26-29)."
 import json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
-import parity_harness as ph
+sys.path.insert(0, ROOT)
 from neural_jacobian_field_amd import inverse_dynamics as idyn, synthetic
 from neural_jacobian_field_amd.config import model_cfg_from_dict
 from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
@@ -15,7 +14,7 @@ from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)  # the flow residual of the solve depends on the drawn image / command
 B, H, W, R, S, A = 1, 256, 256, int(os.environ.get("RAYS", 256)), 64, 8
-case = ph.make_case(B, H, W, R, A, seed=0)
+case = synthetic.synthetic_case(B, H, W, R, A, seed=0, device=dev)   # package-only inputs: the tool travels without oracle/
 model = Model(model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
                                    "action_decoder": {"name": "jacobian_mlp"}}))
 sd = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", A), seed=0)

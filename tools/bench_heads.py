@@ -4,15 +4,14 @@ C2 shape (B=1, 256x256 rays, 64+64 samples, A=8), encoder excluded (features giv
 import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
-import parity_harness as ph
+sys.path.insert(0, ROOT)
 from neural_jacobian_field_amd import synthetic
 from neural_jacobian_field_amd.config import model_cfg_from_dict
 from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
 
 dev = torch.device("cuda:0")
 B, H, W, S, A = 1, 256, 256, 64, 8
-case = ph.make_case(B, H, W, None, A, seed=0)
+case = synthetic.synthetic_case(B, H, W, None, A, seed=0, device=dev)   # package-only inputs: the tool travels without oracle/
 c = case["cams"]; d = lambda t: t.to(dev)
 res = {}
 for kind in ("jacobian_mlp", "jacobian_transformer"):

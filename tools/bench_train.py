@@ -34,6 +34,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank")
+    ap.add_argument("--scenes", type=int, default=7, help="scenes per rank (reference: 7, configurations/config.yaml:18-20)")
+    ap.add_argument("--rays", type=int, default=256, help="rays per scene (reference: 256)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=1234, help="torch seed of every rank (stratified jitter): the same step twice gives the same loss")
     ap.add_argument("--start-step", type=int, default=0,
                     help="global step of the first iteration (20000: steady state -- anneal exponent 1, proposal nets updated every sixth step)")
     args = ap.parse_args()
@@ -59,7 +64,8 @@ def main():
 
     if os.environ.get("NJF_MIOPEN_FIND"):
         torch.backends.cudnn.benchmark = True
-    B, H, W, R, S, A = 7, 256, 256, 256, 64, 8
+    B, H, W, R, S, A = args.scenes, args.height, args.width, args.rays, 64, 8
+    torch.manual_seed(args.seed)
     model = Model(model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
                                        "action_decoder": {"name": "jacobian_mlp"}}))
     model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", A), seed=0))   # replicated weights
@@ -131,7 +137,7 @@ def main():
     bucket = sum(p.numel() for p in trainable) * 4
     if rank == 0:
         dt = elapsed / args.steps
-        line = {"metric": "training rays/s (config 4: 7 scenes x 256 rays per rank, 64+64 samples, fwd + bwd + gradient all-reduce + Adam)",
+        line = {"metric": f"training rays/s (config 4: {B} scene(s) x {R} rays per rank, 64+64 samples, fwd + bwd + gradient all-reduce + Adam)",
                 "value": round(world * B * R / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * dt, 3), "training_step_ms": round(1e3 * dt, 2), "higher_is_better": True, "scaling": "weak",
                 "rays_per_step": world * B * R, "samples": f"{S}+{S}", "train_rays_per_s": round(world * B * R / dt, 1),

@@ -1,4 +1,5 @@
-"""Pick the host thread count for bench.py's cpu_baseline leg (run once on the GPU box)."""
+"""Pick the host thread count for bench.py's cpu_baseline leg (run once on the GPU box).  Times the CPU ORACLE itself, so it
+needs oracle/ next to the package (the only kind of tool that does: it measures / verifies with the checker)."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]

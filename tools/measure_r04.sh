@@ -56,7 +56,9 @@ ablate)    # experiment builds (build/libnjf_ablate_<v>.so, -DNJF_ABLATE_<V>): k
     done
   done | tee $O/ablate.txt
   unset NJF_HIP_LIB ;;
-mix)       # VERDICT r03 "next" #5: the first n wide layers of the (f16x2) proposal net on the fp6-corrected product form
+mix)       # VERDICT r03 "next" #5: the first n wide layers of the (f16x2) proposal net on the fp6-corrected product form.
+           # (round 5: the kernel switch -DNJF_PROPOSAL_MIX and the host splice it needed were removed from the product -- ADVICE r04;
+           #  the experiment is reproducible from commit b0f5543, its result is profiles/r04_proposal_layer_mix_gpu.txt)
   for n in 0 2 3 5; do
     if [ $n = 0 ]; then unset NJF_HIP_LIB NJF_PROPOSAL_MIX; else export NJF_HIP_LIB=$PWD/build/libnjf_mix$n.so NJF_PROPOSAL_MIX=$n; fi
     timeout 300 python bench.py --precision f16f6 --no-other-precisions --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/mix$n.json

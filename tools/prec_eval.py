@@ -4,7 +4,8 @@ parity-suite cases (with the fp32-vs-fp64 noise floor of the oracle beside them)
 
     python tools/prec_eval.py [--quick] > gpurun_out/prec_eval.log
 
-Experiment tooling; not part of the product path."""
+Experiment tooling; not part of the product path.  It VERIFIES against the CPU oracle (oracle/parity_harness.py), so it needs
+oracle/ next to the package -- inputs-only tools build their frames with synthetic.synthetic_case instead."""
 import json
 import os
 import sys

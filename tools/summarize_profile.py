@@ -18,16 +18,17 @@ prec = sys.argv[2] if len(sys.argv) > 2 else "f16x2"
 src = f"gpurun_out/prof_{tag}_{prec}"
 round_tag = tag
 tag = f"{tag}_{prec}"
+bench_args = " ".join(sys.argv[3:])   # what the profiled bench ran with besides the defaults (e.g. --height 512 --width 512)
 # per MFMA instruction: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16.  The f16f6 kernels issue two kinds (f16 K=16:
 # 32 cycles, 32,768 FLOP; fp6 K=64: 32 cycles, 131,072 FLOP) in the ratio 2:1 -> 65,536 FLOP per instruction on average
-MFMA_FLOP = {"f32": 4096, "f16x2": 32768, "f16f6": 65536}[prec]
+MFMA_FLOP = {"f32": 4096, "f16x2": 32768, "f16f6": 65536, "f16": 32768}[prec]
 MFMA_CYCLES = 64 if prec == "f32" else 32
 os.makedirs("profiles", exist_ok=True)
 # the traced command may fork helpers, each leaving its own stats file: take the one that holds the fused kernels
 stats = max(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=lambda f: open(f).read().count("render_kernel"))
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
-PCODE = {"f32": 0, "f16x2": 1, "f16f6": 2}[prec]    # template argument of this precision's instantiations
+PCODE = {"f32": 0, "f16x2": 1, "f16f6": 2, "f16": 3}[prec]    # template argument of this precision's instantiations
 PROP = 1 if prec == "f16f6" else PCODE              # under f16f6 the proposal networks stay on f16x2 (Model.set_precision)
 KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PROP},": "proposal",
            ("project_kernel(" if prec == "f32" else "project_kernel_f16x2<"): "project"}
@@ -46,8 +47,8 @@ for r in csv.DictReader(open(stats)):
         if pat in r["Name"]:
             dur[short] = float(r["AverageNs"]) * 1e-9
 
-lines = [f"# {tag}: rocprofv3 PMC summary (MI355X; durations from `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3`, counters from `--pmc` runs of `bench.py --steps 2 --warmup 1`, per-launch means)", "",
-         f"Collected by `tools/profile_{round_tag}.sh {prec}`: kernel-trace/stats and each PMC group in separate runs.", "",
+lines = [f"# {tag}: rocprofv3 PMC summary (MI355X; durations from `rocprofv3 --kernel-trace --stats -- python bench.py --precision {prec} {bench_args} --steps 20 --warmup 3`, counters from `--pmc` runs of the same command with `--steps 2 --warmup 1`, per-launch means)", "",
+         f"Collected by `tools/profile_{round_tag.split('_')[0]}.sh {prec} {round_tag}`: kernel-trace/stats and each PMC group in separate runs.", "",
          "| kernel | avg duration (kernel-trace) | launch config |", "|---|---|---|"]
 for k in ("project", "proposal", "render"):
     lines.append(f"| {k} | {dur[k]*1e3:.3f} ms | {meta.get(k)} |")
@@ -64,7 +65,7 @@ for k in ("proposal", "render"):
     mfma_util_insts = mean[(k, "SQ_INSTS_MFMA")] * MFMA_CYCLES / (1024 * dur[k] * 2.4e9)   # at the 2.4 GHz peak clock
     fetch, write = mean[(k, "FETCH_SIZE")] * 1024, mean[(k, "WRITE_SIZE")] * 1024
     hbm = 2 * fetch + write   # gfx950: FETCH_SIZE reports half of wide (16 B/lane) reads (MI355X_MICROARCH.md, HBM)
-    l2 = mean[(k, "TCC_HIT_sum")] / (mean[(k, "TCC_HIT_sum")] + mean[(k, "TCC_MISS_sum")])
+    l2 = (mean[(k, "TCC_HIT_sum")] / (mean[(k, "TCC_HIT_sum")] + mean[(k, "TCC_MISS_sum")])) if (k, "TCC_HIT_sum") in mean else float("nan")
     wc = mean[(k, "SQ_WAVE_CYCLES")]
     lines += [f"### {k}",
               f"* effective clock {clock/1e9:.2f} GHz; issued MFMA work {flop/1e12:.3f} TFLOP (incl. zero padding) "
@@ -84,6 +85,11 @@ for k in ("proposal", "render"):
               f"* L2 hit rate {100*l2:.1f} %; memory-side traffic: FETCH_SIZE {fetch/1e9:.2f} GB (x2 correction -> "
               f"{2*fetch/1e9:.2f} GB), WRITE_SIZE {write/1e9:.2f} GB -> {hbm/1e9:.2f} GB per launch "
               f"({hbm/dur[k]/1e12:.2f} TB/s; includes Infinity-Cache hits and scratch spill traffic)", ""]
+    if (k, "TA_TA_BUSY_sum") in mean:   # texture-addresser occupancy: summed over the TA instances (one per CU)
+        ta = mean[(k, "TA_TA_BUSY_sum")]
+        lines += [f"* texture addresser (vector-memory issue path: gathers + the weight stream's LDS-DMA): TA_TA_BUSY_sum {ta:.3g} cycles "
+                  f"over 256 CUs = {100 * ta / 256 / xcd_cycles:.0f} % of the kernel's cycles per CU"
+                  + (f"; TA_BUSY_avr {mean[(k, 'TA_BUSY_avr')]:.3g}, TA_BUSY_max {mean[(k, 'TA_BUSY_max')]:.3g}" if (k, "TA_BUSY_avr") in mean else ""), ""]
     if k == "render":
         out_json = {"kernel": f"render_kernel<jacobian_mlp, {prec}>", "hbm_bytes_per_launch": hbm, "fetch_size_bytes_raw": fetch,
                     "write_size_bytes": write, "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), rocprofv3 --pmc, "
