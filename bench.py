@@ -156,9 +156,9 @@ def emit(line: dict, gpus: int) -> None:
     from neural_jacobian_field_amd import launch
     launch.check_line(line, gpus)
     import ctypes
-    ctypes.CDLL(None).fflush(None)  # anything native libraries buffered on stdout goes out BEFORE the JSON line
+    ctypes.CDLL(None).fflush(None)  # anything native libraries buffered goes out first (to stderr once stdout is reserved)
     sys.stdout.flush()
-    print(json.dumps(line), flush=True)
+    launch.print_line(line)         # the process's ORIGINAL stdout: nothing else is ever written there (launch.reserve_stdout)
 
 
 def cpu_baseline(case, ray_index, passes: int):
@@ -285,6 +285,7 @@ def main():
     dry = args.dry_launch is not None
     # a plain process with --gpus N > 1 spawns its N ranks and exits with their status; under a launcher the world is checked
     launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_devices=not dry)
+    launch.reserve_stdout()   # from here on only the JSON line reaches this rank's stdout (native libraries print to stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

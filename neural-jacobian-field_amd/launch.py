@@ -72,7 +72,7 @@ def init_process_group(backend: str, device: Optional[torch.device] = None):
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         kw = dict(store=dist.TCPStore("127.0.0.1", 0, 1, is_master=True), rank=0, world_size=1)
     if backend == "nccl":
-        os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's banner would precede the one JSON line on stdout
+        reserve_stdout()   # RCCL prints its version banner on stdout when the first communicator is created
         dist.init_process_group("nccl", device_id=device, **kw)
     else:
         dist.init_process_group(backend, **kw)
@@ -131,6 +131,30 @@ def rank_evidence(dist, device: torch.device, local_step_ms: float, graph: bool 
         out["transport_env"] = {k: os.environ[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES",
                                                           "ROCR_VISIBLE_DEVICES") if k in os.environ}
     return out
+
+
+_line_stream = None
+
+
+def reserve_stdout():
+    """Make the process's stdout carry the ONE JSON line and nothing else: the original descriptor is kept for ``print_line``,
+    descriptor 1 itself is pointed at stderr, so whatever native libraries print (RCCL's version banner at communicator
+    creation -- it appears at NCCL_DEBUG=WARN too, found by tests/test_rccl_gpu.py in round 5 --, MIOpen warnings) cannot
+    precede or follow the line.  Idempotent; call before the process group is initialised."""
+    global _line_stream
+    if _line_stream is None:
+        sys.stdout.flush()
+        _line_stream = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _line_stream
+
+
+def print_line(line: Dict) -> None:
+    """The JSON line, on the process's ORIGINAL stdout (see reserve_stdout)."""
+    import json
+    out = reserve_stdout()
+    out.write(json.dumps(line) + "\n")
+    out.flush()
 
 
 def check_line(line: Dict, gpus: int) -> Dict:

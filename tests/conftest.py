@@ -46,7 +46,8 @@ def _rel(a, b):
 
 @pytest.fixture(scope="session")
 def margins():
-    def check(case, key, got, ref32, ref64=None, tol=1e-4, floor=None, self_noise=(), floor_fp64=None, truth_assert=False):
+    def check(case, key, got, ref32, ref64=None, tol=1e-4, floor=None, self_noise=(), floor_fp64=None, truth_assert=False,
+              factor=2.0):
         """assert rel(got, ref32) <= max(tol, 2 * floor_fp64), floor_fp64 = rel(ref32, ref64): the reference's fp32 run
         against its float64 run (or the explicit ``floor_fp64`` / ``floor``).  Only where that fails are the `self_noise`
         figures consulted -- how far the reference's OWN fp32 output moves when its inputs move by what no fp32
@@ -54,7 +55,8 @@ def margins():
         MIOpen-vs-ATen difference) -- and the row is marked ``self_noise_floor_used``; the limit is capped at
         SELF_NOISE_CEILING.  ``floor`` together with ``floor_fp64``: floor = the largest of all floors of that quantity,
         floor_fp64 = its fp64 part (gradient tests).  ``ref64`` (a float64 tensor) additionally records the truth-referenced
-        element-wise row of this comparison (asserted with ``truth_assert`` on tensors of >= 1,024 elements)."""
+        element-wise row of this comparison (asserted with ``truth_assert`` on tensors of >= 1,024 elements).  ``factor``: the
+        multiple of the fp64 floor (default 2; the given-bins gradient rows of the DEFAULT precision state 4, see there)."""
         err = _rel(got, ref32)
         truth_failure = None
         if ref64 is not None:
@@ -71,7 +73,7 @@ def margins():
         if floor is None:
             floor = _rel(ref32, ref64) if ref64 is not None else 0.0
         floor64 = floor if floor_fp64 is None else float(floor_fp64)
-        limit = max(tol, 2.0 * floor64)
+        limit = max(tol, factor * floor64)
         used_self_noise = False
         noise = max([float(f) for f in self_noise] + ([floor] if floor_fp64 is not None else []), default=0.0)
         if not err <= limit and noise > floor64:
@@ -81,7 +83,7 @@ def margins():
             used_self_noise = True
         row = {"case": case, "key": key, "err": float(f"{err:.3e}"), "floor": float(f"{(noise if used_self_noise else floor64):.3e}"),
                "floor_fp64": float(f"{floor64:.3e}"), "limit": float(f"{limit:.3e}"), "needs_floor": bool(err > tol),
-               "self_noise_floor_used": used_self_noise, "ok": bool(err <= limit)}
+               "self_noise_floor_used": used_self_noise, "ok": bool(err <= limit), **({"floor_factor": factor} if factor != 2.0 else {})}
         _MARGIN_ROWS.append(row)
         if not err <= limit:   # (raised by hand: the payload stays a dict for callers that collect several failures)
             raise AssertionError({"case": case, "key": key, "err": err, "floor_fp64": floor64, "self_noise": noise, "limit": limit})

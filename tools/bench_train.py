@@ -44,6 +44,7 @@ def main():
     args = ap.parse_args()
     mode = args.mode or args.mode_pos or "action"
     launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    launch.reserve_stdout()   # only the JSON line reaches stdout (RCCL's banner, MIOpen's notes go to stderr)
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -149,7 +150,7 @@ def main():
                            "parallelism": f"dp{world}"},
                 "rccl": evidence}
         launch.check_line(line, args.gpus)
-        print(json.dumps(line), flush=True)
+        launch.print_line(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
