@@ -562,6 +562,9 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
     // 32-clock MFMA hides ~5 single-issue instructions, MI355X_MICROARCH.md).
     const f16x8* base = (const f16x8*)wl + lane;
     constexpr int T = NKB * 2;
+#ifdef NJF_F16_SETPRIO   // A/B builds: the wave inside a chunk's MFMA stream outranks its SIMD neighbour's VALU phases
+    __builtin_amdgcn_s_setprio(NJF_F16_SETPRIO);
+#endif
     unsigned bc[4], bn[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) bc[p] = pack_pair_f16<RELU>(in[KB0][2 * p], in[KB0][2 * p + 1]);
@@ -578,10 +581,22 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
           for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
         }
         if constexpr (SPREAD) {  // the next chunk's 8 DMA rounds, two behind each of the first four steps
+#if defined(NJF_F16_DMA_PLACE) && NJF_F16_DMA_PLACE == 1   // A/B builds: one round per step (8-step chunks)
+          if (T == 8 ? true : t < 4) {
+            if (T == 8) dma_issue(st, t);
+            else { dma_issue(st, 2 * t); dma_issue(st, 2 * t + 1); }
+          }
+#elif defined(NJF_F16_DMA_PLACE) && NJF_F16_DMA_PLACE == 2  // A/B builds: the whole chunk as one burst behind the barrier
+          if (t == 0) {
+#pragma unroll
+            for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
+          }
+#else
           if (t < 4) {
             dma_issue(st, 2 * t);
             dma_issue(st, 2 * t + 1);
           }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -619,6 +634,9 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
         for (int p = 0; p < 4; ++p) bc[p] = bn[p];
       }
     }
+#ifdef NJF_F16_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   } else {
     // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
     // Lane (j,hh) supplies its own registers 8*tt .. 8*tt+7 of block kb as the 8 k-values of step t = 2*kb + tt.
