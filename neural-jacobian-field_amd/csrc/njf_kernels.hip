@@ -2780,15 +2780,17 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   a.out = *out;
   hipStream_t s = (hipStream_t)stream;
   const int n = a.rc.total_rays;
-#ifdef NJF_TRAIN_AF   // A/B builds only (tools/measure_r05.sh spills): the round-4 training instantiations, with the 16 accumulators
-  constexpr bool TRAIN_AF = true;
-#else
+  // Training forwards keep the AF = true instantiations (the 16 action-feature accumulators stay allocated although no training
+  // forward composites them any more, model.py::_vis_at_bins).  Round 5 built the AF = false ones to get the dump kernels off the
+  // spill path -- 104-119 spilled VGPRs -> 45-68 -- and measured them SLOWER or equal on the C4 shard (1 x 8,192 rays: action step
+  // 8.56 vs 8.34 ms, perception 13.63 vs 13.67 ms, two repetitions each, profiles/r05_spills_ab.txt): the spills are not what
+  // these kernels wait for.  -DNJF_TRAIN_NO_AF rebuilds the A/B.
+#ifdef NJF_TRAIN_NO_AF
   constexpr bool TRAIN_AF = false;
+#else
+  constexpr bool TRAIN_AF = true;
 #endif
   const bool training_forward = out->jac_act != nullptr || out->jac_pe != nullptr || out->den_act != nullptr;
-  // Training forwards never composite the action features (sum_s w J: 16 more live accumulators per lane cost the dump
-  // instantiations ~80 spilled VGPRs, and no loss reads them): a caller that wants them next to a training forward renders
-  // them with an inference call at the same bins (model.py does)
   if (!TRAIN_AF && training_forward && out->action_features != nullptr) return NJF_E_MODE;
   if (out->jac_act != nullptr || (out->jac_pe != nullptr && out->den_act == nullptr)) {
     // action-mode training forward: dump the Jacobian head's backward-pass inputs (ResnetFC head: activations +

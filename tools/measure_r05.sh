@@ -44,9 +44,10 @@ train)     # SURVEY's C4 as written: one rank of an 8-way split of a C2-shaped b
     timeout 600 python tools/bench_train.py --mode $m --force-dist --start-step 20000 > $O/train_ref_$m.json 2>> $O/train_ref.err
     tail -1 $O/train_ref_$m.json | cut -c1-300
   done ;;
-spills)    # A/B: the round-4 training instantiations (16 action-feature accumulators: 104-119 spilled VGPRs) against the shipped
-           # ones (45-68), same box, C4 shard
-  for v in shipped train_af shipped train_af; do
+spills)    # A/B: training instantiations WITHOUT the 16 action-feature accumulators (build/libnjf_train_noaf.so, -DNJF_TRAIN_NO_AF: 45-68
+           # spilled VGPRs) against the shipped ones (104-119), same box, C4 shard.  (Round 5 ran it the other way round -- the library
+           # then shipped was the no-AF one, build/libnjf_train_af.so the round-4 form -- and kept the faster: profiles/r05_spills_ab.txt)
+  for v in shipped train_noaf shipped train_noaf; do
     if [ $v = shipped ]; then unset NJF_HIP_LIB; else export NJF_HIP_LIB=$PWD/build/libnjf_$v.so; fi
     for m in action perception; do
       timeout 300 python tools/bench_train.py --mode $m --scenes 1 --rays 8192 --start-step 20000 --steps 20 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', '$m', d['ms_per_step'])"
@@ -58,7 +59,7 @@ patch)
 abinit)
   timeout 600 python tools/ab_reference_init.py > $O/ab_reference_init.json 2> $O/ab_reference_init.err; echo "abinit rc=$?"
   python -c "
-import json; d=json.load(open('$O/ab_reference_init.json')); print({k: d[k] for k in ('initial_loss','final_loss','default_vs_f32','f32+ulp_vs_f32','ratio_default_over_ulp')})" ;;
+import json; d=json.load(open('$O/ab_reference_init.json')); [print(k, v['summary']) for k, v in d['regimes'].items()]" ;;
 heads)
   timeout 300 python tools/bench_heads.py > $O/heads.json 2>/dev/null; cat $O/heads.json
   timeout 300 python tools/bench_control.py > $O/control.json 2>/dev/null; cat $O/control.json ;;
