@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 H = W = 256
 S_PROP, S_FINAL, ACTION_DIM = 64, 64, 8
-PROFILE_ROUNDS = ("r04", "r03")   # newest first: where roofline.traffic (PMC passes, never taken in the timed run) is looked up
+PROFILE_ROUNDS = ("r05", "r04", "r03")   # newest first: where roofline.traffic (PMC passes, never taken in the timed run) is looked up
 HEADLINE_PRECISION = "f32"        # the reference's arithmetic; see the module docstring
 
 # Algorithmic work (hoisted-lin_z formulation), MACs per point
@@ -478,7 +478,7 @@ def main():
                     with open(pmc) as f:
                         traffic = json.load(f).get("hbm_bytes_per_launch")
                     traffic_source = (f"NOT measured in this run: read from profiles/{os.path.basename(pmc)} (rocprofv3 --pmc passes "
-                                      "of this command on an earlier box, tools/profile_r04.sh + tools/summarize_profile.py)")
+                                      "of this command on an earlier box, tools/profile_rNN.sh + tools/summarize_profile.py)")
                     break
         return {"kernel": f"render_kernel<jacobian_mlp, {prec}> (density+colour+Jacobian MLPs + compositing)",
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",

@@ -17,16 +17,16 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --precision $PREC --no-other-precisions --no-cpu-baseline $EXTRA"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 20 --warmup 3 > $OUT/trace.log 2>&1
 [ "$PMC" = none ] && { ls $OUT; exit 0; }
-GROUPS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
+PMC_GROUPS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU")
 if [ "$PMC" = full ]; then
-  GROUPS+=("TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"
+  PMC_GROUPS+=("TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM"
            "TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max"
            "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum")
 fi
 i=0
-for grp in "${GROUPS[@]}"; do
+for grp in "${PMC_GROUPS[@]}"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- $BENCH --steps 2 --warmup 1 > $OUT/pmc$i.log 2>&1
 done
