@@ -82,7 +82,7 @@ DTYPE_TEXT = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)    # (2 s of timed headline steps: long enough for a 1-s utilisation sampler to see them)
     ap.add_argument("--warmup", type=int, default=5)   # >= 5 warm-ups, >= 20 timed steps
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: split ONE frame's rays over the ranks (SURVEY 8e, default) or one full frame per rank")

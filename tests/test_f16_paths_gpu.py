@@ -174,3 +174,21 @@ def test_f16_is_bit_reproducible_and_shard_exact(dev):  # noqa: F811
     sub = dict(case, origins=case["origins"][:, 100:231].contiguous(), directions=case["directions"][:, 100:231].contiguous())
     c, _, _ = ph.hip_forward(sub, 64, 64, dev, request=RenderRequest(), precision="f16")
     assert torch.equal(c.rgb, a.rgb[:, 100:231]) and torch.equal(c.optical_flow, a.optical_flow[:, 100:231])
+
+
+def test_f16_shading_with_compensated_placement(model_and_golden):  # noqa: F811
+    """set_precision("f16", proposal_precision="f16x2"): the proposal pass keeps fp32-class sample PLACEMENT (its own fp32 hoisted
+    map; the networks no longer share one projection), only the final pass runs in plain fp16 -- the end-to-end pixels are then
+    within the per-network figure of the exact-fp32 frame instead of carrying placement noise."""
+    model, g = model_and_golden
+    try:
+        with _from_reference_features(model, g):
+            model.set_precision("f16", proposal_precision="f16x2")
+            assert model.decoder.precision == "f16" and all(p.precision == "f16x2" for p in model.proposal_networks)
+            mixed = model.forward(*_inputs(g)).standard_output
+            model.set_precision("f32")
+            exact = model.forward(*_inputs(g)).standard_output
+    finally:
+        model.set_precision("f16x2")
+    errs = {"rgb": rel(mixed.rgb, exact.rgb), "depth": rel(mixed.depth, exact.depth), "flow": rel(mixed.optical_flow, exact.optical_flow)}
+    assert errs["rgb"] < AT_POSITIONS and errs["depth"] < AT_POSITIONS and errs["flow"] < 2e-2, errs
