@@ -545,7 +545,8 @@ def main():
                     "kernel_ms": {k: round(v, 3) for k, v in run["kernel_ms"].items()}, "roofline": rf,
                     "note": "an accelerated mode held to the same parity bounds (parity_on_bench_frame, profiles/r04_parity_margins.json); "
                             "its products are not fp32 products, so it is not the headline"}
-        out["parity_note"] = ("every precision is held to the SAME bound against the CPU oracle / the reference's goldens: "
+        out["parity_note"] = ("every PARITY precision (f32, f16x2, f16f6) is held to the SAME bound against the CPU oracle / the reference's goldens "
+                              "(the reduced-precision mode f16 has its own stated rule: other_precisions.f16.tolerance): "
                               "max(1e-4, 2 x the reference's own fp32-vs-fp64 difference of that quantity), and is reported "
                               "element-wise against the float64 truth next to the reference's own fp32 error (truth columns).  rgb, "
                               "depth and the per-sample fields meet north_star's 1e-4; END-TO-END optical_flow is bounded by the "

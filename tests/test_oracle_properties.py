@@ -57,3 +57,40 @@ def test_anneal_schedule_is_monotone_bias(seed, step, max_iters, slope):
     a0, a1 = orc.anneal_value(step, max_iters, slope), orc.anneal_value(step + 1, max_iters, slope)
     assert 0.0 <= a0 <= 1.0 and a1 >= a0 - 1e-12
     assert orc.anneal_value(0, max_iters, slope) == 0.0 and abs(orc.anneal_value(max_iters, max_iters, slope) - 1.0) < 1e-12
+
+
+def test_operand_rounding_model_of_the_plain_fp16_mode():
+    """oracle/njf_oracle.py::operand_rounding -- the yardstick of the reduced-precision GPU rows (round 5): outside the context
+    the oracle is untouched; inside it every Linear sees fp16-rounded inputs and weights (the hoisted lin_z layers round their
+    output), which moves a ResnetFC's output by the per-network figure the stated tolerance is built on (~1e-3 norm-wise)."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import synthetic
+    p = {k[len("decoder.density_head."):]: v for k, v in
+         synthetic.seeded_state_dict(synthetic.decoder_shapes("jacobian_mlp", 8), seed=3).items() if k.startswith("decoder.density_head.")}
+    g = torch.Generator().manual_seed(5)
+    z, x = torch.randn(1, 300, 512, generator=g), torch.randn(1, 300, 63, generator=g)
+    base = orc.resnet_fc(p, z, x)
+    with orc.operand_rounding("f16"):
+        assert orc._OPERAND_ROUNDING == "f16"
+        a = orc.resnet_fc(p, z, x)
+        b = orc.resnet_fc(p, z, x)
+    assert orc._OPERAND_ROUNDING is None and torch.equal(a, b)
+    assert torch.equal(orc.resnet_fc(p, z, x), base)
+    err = ((a - base).abs().max() / base.abs().max()).item()
+    assert 1e-4 < err < 5e-3, err
+    # the context restores the mode when its body raises, and refuses unknown modes
+    try:
+        with orc.operand_rounding("f16"):
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert orc._OPERAND_ROUNDING is None
+    import pytest
+    with pytest.raises(ValueError):
+        orc.operand_rounding("bf16")
+    # one Linear: exactly F.linear of the rounded operands, bias in the working precision
+    w, bias, inp = torch.randn(7, 5, generator=g), torch.randn(7, generator=g), torch.randn(3, 5, generator=g)
+    with orc.operand_rounding("f16"):
+        got = orc._affine({"l.weight": w, "l.bias": bias}, "l", inp)
+    want = torch.nn.functional.linear(inp.half().float(), w.half().float(), bias)
+    assert torch.equal(got, want)
