@@ -149,7 +149,9 @@ int njf_invert_4x4(const float* matrices, int count, float* out, void* stream);
 /* Packs one ResnetFC into `w_out` [NJF_RESNET_W_FLOATS] / `b_out` [NJF_RESNET_B_FLOATS] and its
  * three lin_z layers into `wz_out` [512,384] (k-major) / `bz_out` [384] (inputs of
  * njf_project_features).  Replaces nothing in the reference: it is the layout change that lets
- * ResnetFC.forward (resnet_fc.py:130-154) run as one fused kernel. */
+ * ResnetFC.forward (resnet_fc.py:130-154) run as one fused kernel.  NJF_PRECISION_F16: `wz_out` / `bz_out` are REQUIRED -- the
+ * biases of blocks 0 and 1's fc_1 are folded into `bz_out` (the latent of the next block is added right behind them and a
+ * bilinear footprint's weights sum to 1), so the weight blob and the lin_z pack of one network always come from the same call. */
 int njf_pack_resnetfc(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, float* bz_out,
                       int precision, void* stream);
 /* Same, writing lin_z into a wider [512, wz_ld] matrix (several nets side by side: pass wz_out + column offset). */

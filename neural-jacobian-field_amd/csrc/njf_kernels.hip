@@ -330,6 +330,7 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
   if (!src->lin_in_w || !src->lin_in_b || !src->lin_out_w || !src->lin_out_b) return NJF_E_NULL;
   for (int i = 0; i < 5; ++i)
     if (!src->fc0_w[i] || !src->fc0_b[i] || !src->fc1_w[i] || !src->fc1_b[i]) return NJF_E_NULL;
+  if (P == NJF_PRECISION_F16 && !wz_out) return NJF_E_NULL;  // two of its accumulated biases live in the hoisted map's bias
   hipStream_t s = (hipStream_t)stream;
   // chunk 0: lin_in 63(+bias) -> 128
   launch_pack(src->lin_in_w, src->lin_in_b, 128, NJF_PE_DIM, 4, 2, 1, P, w_out, nullptr, s);
@@ -347,7 +348,6 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
   float* last = w_out + (size_t)(1 + 10 * per_layer) * NJF_CHUNK_FLOATS;
   launch_pack(src->lin_out_w, src->lin_out_b, src->d_out, 128, 1, 4, 0, P, last, b_out + 1280, s);
   fill_kernel<<<16, 256, 0, s>>>(last + 4096, 4096, 0.f);
-  if (P == NJF_PRECISION_F16 && !wz_out) return NJF_E_NULL;  // two of its biases live in the map
   if (wz_out) {
     if (!bz_out || wz_ld < 384) return NJF_E_SHAPE;
     for (int i = 0; i < 3; ++i)
