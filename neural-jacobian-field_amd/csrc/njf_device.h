@@ -1044,7 +1044,17 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
   Footprint f;
   point_footprint(g, f);
   const _Float16* gb = gz + (size_t)g.gofs + 8 * hh;
+#ifdef NJF_ABLATE_GATHER_ADDR   // experiment builds only (results are garbage): every load instruction reads 4 records of 256
+                                // contiguous bytes (16 lanes each: the texel of the group's first lane) instead of 64 scattered
+                                // 16-byte pieces -- what a gather staged through LDS by DMA would present to the texture
+                                // addresser; same load count, same bytes per lane
+  const int lane_ = threadIdx.x & 63;
+  const int cap_ = (g.hf * g.wf - 2) * g.stride;
+  auto lead = [&](int t) { return min(__shfl(t, lane_ & ~15, 64), cap_) + (lane_ & 15) * 8 - 8 * hh; };
+  const _Float16* p[4] = {gb + lead(f.t00), gb + lead(f.t01), gb + lead(f.t10), gb + lead(f.t11)};
+#else
   const _Float16* p[4] = {gb + f.t00, gb + f.t01, gb + f.t10, gb + f.t11};
+#endif
   const float w[4] = {f.w00, f.w01, f.w10, f.w11};
   // a batch = (texel t, block m) = 2 loads of 16 bytes (16 channels); DEPTH batches in flight, refilled as they are consumed
   constexpr int NB = 4 * MB;
