@@ -149,6 +149,16 @@ def reserve_stdout():
     return _line_stream
 
 
+def release_stdout() -> None:
+    """Undo reserve_stdout (tools that call a bench's main() and then print their own report: tools/stamps.py)."""
+    global _line_stream
+    if _line_stream is not None:
+        sys.stdout.flush()
+        os.dup2(_line_stream.fileno(), 1)
+        _line_stream.close()
+        _line_stream = None
+
+
 def print_line(line: Dict) -> None:
     """The JSON line, on the process's ORIGINAL stdout (see reserve_stdout)."""
     import json

@@ -17,7 +17,9 @@ sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "
 import bench  # noqa: E402
 
 bench.main()
-from neural_jacobian_field_amd import hip  # noqa: E402
+from neural_jacobian_field_amd import hip, launch  # noqa: E402
+
+launch.release_stdout()   # bench.main() reserved the process's stdout for its JSON line; the report below goes there again
 
 lib = hip.load_library()
 buf = (ctypes.c_uint * 1024)()
