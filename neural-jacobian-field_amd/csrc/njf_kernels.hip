@@ -550,6 +550,83 @@ __global__ void __launch_bounds__(256, 2) project_kernel_f16x2(const float* __re
   }
 }
 
+// Exact-fp32 projection through LDS (round 5).  The form above fetches every operand of every MFMA straight from global memory
+// (one 4-byte load per lane and matrix instruction): 0.27 ms per C2 map = 0.45 of the fp32-MFMA peak, replicated on every rank of a
+// ray-sharded frame.  Here a workgroup owns a 128-texel x 128-channel tile, K is swept 16 at a time: every thread fetches 8 k-values
+// of ONE texel (A) and of ONE channel (B) -- coalesced across the threads, the next step's loads in flight during this step's MFMAs
+// -- and writes them to LDS as [k][128] lines (conflict-free both ways: a wave half reads 32 consecutive floats of one line); each
+// of the four waves computes a 64 x 64 sub-tile from 4 LDS reads per 4 MFMAs.  Products and their order are the direct form's (every
+// accumulator sees k = 0, 1, 2, ... through the same v_mfma_f32_32x32x2_f32 sequence): bit-identical output on six shapes
+// (tools/diag/diag_project_ab.py).  Measured, one box: C2 map 0.275 -> 0.231 ms (0.53 of the peak), seven training images 1.60 ->
+// 1.32 ms, 256 x 256 map 0.96 -> 0.80 ms; a 64-texel tile (twice the workgroups, six resident per CU) measured the same 0.235 ms,
+// so the remaining gap to the fused kernels' 0.85 is not the tail of the launch -- per 2,048 cycles of MFMAs a wave also issues 16
+// global loads, 16 LDS writes and a barrier, and its LDS reads are waited for one k-pair at a time.
+__global__ void __launch_bounds__(256, 2) project_kernel_f32_lds(const float* __restrict__ feats, const float* __restrict__ wz,
+                                                                const float* __restrict__ bz, int hw, int n, int ld, int K,
+                                                                float* __restrict__ out) {
+  constexpr int KS = 16;
+  __shared__ float s_a[2][KS][128];
+  __shared__ float s_b[2][KS][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  const int lr = tid & 127, lk = tid >> 7;   // loader role: row lr of the tile, k-group lk (8 consecutive k of a step's 16)
+  const float* fa = feats + (size_t)b * K * hw + min(p0 + lr, hw - 1);
+  const float* fb = wz + min(n0 + lr, n - 1);
+  const int wm = wave & 1, wn = wave >> 1;   // compute role: texel blocks 2*wm, 2*wm+1 x channel blocks 2*wn, 2*wn+1
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[a][t] = (f32x16)(0.f);
+  float xa[8], xb[8];
+  auto fetch = [&](int k0) {
+    const int kb = k0 + 8 * lk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xa[i] = fa[(size_t)(kb + i) * hw];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xb[i] = fb[(size_t)(kb + i) * ld];
+  };
+  fetch(0);
+  int st = 0;
+  for (int k0 = 0; k0 < K; k0 += KS, st ^= 1) {   // K is a multiple of 16 (checked by the launchers)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s_a[st][8 * lk + i][lr] = xa[i];
+      s_b[st][8 * lk + i][lr] = xb[i];
+    }
+    __syncthreads();  // stage `st` complete; every wave finished reading the other stage before it arrived here
+    if (k0 + KS < K) fetch(k0 + KS);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk += 2) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = s_a[st][kk + kh][64 * wm + 32 * a + j];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = s_b[st][kk + kh][64 * wn + 32 * t + j];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+    }
+  }
+  // D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (texel)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int c = n0 + 64 * wn + 32 * t + j;
+    if (c >= n) continue;
+    const float bias = bz ? bz[c] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = p0 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < hw) out[((size_t)b * hw + row) * n + c] = acc[a][t][r] + bias;
+      }
+  }
+}
+
 static void launch_project(const float* feats, int K, const float* wz, int ld, const float* bz, int batch, int hw, int n,
                            float* out, int precision, hipStream_t s, bool out16 = false) {
   if (precision != NJF_PRECISION_F32) {  // F16X2, F16F6, F16: both operands split on the fly
@@ -558,7 +635,11 @@ static void launch_project(const float* feats, int K, const float* wz, int ld, c
     else project_kernel_f16x2<16><<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
   } else {
     dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
+#ifdef NJF_PROJECT_DIRECT   // A/B builds only: the rounds 1-4 form (operands straight from global memory)
     project_kernel<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+#else
+    project_kernel_f32_lds<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
+#endif
   }
 }
 

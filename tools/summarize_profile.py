@@ -31,7 +31,7 @@ shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 PCODE = {"f32": 0, "f16x2": 1, "f16f6": 2, "f16": 3}[prec]    # template argument of this precision's instantiations
 PROP = 1 if prec == "f16f6" else PCODE              # under f16f6 the proposal networks stay on f16x2 (Model.set_precision)
 KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PROP},": "proposal",
-           ("project_kernel(" if prec == "f32" else "project_kernel_f16x2<"): "project"}
+           ("project_kernel_f32_lds(" if prec == "f32" else "project_kernel_f16x2<"): "project"}   # (rounds 1-4: "project_kernel(")
 agg = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"{src}/pmc*/*/*_counter_collection.csv"):
