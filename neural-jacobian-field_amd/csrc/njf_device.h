@@ -573,13 +573,28 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
       f16x8 a[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
+#ifdef NJF_F16_PREFETCH2   // A/B builds: A fragments requested TWO K-steps ahead (16 more registers)
+      f16x8 n1[4] = {a[0], a[1], a[2], a[3]};
+      if (T > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n1[i] = base[(4 + i) * 64];
+      }
+#endif
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+#ifdef NJF_F16_PREFETCH2
+        f16x8 n[4] = {n1[0], n1[1], n1[2], n1[3]};
+        if (t + 2 < T) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) n1[i] = base[((t + 2) * 4 + i) * 64];
+        }
+#else
         f16x8 n[4] = {a[0], a[1], a[2], a[3]};
         if (t + 1 < T) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
         }
+#endif
         if constexpr (SPREAD) {  // the next chunk's 8 DMA rounds, two behind each of the first four steps
 #if defined(NJF_F16_DMA_PLACE) && NJF_F16_DMA_PLACE == 1   // A/B builds: one round per step (8-step chunks)
           if (T == 8 ? true : t < 4) {
