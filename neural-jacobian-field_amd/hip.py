@@ -37,6 +37,11 @@ REDUCED_PRECISIONS = ("f16",)   # modes that are NOT held to the fp32 parity bou
 # Default: "f16f6" for the final pass with the proposal networks on "f16x2" (Model.set_precision's policy).  It passes the
 # same parity suite as the exact-fp32 path with the same bounds (profiles/r02_parity_margins.json).
 DEFAULT_PRECISION = os.environ.get("NJF_PRECISION", "f16f6")
+if DEFAULT_PRECISION not in PRECISIONS or DEFAULT_PRECISION in REDUCED_PRECISIONS:
+    # the environment may pick among the modes that meet the fp32 parity bound; a reduced mode is chosen per model
+    # (Model.set_precision("f16")), by code that knows its tolerance -- never by a variable that every process inherits
+    raise ValueError(f"NJF_PRECISION={DEFAULT_PRECISION!r}: the package default must be one of "
+                     f"{sorted(set(PRECISIONS) - set(REDUCED_PRECISIONS))}")
 
 
 def proposal_precision_for(precision: str) -> str:

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import functools
 import os
+import warnings
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -156,6 +157,10 @@ class Model(nn.Module):
         self.inverse_cache_enabled = True
         self._joint: Dict[str, object] = {"features": None}   # ONE per-image projection for all networks of a frame (_joint_hoist)
         self.auto_range_check = os.environ.get("NJF_AUTO_RANGE_CHECK", "1") != "0"   # (off: single-precision experiment libraries)
+        if not self.auto_range_check:
+            warnings.warn("NJF_AUTO_RANGE_CHECK=0: the fp16 range check of the first forward pass is OFF (meant for kernel "
+                          "experiment libraries that hold one precision only); checkpoints whose activations exceed the fp16 "
+                          "range will not fall back to exact fp32 products", RuntimeWarning, stacklevel=2)
         self.range_check_interval = 100
         self._range_checked = None      # weights signature of the last check
         self._range_pending = True      # weights replaced wholesale (construction, load_state_dict)
@@ -490,7 +495,7 @@ class Model(nn.Module):
         if want_vis:
             outs["pos"] = torch.empty(b, r, 3, **f32)
             outs["pos_warped"] = torch.empty(b, r, 3, **f32)
-            if not (dump_jacobian or dump_perception):   # (the training instantiations do not composite them: _vis_at_bins)
+            if not (dump_jacobian or dump_perception):   # (never requested from a training forward: _vis_at_bins)
                 outs["action_features"] = torch.empty(b, r, a3, **f32)
         if want_samples:
             outs["density"] = torch.empty(b, r, s, 1, **f32)
@@ -610,9 +615,11 @@ class Model(nn.Module):
         return out
 
     def _vis_at_bins(self, camera_input, rendering_input, robot_input, features, bins, smp) -> "ModelVisOutput":
-        """ModelVisOutput of a TRAINING forward (model.py:381-394): an inference render of the same samples (``bins``) -- the
-        training instantiations of the render kernel carry the activation dumps instead of the 16 action-feature accumulators
-        (which cost them ~60 spilled VGPRs each for an output no loss reads)."""
+        """ModelVisOutput of a TRAINING forward (model.py:381-394): an inference render of the same samples (``bins``).  No loss
+        reads these fields, so the training forwards do not request them from the dump instantiations of the render kernel --
+        which lets those be built with or without the 16 action-feature accumulators (-DNJF_TRAIN_NO_AF; the A/B of round 5,
+        profiles/r05_spills_ab.txt, kept the accumulators: the leaner build was not faster) -- and the visualisation pays for
+        itself on the steps that ask for it (the reference's validation / logging steps)."""
         with torch.no_grad():
             vis, *_ = self._fused_render(camera_input, rendering_input, robot_input, features, want_lists=False, want_vis=True,
                                          want_samples=False, final_bins=bins)

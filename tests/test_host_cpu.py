@@ -109,6 +109,19 @@ def test_no_cpu_fallback():
         FusedRenderer(torch.device("cpu"))
 
 
+def test_environment_cannot_make_a_reduced_mode_the_default():
+    """NJF_PRECISION picks the package default among the modes held to the fp32 parity bound; the reduced-precision "f16"
+    (and anything unknown) is refused at import instead of being inherited silently by every process."""
+    code = "import sys; sys.path.insert(0, %r); from neural_jacobian_field_amd import hip; print(hip.DEFAULT_PRECISION)" % ROOT
+    for value, ok in (("f16x2", True), ("f32", True), ("f16", False), ("bf16", False)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NJF_PRECISION=value), capture_output=True, text=True)
+        assert (r.returncode == 0) == ok, (value, r.stderr[-400:])
+        if ok:
+            assert r.stdout.strip() == value
+        else:
+            assert "NJF_PRECISION" in r.stderr
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "neural-jacobian-field_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -31,6 +31,15 @@ FLOOR_FACTOR = {"f32": 2.0, "default": 4.0}   # multiples of the fp64 floor at g
 GRAD_TOL = {"f32": 1e-4, "default": 1e-3}
 
 
+_ORACLE_ONCE = {}   # the CPU oracle's backward passes do not depend on the MFMA precision under test: evaluated once per test
+
+
+def _once(key, fn):
+    if key not in _ORACLE_ONCE:
+        _ORACLE_ONCE[key] = fn()
+    return _ORACLE_ONCE[key]
+
+
 def _bins_of(samples):
     return torch.cat([samples.spacing_starts[..., 0], samples.spacing_ends[..., -1:, 0]], -1)
 
@@ -179,7 +188,7 @@ def test_perception_mode_gradients_at_given_bins(fixed, margins, precision):
             losses[mode] = l.detach().reshape(1)
             return {n: params[n].grad for n in names}
 
-        g32, g64 = oracle_backward(None), oracle_backward("fp64")
+        g32, g64, losses = _once("perception@bins", lambda: (oracle_backward(None), oracle_backward("fp64"), losses))
         margins(tag, "loss", loss.reshape(1), losses[None], floor=rel(losses["fp64"], losses[None]))
         failures = []
         own = dict(model.named_parameters())
@@ -288,8 +297,8 @@ def test_wrapper_perception_step_whole_loss_gradients(setup, margins, precision)
             parts[mode] = {k: v.detach().reshape(1) for k, v in t.items()}
             return {n: params[n].grad for n in names}
 
-        base = oracle_backward(None)
-        moved = {mode: oracle_backward(mode) for mode in FLOOR_MODES}
+        base, moved, losses, parts = _once("wrapper.perception", lambda: (
+            oracle_backward(None), {mode: oracle_backward(mode) for mode in FLOOR_MODES}, losses, parts))
         for k in terms:   # the four terms individually, then their sum
             margins(tag, k, terms[k].reshape(1), parts[None][k], floor=max(rel(parts[m][k], parts[None][k]) for m in FLOOR_MODES),
                     floor_fp64=rel(parts["fp64"][k], parts[None][k]))
