@@ -1095,6 +1095,89 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
   }
 }
 
+// PREC_F16, fc_0 chunk of a block WITH the next block's gather riding on it (-DNJF_F16_RIDE): net += W * relu(h) exactly as
+// mma_chunk<PREC_F16, 4, 4, 0, true, 4>, and h += the hoisted latent of the NEXT block (`gz`) while the chunk's MFMAs run.
+// K-step t reads h[t >> 1] only, and its fp16 copy is made one step ahead, so h[m] is dead from step 2m + 1 on -- until fc_1
+// accumulates into it -- and the sum  h + fc_1(..) + latent  does not care in which order it is formed.  The footprint's 16
+// (texel, block) batches are ordered block-major (b = 4 m + texel), four in flight (32 VGPRs): those of block 0 are requested
+// in front of the loop, every fold frees a slot for the batch four further on; folds of block m sit in steps 2m+1, 2m+2
+// (block 3: step 7 and the tail).  The wave's own 32-clock MFMAs cover the fold's v_fma_mix stream and most of the latency of
+// the loads, which a gather in front of the chunk exposes in full (5,200 clocks per gather with eight waves of a CU arriving at
+// the texture addresser together, profiles/r05_stamps_f16.txt).
+#ifndef NJF_F16_RIDE_DEPTH
+#define NJF_F16_RIDE_DEPTH 2   // (texel, block) batches in flight, 8 VGPRs each (static report, render kernel: 1 -> 0, 2 -> 2, 3 -> 13, 4 -> 36 spilled VGPRs)
+#endif
+template <bool RELU, class ST>
+__device__ __forceinline__ void mma_chunk_f16_ride(ST& st, const float* __restrict__ wl, int lane, f32x16 (&h)[4],
+                                                   f32x16 (&out)[4], const _Float16* __restrict__ gz, const PointGeom& g) {
+  const f16x8* base = (const f16x8*)wl + lane;
+  constexpr int T = 8, D = NJF_F16_RIDE_DEPTH;
+  Footprint f;
+  point_footprint(g, f);
+  const _Float16* gb = gz + (size_t)g.gofs + 8 * (lane >> 5);
+  const int o[4] = {f.t00, f.t01, f.t10, f.t11};
+  const float w[4] = {f.w00, f.w01, f.w10, f.w11};
+  f16x8 v[D][2];
+  auto issue = [&](int b) {
+    const _Float16* src = gb + o[b & 3] + 32 * (b >> 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v[b % D][q] = *(const f16x8*)(src + 16 * q);
+  };
+  auto fold = [&](int b, int q) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[b >> 2][8 * q + e] = fmaf((float)v[b % D][q][e], w[b & 3], h[b >> 2][8 * q + e]);
+  };
+  unsigned bc[4], bn[4];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) bc[pp] = pack_pair_f16<RELU>(h[0][2 * pp], h[0][2 * pp + 1]);
+  auto op8 = [](const unsigned (&u)[4]) { return __builtin_bit_cast(f16x8, u32x4{u[0], u[1], u[2], u[3]}); };
+#pragma unroll
+  for (int b = 0; b < D; ++b) issue(b);
+  f16x8 a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f16x8 n[4] = {a[0], a[1], a[2], a[3]};
+    if (t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
+    }
+    if (t < 4) {
+      dma_issue(st, 2 * t);
+      dma_issue(st, 2 * t + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int b0 = 2 * (t - 1);   // the two batches folded in this step (t >= 1)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], op8(bc), out[m], 0, 0, 0);
+      if (t + 1 < T) {
+        const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
+        bn[m] = pack_pair_f16<RELU>(h[kb2][8 * tt2 + 2 * m], h[kb2][8 * tt2 + 2 * m + 1]);
+      }
+      if (t >= 1) {
+        fold(b0 + (m >> 1), m & 1);
+        if (m & 1) {
+          asm volatile("" : "+v"(h[(b0 + (m >> 1)) >> 2]) : : "memory");   // the fmas retire before the slot is reloaded
+          if (b0 + (m >> 1) + D < 16) issue(b0 + (m >> 1) + D);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = n[i];
+      bc[i] = bn[i];
+    }
+  }
+#pragma unroll
+  for (int b = 14; b < 16; ++b) {
+    fold(b, 0);
+    fold(b, 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Which form a network uses follows its MFMA precision (and so does the layout its lin_z columns are packed in,
 // njf_hoist_layout): the quad/MFMA form where the matrix pipe has headroom -- the fp6-corrected networks, measured
 // -3.8 % on the C2 final pass -- and the half/VALU form where it is the busier pipe (F16X2: the proposal pass measured
@@ -1299,6 +1382,37 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
   if constexpr (PREC == PREC_F16) {
     // 12 chunks: lin_in | (fc_0, fc_1) x 5, a whole 128 x 128 layer per chunk | lin_out
     static_assert(!DUMP, "the plain-fp16 mode is an inference mode (training forwards dump fp32-class activations)");
+#ifdef NJF_F16_RIDE
+    // the latents of blocks 1 and 2 ride on the fc_0 chunks of blocks 0 and 1 (mma_chunk_f16_ride); two loops, so that no
+    // join point carries both forms of the chunk
+    NJF_STAMP(st, 4);
+    add_hoisted_latent<4, PREC>(map_at<PREC>(gz, 0), g, lane, h);
+    NJF_STAMP(st, 5);
+    for (int blk = 0; blk < 2; ++blk) {
+      bias_init<4, true, PREC>(bias + blk * 256, hh, net);
+      {
+        const float* wl = stream_step(st, wave, lane);
+        mma_chunk_f16_ride<true>(st, wl, lane, h, net, (const _Float16*)map_at<PREC>(gz, (blk + 1) * 128), g);
+      }
+      {
+        const float* wl = stream_step(st, wave, lane);
+        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
+      }
+    }
+    for (int blk = 2; blk < 5; ++blk) {
+      const float* bl = bias + blk * 256;
+      bias_init<4, true, PREC>(bl, hh, net);
+      {
+        const float* wl = stream_step(st, wave, lane);
+        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, h, net);
+      }
+      bias_init<4, false, PREC, true>(bl + 128, hh, h);
+      {
+        const float* wl = stream_step(st, wave, lane);
+        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
+      }
+    }
+#else
     for (int blk = 0; blk < 5; ++blk) {
       if (blk < 3) {
         NJF_STAMP(st, 4);
@@ -1317,6 +1431,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
       }
     }
+#endif
   } else
   for (int blk = 0; blk < 5; ++blk) {
     if (blk < 3) {
