@@ -1082,6 +1082,9 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
   };
 #pragma unroll
   for (int b = 0; b < D; ++b) issue(b);
+#ifdef NJF_F16_GATHER_PIN   // A/B builds: every load of the first D batches is issued before the first fold (see the note below)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int t = b / MB, m = b % MB;
