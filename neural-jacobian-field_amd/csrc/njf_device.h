@@ -1052,12 +1052,13 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
 #endif
 template <int MB, int DEPTH = NJF_F16_GATHER_DEPTH>
 __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restrict__ gz, const PointGeom& g, int hh,
-                                                       f32x16 (&h)[MB]) {
+                                                       f32x16 (&h)[MB], const Footprint* shared = nullptr) {
 #ifdef NJF_ABLATE_GATHER  // experiment builds only (tools/ablate.sh)
   return;
 #endif
   Footprint f;
-  point_footprint(g, f);
+  if (shared != nullptr) f = *shared;   // (compile-time known at every call site: TileShareF16)
+  else point_footprint(g, f);
   const _Float16* gb = gz + (size_t)g.gofs + 8 * hh;
 #ifdef NJF_ABLATE_GATHER_ADDR   // experiment builds only (results are garbage): every load instruction reads 4 records of 256
                                 // contiguous bytes (16 lanes each: the texel of the group's first lane) instead of 64 scattered
@@ -1095,6 +1096,50 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
     asm volatile("" : "+v"(h[m]) : : "memory");  // the fmas retire into h before the batch's registers are reloaded
     if (b + D < NB) issue(b + D);
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// PREC_F16, inference: what the ResnetFC networks of ONE tile share.  The density network and the Jacobian head encode the SAME
+// camera-space point and gather at the SAME footprint (and the three gathers of a network share it anyway).  pe: this lane's 64
+// encoding values as the lin_in chunk's fp16 B operands (4 K-steps x 4 dwords): 16 registers held across the tile instead of a
+// second positional encoding (~280 VALU + 60 v_sin); and within a network ONE footprint serves its three gathers (resnet_tile).
+// The plain-fp16 kernels have the registers (232 of 256) and their time follows their instruction count
+// (profiles/r05_ablate_f16.txt, blocks h-j); the other precisions run at the register limit and keep recomputing.
+struct TileShareF16 {
+  unsigned pe[16];
+};
+
+__device__ __forceinline__ void share_tile(const f32x16 (&pe)[2], TileShareF16& sh) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) sh.pe[4 * t + p] = pack_pair_f16<false>(pe[t >> 1][8 * (t & 1) + 2 * p], pe[t >> 1][8 * (t & 1) + 2 * p + 1]);
+}
+
+// lin_in of a PREC_F16 ResnetFC from the packed encoding: mma_chunk<PREC_F16, 4, 2, 0, false, 2> without its conversions
+template <class ST>
+__device__ __forceinline__ void mma_lin_in_f16_packed(ST& st, const float* __restrict__ wl, int lane, const unsigned (&pk)[16],
+                                                      f32x16 (&out)[4]) {
+  const f16x8* base = (const f16x8*)wl + lane;
+  constexpr int T = 4;
+  f16x8 a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f16x8 n[4] = {a[0], a[1], a[2], a[3]};
+    if (t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
+    }
+    dma_issue(st, 2 * t);
+    dma_issue(st, 2 * t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const f16x8 b = __builtin_bit_cast(f16x8, u32x4{pk[4 * t], pk[4 * t + 1], pk[4 * t + 2], pk[4 * t + 3]});
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b, out[m], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = n[i];
   }
 }
 
@@ -1317,11 +1362,14 @@ __device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x1
     }
 }
 
-template <int PREC, bool DUMP = false, class ST>
+// SHARED (PREC_F16 inference only), bits: 1 = lin_in reads the packed encoding of `share` instead of `pe` (which is then not
+// read); 2 = ONE footprint, computed here, serves the network's three gathers (8 registers held across blocks 0-2).
+template <int PREC, bool DUMP = false, int SHARED = 0, class ST>
 __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bias,
                                             const float* __restrict__ gz, const PointGeom& g,
                                             const f32x16 (&pe)[2], int wave, int lane, f32x16 (&out)[1],
-                                            ActDump dump = ActDump{nullptr, nullptr, 0}) {
+                                            ActDump dump = ActDump{nullptr, nullptr, 0}, const TileShareF16* share = nullptr) {
+  static_assert(SHARED == 0 || (PREC == PREC_F16 && !DUMP), "the shared tile state exists for the plain-fp16 inference kernels");
   const int hh = lane >> 5;
   f32x16 h[4], net[4];
 #pragma unroll
@@ -1380,11 +1428,14 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
 #else
   {
     const float* wl = stream_step(st, wave, lane);
-    mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
+    if constexpr ((SHARED & 1) != 0) mma_lin_in_f16_packed(st, wl, lane, share->pe, h);
+    else mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
   }
   if constexpr (PREC == PREC_F16) {
     // 12 chunks: lin_in | (fc_0, fc_1) x 5, a whole 128 x 128 layer per chunk | lin_out
     static_assert(!DUMP, "the plain-fp16 mode is an inference mode (training forwards dump fp32-class activations)");
+    Footprint fp_net;
+    if constexpr ((SHARED & 2) != 0) point_footprint(g, fp_net);
 #ifdef NJF_F16_RIDE
     // the latents of blocks 1 and 2 ride on the fc_0 chunks of blocks 0 and 1 (mma_chunk_f16_ride); two loops, so that no
     // join point carries both forms of the chunk
@@ -1419,7 +1470,8 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
     for (int blk = 0; blk < 5; ++blk) {
       if (blk < 3) {
         NJF_STAMP(st, 4);
-        add_hoisted_latent<4, PREC>(map_at<PREC>(gz, blk * 128), g, lane, h);
+        if constexpr ((SHARED & 2) != 0) add_hoisted_latent_f16<4>((const _Float16*)map_at<PREC>(gz, blk * 128), g, hh, h, &fp_net);
+        else add_hoisted_latent<4, PREC>(map_at<PREC>(gz, blk * 128), g, lane, h);
         NJF_STAMP(st, 5);
       }
       const float* bl = bias + blk * 256;

@@ -1382,6 +1382,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     if (DUMP && valid && ray_ok)
       dump = point_dump(a.dump, (size_t)ray * a.s_in + s, (size_t)a.rc.total_rays * a.s_in, hh, g,
                         b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
+    // (plain fp16: one footprint for the three gathers + lin_in from a packed encoding, as in the render kernel, measured 0.7 %
+    //  SLOWER here -- profiles/r05_ablate_f16.txt block k -- and is not used)
     resnet_tile<PREC, DUMP>(st, bias, gz, g, pe, wave, lane, out, dump);
 #ifdef NJF_STAMPS_PROPOSAL
     NJF_STAMP(st, 14);
@@ -1423,13 +1425,20 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
 // JKIND: 0 = no Jacobian head, 1 = ResnetFC head (jacobian_mlp), 2 = folded transformer head (jacobian_transformer)
 // DUMP: 0 = inference, 1 = dump the Jacobian ResnetFC (action-mode training), 2 = dump the density ResnetFC and the
 // colour head (perception-mode training); `dump` addresses the dumped net, `cdump` the colour head.
-template <int PREC, int DUMP, class ST>
+// SHARE (plain-fp16 inference): the stage fills `share` (packed encoding + footprint of this tile's points, TileShareF16) for
+// its own network and for a ResnetFC Jacobian head that follows.
+template <int PREC, int DUMP, int SHARE = 0, class ST>
 __device__ __forceinline__ float density_stage(ST& st, const float* __restrict__ gz_d, const PointGeom& g, int wave,
-                                               int lane, f32x16 (&geo)[1], ActDump dump) {
+                                               int lane, f32x16 (&geo)[1], ActDump dump, TileShareF16* share = nullptr) {
   const int j = lane & 31, hh = lane >> 5;
   f32x16 pe[2];
   positional_encoding(g.xc, g.yc, g.zc, hh, pe);
-  resnet_tile<PREC, DUMP == 2>(st, njf_lds + LDS_BIAS, gz_d, g, pe, wave, lane, geo, dump);
+  if constexpr (SHARE != 0) {
+    share_tile(pe, *share);
+    resnet_tile<PREC, false, SHARE>(st, njf_lds + LDS_BIAS, gz_d, g, pe, wave, lane, geo, dump, share);
+  } else {
+    resnet_tile<PREC, DUMP == 2>(st, njf_lds + LDS_BIAS, gz_d, g, pe, wave, lane, geo, dump);
+  }
   return expf(__shfl(geo[0][15], j, 64) - 1.0f);
 }
 
@@ -1455,12 +1464,19 @@ __device__ __forceinline__ void color_stage(ST& st, const f32x16 (&geo)[1], floa
   }
 }
 
-template <int JKIND, int PREC, int DUMP, class ST>
+template <int JKIND, int PREC, int DUMP, int SHARE = 0, class ST>
 __device__ __forceinline__ void jacobian_stage(ST& st, const float* __restrict__ gz_j, const PointGeom& g,
                                                const float* __restrict__ action, int action_dim, int wave, int lane,
-                                               f32x16 (&jac)[1], float (&flow)[3], ActDump dump) {
+                                               f32x16 (&jac)[1], float (&flow)[3], ActDump dump, const TileShareF16* share = nullptr) {
   const int hh = lane >> 5;
   const float* bias = njf_lds + LDS_BIAS + NJF_RESNET_B_FLOATS + NJF_COLOR_B_FLOATS;
+  if constexpr (SHARE != 0) {   // ResnetFC head in plain fp16: the density stage's packed encoding (TileShareF16)
+    static_assert(JKIND == 1 && DUMP == 0, "shared tile state: ResnetFC Jacobian head, inference");
+    NJF_STAMP(st, 6);
+    NJF_STAMP(st, 7);
+    f32x16 unused[2];
+    resnet_tile<PREC, false, SHARE>(st, bias, gz_j, g, unused, wave, lane, jac, dump, share);
+  } else {
   // the encoding is recomputed (~1 % of the head's time) rather than held in 32 VGPRs across density + colour
   // ... and REALLY recomputed: without the opaque copies the compiler keeps the density stage's 25 encoding values alive
   // through scratch and reloads them inside the lin_in chunk, each reload behind its own s_waitcnt vmcnt(0)
@@ -1488,6 +1504,7 @@ __device__ __forceinline__ void jacobian_stage(ST& st, const float* __restrict__
         }
     }
     transformer_tile<PREC>(st, bias, gz_j, g, pe, action_dim, wave, lane, jac);
+  }
   }
   // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
   // logical outputs 16*hh + r.  Partial sums by phase r%3, then the two halves are combined.
@@ -1623,7 +1640,16 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     }
     // ---- density net -> sample weight; everything that only needs the weight is composited right away
     f32x16 geo[1];
-    const float sigma = density_stage<PREC, DUMP>(st, gz_d, g, wave, lane, geo, DUMP == 2 ? dump : ActDump{nullptr, nullptr, 0});
+    // plain-fp16 inference: the tile's packed encoding serves both networks, one footprint the gathers of a network (TileShareF16)
+#ifndef NJF_F16_SHARE_D
+#define NJF_F16_SHARE_D 1
+#define NJF_F16_SHARE_J 3
+#endif
+    // (the instantiations that also composite the action features, AF, have no registers to spare: 6-35 spilled VGPRs with any of it)
+    constexpr int SHARE_D = (PREC == PREC_F16 && DUMP == 0 && !AF) ? NJF_F16_SHARE_D : 0;
+    constexpr int SHARE_J = (SHARE_D != 0 && JKIND == 1 && PRECJ == PREC_F16) ? NJF_F16_SHARE_J : 0;
+    TileShareF16 share;
+    const float sigma = density_stage<PREC, DUMP, SHARE_D>(st, gz_d, g, wave, lane, geo, DUMP == 2 ? dump : ActDump{nullptr, nullptr, 0}, &share);
     float w;
     {
       SamplePlace sp;
@@ -1668,7 +1694,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     float flow[3] = {0.f, 0.f, 0.f};
     if (WITH_J) {
       f32x16 jac[1];
-      jacobian_stage<JKIND, PRECJ, DUMP>(st, gz_j, g, action, A, wave, lane, jac, flow, DUMP == 1 ? dump : ActDump{nullptr, nullptr, 0});
+      jacobian_stage<JKIND, PRECJ, DUMP, SHARE_J>(st, gz_j, g, action, A, wave, lane, jac, flow, DUMP == 1 ? dump : ActDump{nullptr, nullptr, 0}, &share);
       if (valid && want_af) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_j[r] = fmaf(w, jac[0][r], acc_j[r]);

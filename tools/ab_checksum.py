@@ -19,7 +19,7 @@ dev = torch.device("cuda:0")
 case = synthetic.synthetic_case(2, 32, 48, 700, 8, seed=7, device=dev, identity_context=False)   # package-only inputs: no oracle/
 c = case["cams"]
 req = RenderRequest(vis=True, sample_weights=True, per_sample=True)
-for prec in ("f16x2", "f32"):
+for prec in (sys.argv[1:] or ["f16x2", "f32"]):   # (round 5: pass e.g. `f16` for the plain-fp16 kernels)
     fr = FusedRenderer(dev, 1, 8, precision=prec)
     fr.load_weights(case["params"])
     res = fr.render(case["feats"], case["origins"], case["directions"], c["ctxt_c2w"], c["ctxt_k_norm"], c["z_near"], c["z_far"],
