@@ -713,3 +713,38 @@ def test_training_step_drives_the_sampler_schedule():
     anneals = [a for a, _ in seen]
     assert anneals[0] == 0.0 and 0.0 < anneals[1] < anneals[2] == 1.0     # frac = step / 1000 -> 0, 0.5, 1.0
     assert wrapper.model.proposal_sampler._step == 1000 and wrapper.model.proposal_sampler._steps_since_update >= 1
+
+
+def test_device_constant_caches_key_on_type_and_index():
+    """the device-constant caches key on (type, index), build their constant once, and hand back the same tensor."""
+    from neural_jacobian_field_amd import hip
+    assert hip.device_key("cpu") == ("cpu", None)
+    assert hip.device_key(torch.device("cuda", 3)) == ("cuda", 3) and hip.device_key("cuda:1") == ("cuda", 1)
+    cache, built = {}, []
+
+    def make():
+        built.append(1)
+        return torch.arange(4, dtype=torch.float32)
+
+    key = ("u_base", 4) + hip.device_key("cpu")
+    a = hip.cached_device_constant(cache, key, "cpu", make)
+    b = hip.cached_device_constant(cache, key, "cpu", make)
+    assert a is b and len(built) == 1 and list(cache) == [key]
+
+
+def test_reserved_stdout_carries_the_json_line_and_nothing_else():
+    """launch.reserve_stdout: whatever python OR native code writes to descriptor 1 afterwards lands on stderr; the one line of
+    print_line goes to the process's original stdout (RCCL's banner used to precede the bench line, tests/test_rccl_gpu.py)."""
+    code = ("import sys, os, ctypes; sys.path.insert(0, %r)\n"
+            "from neural_jacobian_field_amd import launch\n"
+            "print('before')\n"
+            "launch.reserve_stdout(); launch.reserve_stdout()\n"
+            "print('python noise'); os.write(1, b'descriptor noise\\n')\n"
+            "libc = ctypes.CDLL(None); libc.puts(b'native noise'); libc.fflush(None)\n"
+            "launch.print_line({'metric': 'x', 'value': 1})\n"
+            "launch.release_stdout(); print('after')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert r.stdout.splitlines() == ["before", json.dumps({"metric": "x", "value": 1}), "after"]
+    for noise in ("python noise", "descriptor noise", "native noise"):
+        assert noise in r.stderr
