@@ -1078,8 +1078,24 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
   f16x8 v[D][2];
   auto issue = [&](int b) {
     const _Float16* src = p[b / MB] + 32 * (b % MB);
+#ifdef NJF_ABLATE_GATHER_HALFBYTES   // experiment builds only (results are garbage): every load fetches 8 bytes per lane instead of 16
+                                     // and its four values are folded twice -- same load and VALU instruction counts, HALF the bytes
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f16x4_t x = *(const f16x4_t*)(src + 16 * q);
+      v[b % D][q] = __builtin_shufflevector(x, x, 0, 1, 2, 3, 0, 1, 2, 3);
+    }
+#elif defined(NJF_ABLATE_GATHER_NOLOAD)   // experiment builds only (garbage): no loads at all, the 256 folds read registers
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      v[b % D][q] = __builtin_bit_cast(f16x8, u32x4{(unsigned)b, (unsigned)q, (unsigned)f.t00, (unsigned)f.t11});
+      asm volatile("" : "+v"(v[b % D][q]));
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 2; ++q) v[b % D][q] = *(const f16x8*)(src + 16 * q);
+#endif
   };
 #pragma unroll
   for (int b = 0; b < D; ++b) issue(b);
@@ -1089,10 +1105,16 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int t = b / MB, m = b % MB;
+#ifdef NJF_ABLATE_GATHER_NOFOLD   // experiment builds only (garbage): every load is issued and waited for, ONE fold per load instead of 8
+#pragma unroll
+    for (int q = 0; q < 2; ++q) h[m][8 * q] = fmaf((float)v[b % D][q][0], w[t], h[m][8 * q]);
+    asm volatile("" : : "v"(v[b % D][0]), "v"(v[b % D][1]));
+#else
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) h[m][8 * q + e] = fmaf((float)v[b % D][q][e], w[t], h[m][8 * q + e]);
+#endif
     asm volatile("" : "+v"(h[m]) : : "memory");  // the fmas retire into h before the batch's registers are reloaded
     if (b + D < NB) issue(b + D);
     __builtin_amdgcn_sched_barrier(0);
