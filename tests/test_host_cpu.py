@@ -666,6 +666,12 @@ def test_static_isa_properties_of_the_fused_kernels():
         r = row(name)
         assert r["lds_dma"] > 0 and r["spill"] <= spill, (name, r)
         assert sum(v for k, v in r["lgkm"].items() if k > 0) > r["lgkm"].get(0, 0), (name, r["lgkm"])
+    # the plain-fp16 kernels (round 5): no spilled VGPR in any inference instantiation -- the shared tile state of the render kernel
+    # (TileShareF16, 16-24 registers) is only instantiated where it fits -- and the weight stream is the LDS DMA here too
+    for name in ("void render_kernel<1, 3, 0, false, 3>", "void render_kernel<1, 3, 0, true, 3>", "void render_kernel<2, 3, 0, false, 3>",
+                 "void render_kernel<2, 3, 0, true, 3>", "void proposal_kernel<3, false>", "void points_kernel<2, 3, 3>"):
+        r = row(name)
+        assert r["spill"] == 0 and r["lds_dma"] > 0, (name, r)
 
 
 def test_reference_checkpoint_keys_load_strictly():
