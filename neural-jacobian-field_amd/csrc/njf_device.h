@@ -48,9 +48,7 @@ typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 // Workgroup = 4 waves (one per SIMD), two workgroups resident per CU: the two waves sharing a SIMD's
 // MFMA pipe belong to DIFFERENT workgroups, so one workgroup's barrier / gather / encoding phases are
 // covered by the other's MFMA stream (with one 8-wave workgroup both waves of a SIMD stall together).
-#ifndef NJF_WAVES
 #define NJF_WAVES 4
-#endif
 #define NJF_THREADS (NJF_WAVES * 64)
 #define NJF_CHUNK 8192  // floats per weight chunk (32 KiB)
 
@@ -59,13 +57,8 @@ typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 // fit in the CU's 160 KiB: 2 x 32 KiB weight buffers + biases (+ per-wave scratch of the PDF stage).
 // NJF_ASYNC_STREAM (experiment build, needs -DNJF_WAVES=8: ONE 8-wave workgroup per CU): four weight buffers and a
 // barrier-free stream -- see stream_step.
-#ifdef NJF_ASYNC_STREAM
-#define NJF_STREAM_BUFFERS 4
-#define LDS_CTR_FLOATS 8            // eight arrival counters (ring) behind everything else
-#else
 #define NJF_STREAM_BUFFERS 2
 #define LDS_CTR_FLOATS 0
-#endif
 #define LDS_W0 0
 #define LDS_W1 NJF_CHUNK
 #define LDS_BIAS (NJF_STREAM_BUFFERS * NJF_CHUNK)
@@ -82,6 +75,57 @@ __device__ __forceinline__ float mfma_step(float a, float b, f32x16& c) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   return 0.f;
 }
+
+// Timeline instrumentation of ONE wave (experiment builds only, -DNJF_STAMPS; tools/stamps.py): (tag << 24 | low 24
+// bits of s_memtime) words, logged to a spare LDS area and copied out when the wave retires.  -DNJF_STAMPS logs a wave of the
+// render kernel, -DNJF_STAMPS -DNJF_STAMPS_PROPOSAL a wave of the proposal kernel (its LDS use ends higher).  Everything the
+// kernels say about it goes through the macros below, which are empty in product builds.
+#ifdef NJF_STAMPS
+#define NJF_STAMP_SLOTS 1024
+#ifdef NJF_STAMPS_PROPOSAL
+#define NJF_STAMP_BASE LDS_FLOATS_PROPOSAL
+#define NJF_STAMP_LOGS_PROPOSAL true
+#else
+#define NJF_STAMP_BASE LDS_FLOATS_RENDER
+#define NJF_STAMP_LOGS_PROPOSAL false
+#endif
+__device__ unsigned njf_stamp_out[NJF_STAMP_SLOTS];
+#define NJF_STAMP_FIELD int stamp_i;   // next free slot of this wave's log in LDS (-1: this wave does not log)
+#define NJF_STAMP_INIT(st) (st).stamp_i = -1
+#define NJF_STAMP(st, tag)                                                                                   \
+  do {                                                                                                       \
+    if ((st).stamp_i >= 0 && (st).stamp_i < NJF_STAMP_SLOTS) {                                               \
+      njf_lds[NJF_STAMP_BASE + (st).stamp_i] =                                                               \
+          __uint_as_float(((unsigned)(tag) << 24) | ((unsigned)__builtin_readcyclecounter() & 0xffffffu));   \
+      (st).stamp_i += 1;                                                                                     \
+    }                                                                                                        \
+  } while (0)
+// stamps of the proposal kernel (the render kernel's are plain NJF_STAMP: the shared device functions log for whichever wave is armed)
+#define NJF_STAMP_P(st, tag) do { if (NJF_STAMP_LOGS_PROPOSAL) NJF_STAMP(st, tag); } while (0)
+// arm wave 1 of a mid-grid workgroup of the kernel this build logs (IS_PROPOSAL: the caller is the proposal kernel)
+#define NJF_STAMP_ARM(st, IS_PROPOSAL, wave)                                                                                \
+  const bool njf_stamping = ((IS_PROPOSAL) == NJF_STAMP_LOGS_PROPOSAL) && blockIdx.x == gridDim.x / 2 + 3 && (wave) == 1; \
+  if (njf_stamping) (st).stamp_i = 0;                                                                                     \
+  NJF_STAMP(st, 9)
+#define NJF_STAMP_FLUSH(st, tag, lane)                                                                       \
+  do {                                                                                                       \
+    NJF_STAMP(st, tag);                                                                                      \
+    if (njf_stamping)                                                                                        \
+      for (int i_ = (lane); i_ < NJF_STAMP_SLOTS; i_ += 64)                                                  \
+        njf_stamp_out[i_] = i_ < (st).stamp_i ? __float_as_uint(njf_lds[NJF_STAMP_BASE + i_]) : 0u;          \
+  } while (0)
+#define NJF_STAMP_PIN(...) asm volatile("" : __VA_ARGS__)   // keeps the stamped phase's results in front of the next stamp
+#define NJF_STAMP_LDS_FLOATS NJF_STAMP_SLOTS
+#else
+#define NJF_STAMP_FIELD
+#define NJF_STAMP_INIT(st) do {} while (0)
+#define NJF_STAMP(st, tag) do {} while (0)
+#define NJF_STAMP_P(st, tag) do {} while (0)
+#define NJF_STAMP_ARM(st, IS_PROPOSAL, wave) do {} while (0)
+#define NJF_STAMP_FLUSH(st, tag, lane) do {} while (0)
+#define NJF_STAMP_PIN(...) do {} while (0)
+#define NJF_STAMP_LDS_FLOATS 0
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Weight stream: chunks of NJF_CHUNK floats, consumed in program order, wrapping every
@@ -106,40 +150,13 @@ struct WeightStreamState {
   int dma_soff;    // byte offset (wave-uniform) of this wave's share of round 0 of the chunk being prefetched
   float* dma_dst;  // this wave's LDS destination of round 0
   int dma_next;    // 0 = job pending, NJF_DMA_ROUNDS = issued (or nothing to prefetch)
-#ifdef NJF_ASYNC_STREAM
-  int ctr;         // float index of the eight arrival counters in LDS
-  int fetch_pass;  // (idx + 2) % per_pass: position in the blob of the chunk the next step prefetches
-#endif
-#ifdef NJF_STAMPS
-  int stamp_i;     // next free slot of this wave's time-stamp log in LDS (-1: this wave does not log)
-#endif
+  NJF_STAMP_FIELD
 };
 template <int GAP_AT_, int GAP_>
 struct WeightStreamT : WeightStreamState {
   static constexpr int GAP_AT = GAP_AT_, GAP = GAP_;
 };
 typedef WeightStreamT<0x7fffffff, 0> WeightStream;
-// Timeline instrumentation of ONE wave (experiment builds only, -DNJF_STAMPS; tools/stamps.py): (tag << 24 | low 24
-// bits of s_memtime) words, logged to a spare LDS area and copied out by the render kernel when the wave retires.
-#ifdef NJF_STAMPS
-#define NJF_STAMP_SLOTS 1024
-#ifdef NJF_STAMPS_PROPOSAL   // log a wave of the proposal kernel (its LDS use ends higher than the render kernel's)
-#define NJF_STAMP_BASE LDS_FLOATS_PROPOSAL
-#else
-#define NJF_STAMP_BASE LDS_FLOATS_RENDER
-#endif
-__device__ unsigned njf_stamp_out[NJF_STAMP_SLOTS];
-#define NJF_STAMP(st, tag)                                                                                   \
-  do {                                                                                                       \
-    if ((st).stamp_i >= 0 && (st).stamp_i < NJF_STAMP_SLOTS) {                                               \
-      njf_lds[NJF_STAMP_BASE + (st).stamp_i] =                                                               \
-          __uint_as_float(((unsigned)(tag) << 24) | ((unsigned)__builtin_readcyclecounter() & 0xffffffu));   \
-      (st).stamp_i += 1;                                                                                     \
-    }                                                                                                        \
-  } while (0)
-#else
-#define NJF_STAMP(st, tag) do {} while (0)
-#endif
 #define NJF_DMA_ROUNDS (NJF_CHUNK / (NJF_THREADS * 4))
 
 __device__ __forceinline__ void dma_issue(const WeightStreamState& st, int r) {
@@ -157,7 +174,6 @@ __device__ __forceinline__ void dma_issue(const WeightStreamState& st, int r) {
 }
 
 // Issue the whole pending job at once (chunk shapes that do not interleave; start of the kernel).
-#ifndef NJF_ASYNC_STREAM
 __device__ __forceinline__ void stream_flush(WeightStreamState& st) {
   if (st.dma_next == 0) {
 #pragma unroll
@@ -165,7 +181,6 @@ __device__ __forceinline__ void stream_flush(WeightStreamState& st) {
     st.dma_next = NJF_DMA_ROUNDS;
   }
 }
-#endif
 
 template <class ST>
 __device__ __forceinline__ void dma_job(ST& st, int chunk, int buf, int wave) {
@@ -177,7 +192,6 @@ __device__ __forceinline__ void dma_job(ST& st, int chunk, int buf, int wave) {
   st.dma_next = 0;
 }
 
-#ifndef NJF_ASYNC_STREAM
 template <class ST>
 __device__ __forceinline__ void stream_begin(ST& st, const float* g, int per_pass, int passes, int wave,
                                              int lane) {
@@ -188,9 +202,7 @@ __device__ __forceinline__ void stream_begin(ST& st, const float* g, int per_pas
   st.idx = 0;
   st.in_pass = 0;
   st.dma_voff = lane * 16;
-#ifdef NJF_STAMPS
-  st.stamp_i = -1;
-#endif
+  NJF_STAMP_INIT(st);
   dma_job(st, 0, 0, wave);
   stream_flush(st);
 }
@@ -223,81 +235,6 @@ __device__ __forceinline__ const float* stream_step(ST& st, int wave, int lane) 
   return cur;
 }
 
-#else
-// ---- barrier-free weight stream (experiment) ---------------------------------------------------------------------------------
-// Four buffers, the eight waves of the workgroup drift by up to one chunk instead of meeting at a barrier per chunk.  At the
-// start of step k (consume chunk k) a wave
-//   1. waits vmcnt(0): the only DMA it can have outstanding is its share of chunk k+1, issued at step k-1 -- a whole chunk ago;
-//   2. adds one to arrival counter k & 7 (LDS atomic, lane 0);
-//   3. waits until ALL waves have arrived at step k-1: then every share of chunk k has landed (each wave passed its vmcnt(0)
-//      of step k-1 after issuing nothing newer than chunk k) and nobody reads buffer (k-2) & 3 any more;
-//   4. issues its share of chunk k+2 into buffer (k+2) & 3 = (k-2) & 3, as one burst (the waves are no longer in lock-step,
-//      so the bursts do not collide the way they did behind a barrier).
-// Counter k & 7 is reused every eight steps: its value after step k is NJF_WAVES * (k / 8 + 1).
-typedef __attribute__((address_space(3))) unsigned lds_u32;
-template <class ST>
-__device__ __forceinline__ void stream_issue(ST& st, int in_pass, int buf, int wave) {
-  dma_job(st, in_pass, buf, wave);
-#pragma unroll
-  for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
-  st.dma_next = NJF_DMA_ROUNDS;
-}
-__device__ __forceinline__ void stream_flush(WeightStreamState&) {}
-
-template <class ST>
-__device__ __forceinline__ void stream_begin(ST& st, const float* g, int per_pass, int passes, int wave,
-                                             int lane, int ctr_index = LDS_FLOATS_RENDER - LDS_CTR_FLOATS) {
-  st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7ffffff0, 0x00020000);
-  st.per_pass = per_pass;
-  st.total = per_pass * passes;
-  st.idx = 0;
-  st.in_pass = 0;
-  st.dma_voff = lane * 16;
-  st.ctr = ctr_index;
-#ifdef NJF_STAMPS
-  st.stamp_i = -1;
-#endif
-  if (threadIdx.x < LDS_CTR_FLOATS) ((lds_u32*)(njf_lds + ctr_index))[threadIdx.x] = 0u;
-  stream_issue(st, 0, 0, wave);
-  if (st.total > 1) stream_issue(st, 1 % per_pass, 1, wave);
-  st.fetch_pass = 2 % per_pass;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // chunks 0 and 1 resident, counters zeroed, the bias block the caller loaded is published
-}
-
-template <class ST>
-__device__ __forceinline__ const float* stream_step(ST& st, int wave, int lane) {
-  const int k = st.idx;
-  NJF_STAMP(st, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of chunk k+1 (issued one chunk ago)
-  NJF_STAMP(st, 2);
-  // arrival counter k & 7 += 1 (lane 0 only) and the wait for counter (k-1) & 7, both as opaque asm: C-level control flow
-  // here (45 loops per tile) splits the tile's one huge basic block and costs ~40 spilled VGPRs
-  const unsigned base = (unsigned)(size_t)(lds_u32*)(njf_lds + st.ctr);
-  {
-    unsigned addr = base + 4u * (unsigned)(k & 7), one = 1u;
-    unsigned long long saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "v"(addr), "v"(one) : "memory");
-  }
-  if (k > 0) {   // (k is wave-uniform: a scalar branch around the asm, no exec manipulation)
-    const unsigned want = (unsigned)NJF_WAVES * (unsigned)(((k - 1) >> 3) + 1);
-    unsigned addr = base + 4u * (unsigned)((k - 1) & 7), got;
-    asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_cmp_lt_u32 vcc, %0, %2\n\ts_cbranch_vccz 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
-                 : "=&v"(got) : "v"(addr), "s"(want) : "vcc", "memory");
-  }
-  asm volatile("" ::: "memory");
-  NJF_STAMP(st, 3);
-  const float* cur = njf_lds + (k & 3) * NJF_CHUNK;
-  st.idx = k + 1;
-  if (k + 2 < st.total) {
-    stream_issue(st, st.fetch_pass, (k + 2) & 3, wave);
-    st.fetch_pass += 1;
-    if (st.fetch_pass == st.per_pass) st.fetch_pass = 0;
-  }
-  return cur;
-}
-#endif
 
 // hi/lo split of two fp32 values (ReLU'd on request) into elements 2p, 2p+1 of the packed B operands:
 // hi = fp16(x), lo = fp16(x - hi) (the residual is exact in fp32, so lo carries the next 11 bits of x).
@@ -338,11 +275,6 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 // split_pair with the packed {hi0, hi1} and {lo0, lo1} halves returned as dwords
 template <bool RELU>
 __device__ __forceinline__ void split_pair_u(float x0, float x1, unsigned& hu, unsigned& lu) {
-#ifdef NJF_ABLATE_SPLIT  // experiment builds only: no conversion work (results are garbage)
-  hu = __float_as_uint(x0) >> 3;
-  lu = __float_as_uint(x1) >> 3;
-  return;
-#endif
   if (RELU) {
     x0 = relu_bits(x0);
     x1 = relu_bits(x1);
@@ -442,16 +374,7 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
       mx[p] = RELU ? bh[0][p] : (bh[0][p] & 0x7fff7fffu);
     }
 #define NJF_LDS(T) const __attribute__((address_space(3))) T*
-#ifdef NJF_ABLATE_AFRAG  // experiment builds only: no LDS reads of the weight fragments
-    auto hfrag = [&](int i) { return __builtin_bit_cast(f16x8, u32x4{(unsigned)i, (unsigned)lane, 3u, 4u}); };
-    auto f6frag = [&](int idx) { return i32x8{idx, lane, 2, 3, 4, 5, 0, 0}; };
-#else
-#ifdef NJF_ABLATE_AFRAG_HALF  // experiment builds only: every second hi fragment re-uses its neighbour's LDS read (half the
-                             // A-fragment traffic of the f16 MFMAs, same MFMA count; results are garbage)
-    auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + (i & ~1) * 1024); };
-#else
     auto hfrag = [&](int i) { return *(NJF_LDS(f16x8))(p16 + i * 1024); };                  // hi fp16 fragment (t, m): i = 4t + m
-#endif
     auto f6frag = [&](int idx) {                                                           // fp6 fragment idx = 2m + w
       const i32x4 a4 = *(NJF_LDS(i32x4))(p16 + F6_P1 + idx * 1024);
       // volatile: keeps the load-store optimiser from fusing the 8-byte tails of two fragments into one ds_read2st64_b64,
@@ -460,7 +383,6 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
       const i32x2 b2 = *(volatile NJF_LDS(i32x2))(p8 + F6_P2 + idx * 512);
       return i32x8{a4[0], a4[1], a4[2], a4[3], b2[0], b2[1], 0, 0};
     };
-#endif
     auto op8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], v[2], v[3]}); };
     f16x8 a[2] = {hfrag(0), hfrag(1)};
     unsigned sb_h = 0, sb_l = 0;
@@ -509,11 +431,7 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
           sb_l = e5 + 99u;               // ... and 2^-11 of it for the residuals
           const u32x16 hv = {bh[0][0], bh[0][1], bh[0][2], bh[0][3], bh[1][0], bh[1][1], bh[1][2], bh[1][3],
                              bh[2][0], bh[2][1], bh[2][2], bh[2][3], bh[3][0], bh[3][1], bh[3][2], bh[3][3]};
-#ifdef NJF_ABLATE_CVT6
-          const u32x6 x6 = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5]};
-#else
           const u32x6 x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, hv), __uint_as_float(sb_h << 23));
-#endif
           bh6 = i32x8{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
         }
         a[0] = n[0];
@@ -537,11 +455,7 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
     i32x8 wh6_0 = f6frag(0), wh6_1 = f6frag(2);
     const u32x16 lv = {bl[0][0], bl[0][1], bl[0][2], bl[0][3], bl[1][0], bl[1][1], bl[1][2], bl[1][3],
                        bl[2][0], bl[2][1], bl[2][2], bl[2][3], bl[3][0], bl[3][1], bl[3][2], bl[3][3]};
-#ifdef NJF_ABLATE_CVT6
-    const u32x6 y6 = {lv[0], lv[1], lv[2], lv[3], lv[4], lv[5]};
-#else
     const u32x6 y6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, lv), __uint_as_float(sb_l << 23));
-#endif
     const i32x8 bl6 = {(int)y6[0], (int)y6[1], (int)y6[2], (int)y6[3], (int)y6[4], (int)y6[5], 0, 0};
     __builtin_amdgcn_sched_barrier(0);
     NJF_MFMA6(out[2], wl6_2, bh6, 2, s_w1, sb_h);
@@ -562,9 +476,6 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
     // 32-clock MFMA hides ~5 single-issue instructions, MI355X_MICROARCH.md).
     const f16x8* base = (const f16x8*)wl + lane;
     constexpr int T = NKB * 2;
-#ifdef NJF_F16_SETPRIO   // A/B builds: the wave inside a chunk's MFMA stream outranks its SIMD neighbour's VALU phases
-    __builtin_amdgcn_s_setprio(NJF_F16_SETPRIO);
-#endif
     unsigned bc[4], bn[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) bc[p] = pack_pair_f16<RELU>(in[KB0][2 * p], in[KB0][2 * p + 1]);
@@ -573,45 +484,18 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
       f16x8 a[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
-#ifdef NJF_F16_PREFETCH2   // A/B builds: A fragments requested TWO K-steps ahead (16 more registers)
-      f16x8 n1[4] = {a[0], a[1], a[2], a[3]};
-      if (T > 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) n1[i] = base[(4 + i) * 64];
-      }
-#endif
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-#ifdef NJF_F16_PREFETCH2
-        f16x8 n[4] = {n1[0], n1[1], n1[2], n1[3]};
-        if (t + 2 < T) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) n1[i] = base[((t + 2) * 4 + i) * 64];
-        }
-#else
         f16x8 n[4] = {a[0], a[1], a[2], a[3]};
         if (t + 1 < T) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
         }
-#endif
         if constexpr (SPREAD) {  // the next chunk's 8 DMA rounds, two behind each of the first four steps
-#if defined(NJF_F16_DMA_PLACE) && NJF_F16_DMA_PLACE == 1   // A/B builds: one round per step (8-step chunks)
-          if (T == 8 ? true : t < 4) {
-            if (T == 8) dma_issue(st, t);
-            else { dma_issue(st, 2 * t); dma_issue(st, 2 * t + 1); }
-          }
-#elif defined(NJF_F16_DMA_PLACE) && NJF_F16_DMA_PLACE == 2  // A/B builds: the whole chunk as one burst behind the barrier
-          if (t == 0) {
-#pragma unroll
-            for (int r = 0; r < NJF_DMA_ROUNDS; ++r) dma_issue(st, r);
-          }
-#else
           if (t < 4) {
             dma_issue(st, 2 * t);
             dma_issue(st, 2 * t + 1);
           }
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -649,9 +533,6 @@ __device__ __forceinline__ void mma_chunk(ST& st, const float* __restrict__ wl, 
         for (int p = 0; p < 4; ++p) bc[p] = bn[p];
       }
     }
-#ifdef NJF_F16_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   } else {
     // packed [t][mb][hi|lo][lane][8 x f16], t = K-step of 16 (8 k-values from each lane half), same bytes as fp32.
     // Lane (j,hh) supplies its own registers 8*tt .. 8*tt+7 of block kb as the 8 k-values of step t = 2*kb + tt.
@@ -754,15 +635,9 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ bl, int hh, 
     for (int m = 0; m < MB; ++m) acc[m] = (f32x16)(0.f);
   return;
 #endif
-#if defined(NJF_BIAS_MFMA_ALL)  // A/B builds only
-  constexpr bool VALU = false;
-#elif defined(NJF_BIAS_VALU)
-  constexpr bool VALU = true;
-#else
   // the MFMA form only where the matrix pipe has the headroom (the fp6-corrected chunks); the f16x2 chunks are bound by
   // their 48 matrix instructions (proposal pass: -0.5...1 % with v_add, profiles/r02_ab_variants.txt)
   constexpr bool VALU = ASSIGN || (PREC != PREC_F16F6 && PREC != PREC_F16);
-#endif
   if constexpr (!ASSIGN && PREC == PREC_F16 && SPLIT) {   // (whatever the A/B flags above say: the table holds bit patterns)
     // plain-fp16 networks: the accumulated biases are packed as {fp16 hi, fp16 lo} pairs (njf_pack_resnetfc: bias = hi + lo to
     // 22 bits) and added by ONE f16 MFMA per output block -- A = [hi, lo, 0 ...] for k = 0, 1 (lane half 0), B = [1, 1, 0 ...]:
@@ -877,15 +752,11 @@ __device__ __forceinline__ void point_footprint(const PointGeom& g, Footprint& f
   const float u1 = dot3(c.k + 3, xc, yc, zc);
   const float u2 = dot3(c.k + 6, xc, yc, zc);
   const float den = u2 + 1e-9f;
-#ifdef NJF_FOOTPRINT_IEEE_DIV  // rounds 1-2 (A/B builds): two IEEE divisions, ~20 VALU instructions per footprint
-  const float u = u0 / den, v = u1 / den;
-#else
   // one v_rcp_f32 (1 ulp) and two multiplications: the footprint only feeds the bilinear weights and texel indices -- smooth
   // in uv, unlike the camera-space coordinates above, whose bits the positional encoding amplifies -- and it is recomputed
   // in front of each of the six gathers of a tile
   const float inv = __builtin_amdgcn_rcpf(den);
   const float u = u0 * inv, v = u1 * inv;
-#endif
   const float gx = (u - 0.5f) * 2.0f, gy = (v - 0.5f) * 2.0f;
   float ix = ((gx + 1.0f) / 2.0f) * (float)(wf - 1);
   float iy = ((gy + 1.0f) / 2.0f) * (float)(hf - 1);
@@ -1047,9 +918,7 @@ __device__ __forceinline__ void add_hoisted_latent_half(const float* __restrict_
 // f = 16*MB*hh + 16*m + 8*q + e sits at position 32*m + 16*q + 8*hh + e (njf_hoist_position, layout 2): the two lanes that
 // own a point read ADJACENT 16-byte pieces (8 channels each) in the same instruction.  Each value is folded with ONE
 // v_fma_mix_f32 (fp16 source, fp32 weight and accumulator): the bilinear interpolation itself is carried out in fp32.
-#ifndef NJF_F16_GATHER_DEPTH
 #define NJF_F16_GATHER_DEPTH 8
-#endif
 template <int MB, int DEPTH = NJF_F16_GATHER_DEPTH>
 __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restrict__ gz, const PointGeom& g, int hh,
                                                        f32x16 (&h)[MB], const Footprint* shared = nullptr) {
@@ -1060,17 +929,7 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
   if (shared != nullptr) f = *shared;   // (compile-time known at every call site: TileShareF16)
   else point_footprint(g, f);
   const _Float16* gb = gz + (size_t)g.gofs + 8 * hh;
-#ifdef NJF_ABLATE_GATHER_ADDR   // experiment builds only (results are garbage): every load instruction reads 4 records of 256
-                                // contiguous bytes (16 lanes each: the texel of the group's first lane) instead of 64 scattered
-                                // 16-byte pieces -- what a gather staged through LDS by DMA would present to the texture
-                                // addresser; same load count, same bytes per lane
-  const int lane_ = threadIdx.x & 63;
-  const int cap_ = (g.hf * g.wf - 2) * g.stride;
-  auto lead = [&](int t) { return min(__shfl(t, lane_ & ~15, 64), cap_) + (lane_ & 15) * 8 - 8 * hh; };
-  const _Float16* p[4] = {gb + lead(f.t00), gb + lead(f.t01), gb + lead(f.t10), gb + lead(f.t11)};
-#else
   const _Float16* p[4] = {gb + f.t00, gb + f.t01, gb + f.t10, gb + f.t11};
-#endif
   const float w[4] = {f.w00, f.w01, f.w10, f.w11};
   // a batch = (texel t, block m) = 2 loads of 16 bytes (16 channels); DEPTH batches in flight, refilled as they are consumed
   constexpr int NB = 4 * MB;
@@ -1078,43 +937,18 @@ __device__ __forceinline__ void add_hoisted_latent_f16(const _Float16* __restric
   f16x8 v[D][2];
   auto issue = [&](int b) {
     const _Float16* src = p[b / MB] + 32 * (b % MB);
-#ifdef NJF_ABLATE_GATHER_HALFBYTES   // experiment builds only (results are garbage): every load fetches 8 bytes per lane instead of 16
-                                     // and its four values are folded twice -- same load and VALU instruction counts, HALF the bytes
-    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f16x4_t x = *(const f16x4_t*)(src + 16 * q);
-      v[b % D][q] = __builtin_shufflevector(x, x, 0, 1, 2, 3, 0, 1, 2, 3);
-    }
-#elif defined(NJF_ABLATE_GATHER_NOLOAD)   // experiment builds only (garbage): no loads at all, the 256 folds read registers
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      v[b % D][q] = __builtin_bit_cast(f16x8, u32x4{(unsigned)b, (unsigned)q, (unsigned)f.t00, (unsigned)f.t11});
-      asm volatile("" : "+v"(v[b % D][q]));
-    }
-#else
 #pragma unroll
     for (int q = 0; q < 2; ++q) v[b % D][q] = *(const f16x8*)(src + 16 * q);
-#endif
   };
 #pragma unroll
   for (int b = 0; b < D; ++b) issue(b);
-#ifdef NJF_F16_GATHER_PIN   // A/B builds: every load of the first D batches is issued before the first fold (see the note below)
-  __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int t = b / MB, m = b % MB;
-#ifdef NJF_ABLATE_GATHER_NOFOLD   // experiment builds only (garbage): every load is issued and waited for, ONE fold per load instead of 8
-#pragma unroll
-    for (int q = 0; q < 2; ++q) h[m][8 * q] = fmaf((float)v[b % D][q][0], w[t], h[m][8 * q]);
-    asm volatile("" : : "v"(v[b % D][0]), "v"(v[b % D][1]));
-#else
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) h[m][8 * q + e] = fmaf((float)v[b % D][q][e], w[t], h[m][8 * q + e]);
-#endif
     asm volatile("" : "+v"(h[m]) : : "memory");  // the fmas retire into h before the batch's registers are reloaded
     if (b + D < NB) issue(b + D);
     __builtin_amdgcn_sched_barrier(0);
@@ -1165,88 +999,6 @@ __device__ __forceinline__ void mma_lin_in_f16_packed(ST& st, const float* __res
   }
 }
 
-// PREC_F16, fc_0 chunk of a block WITH the next block's gather riding on it (-DNJF_F16_RIDE): net += W * relu(h) exactly as
-// mma_chunk<PREC_F16, 4, 4, 0, true, 4>, and h += the hoisted latent of the NEXT block (`gz`) while the chunk's MFMAs run.
-// K-step t reads h[t >> 1] only, and its fp16 copy is made one step ahead, so h[m] is dead from step 2m + 1 on -- until fc_1
-// accumulates into it -- and the sum  h + fc_1(..) + latent  does not care in which order it is formed.  The footprint's 16
-// (texel, block) batches are ordered block-major (b = 4 m + texel), four in flight (32 VGPRs): those of block 0 are requested
-// in front of the loop, every fold frees a slot for the batch four further on; folds of block m sit in steps 2m+1, 2m+2
-// (block 3: step 7 and the tail).  The wave's own 32-clock MFMAs cover the fold's v_fma_mix stream and most of the latency of
-// the loads, which a gather in front of the chunk exposes in full (5,200 clocks per gather with eight waves of a CU arriving at
-// the texture addresser together, profiles/r05_stamps_f16.txt).
-#ifndef NJF_F16_RIDE_DEPTH
-#define NJF_F16_RIDE_DEPTH 2   // (texel, block) batches in flight, 8 VGPRs each (static report, render kernel: 1 -> 0, 2 -> 2, 3 -> 13, 4 -> 36 spilled VGPRs)
-#endif
-template <bool RELU, class ST>
-__device__ __forceinline__ void mma_chunk_f16_ride(ST& st, const float* __restrict__ wl, int lane, f32x16 (&h)[4],
-                                                   f32x16 (&out)[4], const _Float16* __restrict__ gz, const PointGeom& g) {
-  const f16x8* base = (const f16x8*)wl + lane;
-  constexpr int T = 8, D = NJF_F16_RIDE_DEPTH;
-  Footprint f;
-  point_footprint(g, f);
-  const _Float16* gb = gz + (size_t)g.gofs + 8 * (lane >> 5);
-  const int o[4] = {f.t00, f.t01, f.t10, f.t11};
-  const float w[4] = {f.w00, f.w01, f.w10, f.w11};
-  f16x8 v[D][2];
-  auto issue = [&](int b) {
-    const _Float16* src = gb + o[b & 3] + 32 * (b >> 2);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) v[b % D][q] = *(const f16x8*)(src + 16 * q);
-  };
-  auto fold = [&](int b, int q) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) h[b >> 2][8 * q + e] = fmaf((float)v[b % D][q][e], w[b & 3], h[b >> 2][8 * q + e]);
-  };
-  unsigned bc[4], bn[4];
-#pragma unroll
-  for (int pp = 0; pp < 4; ++pp) bc[pp] = pack_pair_f16<RELU>(h[0][2 * pp], h[0][2 * pp + 1]);
-  auto op8 = [](const unsigned (&u)[4]) { return __builtin_bit_cast(f16x8, u32x4{u[0], u[1], u[2], u[3]}); };
-#pragma unroll
-  for (int b = 0; b < D; ++b) issue(b);
-  f16x8 a[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a[i] = base[i * 64];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    f16x8 n[4] = {a[0], a[1], a[2], a[3]};
-    if (t + 1 < T) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) n[i] = base[((t + 1) * 4 + i) * 64];
-    }
-    if (t < 4) {
-      dma_issue(st, 2 * t);
-      dma_issue(st, 2 * t + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int b0 = 2 * (t - 1);   // the two batches folded in this step (t >= 1)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], op8(bc), out[m], 0, 0, 0);
-      if (t + 1 < T) {
-        const int kb2 = (t + 1) >> 1, tt2 = (t + 1) & 1;
-        bn[m] = pack_pair_f16<RELU>(h[kb2][8 * tt2 + 2 * m], h[kb2][8 * tt2 + 2 * m + 1]);
-      }
-      if (t >= 1) {
-        fold(b0 + (m >> 1), m & 1);
-        if (m & 1) {
-          asm volatile("" : "+v"(h[(b0 + (m >> 1)) >> 2]) : : "memory");   // the fmas retire before the slot is reloaded
-          if (b0 + (m >> 1) + D < 16) issue(b0 + (m >> 1) + D);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a[i] = n[i];
-      bc[i] = bn[i];
-    }
-  }
-#pragma unroll
-  for (int b = 14; b < 16; ++b) {
-    fold(b, 0);
-    fold(b, 1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
 
 // Which form a network uses follows its MFMA precision (and so does the layout its lin_z columns are packed in,
 // njf_hoist_layout): the quad/MFMA form where the matrix pipe has headroom -- the fp6-corrected networks, measured
@@ -1255,15 +1007,9 @@ __device__ __forceinline__ void mma_chunk_f16_ride(ST& st, const float* __restri
 template <int MB, int PREC, int DEPTH = 4>
 __device__ __forceinline__ void add_hoisted_latent(const float* __restrict__ gz, const PointGeom& g, int lane,
                                                    f32x16 (&h)[MB]) {
-#if defined(NJF_GATHER_ALWAYS_HALF)  // A/B builds only (tools/ablate.sh)
-  add_hoisted_latent_half<MB, DEPTH>(gz, g, lane >> 5, h);
-#elif defined(NJF_GATHER_ALWAYS_QUAD)
-  add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
-#else
   if constexpr (PREC == PREC_F16) add_hoisted_latent_f16<MB>((const _Float16*)gz, g, lane >> 5, h);
   else if constexpr (PREC == PREC_F16F6) add_hoisted_latent_quad<MB, DEPTH>(gz, g, lane, h);
   else add_hoisted_latent_half<MB, DEPTH>(gz, g, lane >> 5, h);
-#endif
 }
 
 // Address arithmetic on a hoisted map in ELEMENTS (fp32 maps: floats; PREC_F16 maps: halves).  The fused kernels carry map
@@ -1289,26 +1035,11 @@ __device__ __forceinline__ float sin_accurate(float arg) {
   float e = fmaf(arg, C_HI, -u);
   e = fmaf(arg, C_LO, e);
   const float y = (u - rintf(u)) + e;                    // [-0.5, 0.5] (+ rounding)
-#ifdef NJF_SIN_POLYNOMIAL  // the rounds 1-2 form, kept for A/B builds
-  float f = y;
-  if (fabsf(f) > 0.25f) f = copysignf(0.5f, f) - f;      // sin(pi - x) = sin(x); |f| <= 0.25 afterwards
-  const float y2 = f * f;
-  // sin(2*pi*f) = f * P(f^2), Taylor to x^13 (truncation < 6e-10 at |x| = pi/2)
-  float p = 3.8199525848482803f;            // +(2pi)^13/13!
-  p = fmaf(p, y2, -15.094642576822984f);    // -(2pi)^11/11!
-  p = fmaf(p, y2, 42.058693944897634f);     // +(2pi)^9/9!
-  p = fmaf(p, y2, -76.70585975306136f);     // -(2pi)^7/7!
-  p = fmaf(p, y2, 81.60524927607504f);      // +(2pi)^5/5!
-  p = fmaf(p, y2, -41.341702240399755f);    // -(2pi)^3/3!
-  p = fmaf(p, y2, 6.283185307179586f);      // 2pi
-  return f * p;
-#else
   // v_sin_f32 takes its argument in REVOLUTIONS, which is what the reduction above produces: on [-0.5, 0.5] it measures
   // 1.25e-7 max abs error against sin(2 pi y) in double (tools/probes/probe_sin.hip; the degree-13 polynomial with its
   // quadrant fold it replaces: 1.93e-7) for one quarter-rate instruction instead of 13 full-rate ones -- the positional
   // encoding is 1,200 of the render kernel's 7,700 VALU instructions per tile (profiles/r03_isa_budget.txt).
   return __builtin_amdgcn_sinf(y);
-#endif
 }
 
 // Positional encoding in B-operand slot order (see njf_pack: kind 1).  Lane half hh=0 supplies
@@ -1407,47 +1138,6 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
       }
   }
-#ifdef NJF_GATHER_DEPHASE
-  // Experiment: the four waves of a workgroup reach every gather together (same barrier phase) and share the CU's texture
-  // addresser, which is what bounds the gather (6.2 k cycles each, 19 % of a tile, tools/stamps.py).  The latent of block k
-  // only has to be in h before fc_0 of block k reads it, and adding it commutes with the products accumulated into h, so
-  // HALF of the waves ("early": wave & 2) fetch it one chunk earlier -- the latent of block 0 in front of lin_in (net is
-  // free), the latents of blocks 1, 2 between the two K-halves of the previous block's fc_1 (the first half of net is dead
-  // by then: 32 landing registers, DEPTH 2) -- and the other half where they always did.  The order of the fp32 additions
-  // into h differs between the two groups (last-bit differences between rays that land in different wave slots).
-  const bool early = (wave & 2) != 0;
-  if (early) add_hoisted_latent<4, PREC>(gz, g, lane, h);
-  {
-    const float* wl = stream_step(st, wave, lane);
-    mma_chunk<PREC, 4, 2, 0, false, 2>(st, wl, lane, pe, h);  // lin_in (bias folded into slot 63)
-  }
-  if (!early) add_hoisted_latent<4, PREC>(gz, g, lane, h);
-  for (int blk = 0; blk < 5; ++blk) {
-    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
-    const float* bl = bias + blk * 256;
-    bias_init<4, true, PREC>(bl, hh, net);
-    {
-      const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, h, net);
-    }
-    {
-      const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, h, net);
-    }
-    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
-    bias_init<4, false, PREC>(bl + 128, hh, h);
-    {
-      const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 0, true, 4>(st, wl, lane, net, h);
-    }
-    if (early && blk < 2) add_hoisted_latent<4, PREC, 2>(gz + (blk + 1) * 128, g, lane, h);
-    {
-      const float* wl = stream_step(st, wave, lane);
-      mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, net, h);
-    }
-    if (!early && blk < 2) add_hoisted_latent<4, PREC>(gz + (blk + 1) * 128, g, lane, h);
-  }
-#else
   {
     const float* wl = stream_step(st, wave, lane);
     if constexpr ((SHARED & 1) != 0) mma_lin_in_f16_packed(st, wl, lane, share->pe, h);
@@ -1458,37 +1148,6 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
     static_assert(!DUMP, "the plain-fp16 mode is an inference mode (training forwards dump fp32-class activations)");
     Footprint fp_net;
     if constexpr ((SHARED & 2) != 0) point_footprint(g, fp_net);
-#ifdef NJF_F16_RIDE
-    // the latents of blocks 1 and 2 ride on the fc_0 chunks of blocks 0 and 1 (mma_chunk_f16_ride); two loops, so that no
-    // join point carries both forms of the chunk
-    NJF_STAMP(st, 4);
-    add_hoisted_latent<4, PREC>(map_at<PREC>(gz, 0), g, lane, h);
-    NJF_STAMP(st, 5);
-    for (int blk = 0; blk < 2; ++blk) {
-      bias_init<4, true, PREC>(bias + blk * 256, hh, net);
-      {
-        const float* wl = stream_step(st, wave, lane);
-        mma_chunk_f16_ride<true>(st, wl, lane, h, net, (const _Float16*)map_at<PREC>(gz, (blk + 1) * 128), g);
-      }
-      {
-        const float* wl = stream_step(st, wave, lane);
-        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
-      }
-    }
-    for (int blk = 2; blk < 5; ++blk) {
-      const float* bl = bias + blk * 256;
-      bias_init<4, true, PREC>(bl, hh, net);
-      {
-        const float* wl = stream_step(st, wave, lane);
-        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, h, net);
-      }
-      bias_init<4, false, PREC, true>(bl + 128, hh, h);
-      {
-        const float* wl = stream_step(st, wave, lane);
-        mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
-      }
-    }
-#else
     for (int blk = 0; blk < 5; ++blk) {
       if (blk < 3) {
         NJF_STAMP(st, 4);
@@ -1508,7 +1167,6 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         mma_chunk<PREC, 4, 4, 0, true, 4>(st, wl, lane, net, h);
       }
     }
-#endif
   } else
   for (int blk = 0; blk < 5; ++blk) {
     if (blk < 3) {
@@ -1542,7 +1200,6 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
       }
     }
   }
-#endif
   if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h);
   bias_init<1, true, PREC>(bias + 1280, hh, out);
   {

@@ -253,15 +253,9 @@ __global__ void fill_kernel(float* p, int n, float v) {
 //   0 "half" (F32, F16X2): the two lanes that own a point read adjacent 16-byte pieces
 //   1 "quad" (F16F6): the 16*MB floats of a lane are contiguous, accumulator register 4*e + i <-> piece i, dword e
 //   2 "half, fp16 map" (F16): as 0 with 8-channel pieces
-#if defined(NJF_GATHER_ALWAYS_HALF)  // A/B builds only (tools/ablate.sh)
-__host__ __device__ inline int njf_hoist_layout(int) { return 0; }
-#elif defined(NJF_GATHER_ALWAYS_QUAD)
-__host__ __device__ inline int njf_hoist_layout(int) { return 1; }
-#else
 __host__ __device__ inline int njf_hoist_layout(int precision) {
   return precision == NJF_PRECISION_F16F6 ? 1 : (precision == NJF_PRECISION_F16 ? 2 : 0);
 }
-#endif
 __host__ __device__ inline int njf_hoist_position(int f, int mb_count, int layout) {
   const int hh = f / (16 * mb_count), r = f % (16 * mb_count);
   const int m = r >> 4;
@@ -391,48 +385,6 @@ extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out,
 // =============================================================================================
 // feature projection  G[b,p,n] = sum_k F[b,k,p] * wz[k*ld+n] + bz[n]   (exact-fp32 MFMA kernel; split variant below)
 // =============================================================================================
-// One wave: 32 texels x 128 channels, K = 512 swept two at a time straight from global memory
-// (A: 32 consecutive texels of one channel plane = one 128-B line; B: 32 consecutive output
-// channels of one k row).  Per-image cost: 19 GFLOP at 256^2.
-__global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ feats, const float* __restrict__ wz,
-                                                      const float* __restrict__ bz, int hw, int n, int ld, int K,
-                                                      float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z;
-  const int p0 = (blockIdx.x * 4 + wave) * 32;
-  const int n0 = blockIdx.y * 128;
-  if (p0 >= hw) return;
-  const int p = min(p0 + j, hw - 1);
-  const float* fa = feats + (size_t)b * K * hw + p;
-  f32x16 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x16)(0.f);
-  int nn[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) nn[t] = min(n0 + 32 * t + j, n - 1);
-  for (int k0 = 0; k0 < K; k0 += 8) {  // K is a multiple of 16 (checked by the launchers)
-#pragma unroll
-    for (int k = k0; k < k0 + 8; k += 2) {
-      const float a = fa[(size_t)(k + kh) * hw];
-      const float* wr = wz + (size_t)(k + kh) * ld;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[nn[t]], acc[t], 0, 0, 0);
-    }
-  }
-  // D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (texel)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = n0 + 32 * t + j;
-    if (c >= n) continue;
-    const float bias = bz ? bz[c] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (p0 + row < hw) out[((size_t)b * hw + p0 + row) * n + c] = acc[t][r] + bias;
-    }
-  }
-}
 
 // Split-precision variant (PREC_F16X2): one wave = 64 texels (two A tiles) x 32*NJF_PROJ_NT channels, K swept 16
 // at a time with v_mfma_f32_32x32x16_f16.  Both operands are fp32 in memory and split x = hi + lo on the fly
@@ -635,11 +587,7 @@ static void launch_project(const float* feats, int K, const float* wz, int ld, c
     else project_kernel_f16x2<16><<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
   } else {
     dim3 grid((hw + 127) / 128, (n + 127) / 128, batch);
-#ifdef NJF_PROJECT_DIRECT   // A/B builds only: the rounds 1-4 form (operands straight from global memory)
-    project_kernel<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
-#else
     project_kernel_f32_lds<<<grid, 256, 0, s>>>(feats, wz, bz, hw, n, ld, K, out);
-#endif
   }
 }
 
@@ -850,9 +798,6 @@ extern "C" int njf_project_pyramid(const NjfPyramidLevel* levels, int num_levels
       blk.shift[l] = pyramid_shift(u.h[l], u.w[l], u.height, u.width);
       blocked = blocked && blk.shift[l] > 0;
     }
-#ifdef NJF_UPSAMPLE_PER_TEXEL  // experiment builds only: the per-texel form for every pyramid
-    blocked = false;
-#endif
     if (blocked) {
       const long long total = (long long)batch * (u.height >> 2) * (u.width >> 2) * (n >> 2);
       upsample_add_block_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blk);
@@ -1337,16 +1282,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
   load_bias_block(a.b_pack, NJF_RESNET_B_FLOATS, 0);
   const int tiles = (a.s_in + 31) >> 5;
   WeightStream st;
-#ifdef NJF_ASYNC_STREAM
-  stream_begin(st, a.w_pack, NJF_RESNET_CHUNKS, tiles, wave, lane, LDS_FLOATS_PROPOSAL - LDS_CTR_FLOATS);
-#else
   stream_begin(st, a.w_pack, resnet_chunks<PREC>(), tiles, wave, lane);
-#endif
-#ifdef NJF_STAMPS_PROPOSAL
-  const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
-  if (stamping) st.stamp_i = 0;
-  NJF_STAMP(st, 9);
-#endif
+  NJF_STAMP_ARM(st, true, wave);
 
   CamCtx cam;
   load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
@@ -1372,9 +1309,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     const float px = ox + (dx * se) / 2.0f, py = oy + (dy * se) / 2.0f, pz = oz + (dz * se) / 2.0f;
     PointGeom g;
     point_geometry(cam, px, py, pz, a.rc.gmap.height, a.rc.gmap.width, a.rc.gmap.stride, 0u, g);
-#ifdef NJF_STAMPS_PROPOSAL
-    NJF_STAMP(st, 10);
-#endif
+    NJF_STAMP_P(st, 10);
     f32x16 pe[2];
     positional_encoding(g.xc, g.yc, g.zc, hh, pe);
     f32x16 out[1];
@@ -1385,9 +1320,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
     // (plain fp16: one footprint for the three gathers + lin_in from a packed encoding, as in the render kernel, measured 0.7 %
     //  SLOWER here -- profiles/r05_ablate_f16.txt block k -- and is not used)
     resnet_tile<PREC, DUMP>(st, bias, gz, g, pe, wave, lane, out, dump);
-#ifdef NJF_STAMPS_PROPOSAL
-    NJF_STAMP(st, 14);
-#endif
+    NJF_STAMP_P(st, 14);
     const float pre = __shfl(out[0][0], j, 64);
     const float sigma = expf(pre - 1.0f);
     const float w = tile_weights(end - start, sigma, valid, j, carry);
@@ -1401,19 +1334,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) proposal_kernel(ProposalArgs a
       }
     }
   }
-#ifdef NJF_STAMPS_PROPOSAL
-  NJF_STAMP(st, 13);
-#endif
+  NJF_STAMP_P(st, 13);
   __syncthreads();
   const float* u = a.u + (a.u_per_ray ? (size_t)rayc * (a.s_out + 1) : 0);
   pdf_resample_ray(sc, bins, a.s_in, u, a.s_out, a.bins_out + (size_t)rayc * (a.s_out + 1), lane, ray_ok);
-#ifdef NJF_STAMPS_PROPOSAL
-  NJF_STAMP(st, 15);
-  if (stamping) {
-    for (int i = lane; i < NJF_STAMP_SLOTS; i += 64)
-      njf_stamp_out[i] = i < st.stamp_i ? __float_as_uint(njf_lds[NJF_STAMP_BASE + i]) : 0u;
-  }
-#endif
+  NJF_STAMP_FLUSH(st, 15, lane);
 }
 
 // =============================================================================================
@@ -1485,9 +1410,7 @@ __device__ __forceinline__ void jacobian_stage(ST& st, const float* __restrict__
   f32x16 pe[2];
   NJF_STAMP(st, 6);  // Jacobian stage begins
   positional_encoding(xc, yc, zc, hh, pe);
-#ifdef NJF_STAMPS
-  asm volatile("" : "+v"(pe[0]), "+v"(pe[1]));
-#endif
+  NJF_STAMP_PIN("+v"(pe[0]), "+v"(pe[1]));
   NJF_STAMP(st, 7);  // encoding done
   if (JKIND == 1)
     resnet_tile<PREC, DUMP == 1>(st, bias, gz_j, g, pe, wave, lane, jac, dump);
@@ -1585,15 +1508,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
   const int tiles = (S + 31) >> 5;
   WeightStreamT<resnet_gap_at<PREC>(), resnet_gap<PREC>()> st;
   stream_begin(st, a.w_all, resnet_chunks<PREC>() + 1 + J_CHUNKS, tiles, wave, lane);
-#ifdef NJF_STAMPS
-#ifdef NJF_STAMPS_PROPOSAL
-  const bool stamping = false;  // that build logs a wave of the proposal kernel instead
-#else
-  const bool stamping = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
-#endif
-  if (stamping) st.stamp_i = 0;
-  NJF_STAMP(st, 9);
-#endif
+  NJF_STAMP_ARM(st, false, wave);
 
   CamCtx cam;
   load_ctx(a.rc.cams.ctxt_w2c, a.rc.cams.ctxt_k, b, cam);
@@ -1641,10 +1556,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     // ---- density net -> sample weight; everything that only needs the weight is composited right away
     f32x16 geo[1];
     // plain-fp16 inference: the tile's packed encoding serves both networks, one footprint the gathers of a network (TileShareF16)
-#ifndef NJF_F16_SHARE_D
 #define NJF_F16_SHARE_D 1
 #define NJF_F16_SHARE_J 3
-#endif
     // (the instantiations that also composite the action features, AF, have no registers to spare: 6-35 spilled VGPRs with any of it)
     constexpr int SHARE_D = (PREC == PREC_F16 && DUMP == 0 && !AF) ? NJF_F16_SHARE_D : 0;
     constexpr int SHARE_J = (SHARE_D != 0 && JKIND == 1 && PRECJ == PREC_F16) ? NJF_F16_SHARE_J : 0;
@@ -1656,9 +1569,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
       place_sample(bin0, bin1, near, far, ox, oy, oz, dx, dy, dz, sp);
       NJF_STAMP(st, 14);  // density net returned
       w = tile_weights(sp.delta, sigma, valid, j, carry);
-#ifdef NJF_STAMPS
-      asm volatile("" : "+v"(w));
-#endif
+      NJF_STAMP_PIN("+v"(w));
       NJF_STAMP(st, 15);  // weights done
       if (valid) {
         acc_w += w;
@@ -1723,13 +1634,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     }
   }
 
-#ifdef NJF_STAMPS
-  NJF_STAMP(st, 13);  // tiles done
-  if (stamping) {
-    for (int i = lane; i < NJF_STAMP_SLOTS; i += 64)
-      njf_stamp_out[i] = i < st.stamp_i ? __float_as_uint(njf_lds[NJF_STAMP_BASE + i]) : 0u;
-  }
-#endif
+  NJF_STAMP_FLUSH(st, 13, lane);  // tiles done
   // reduce over the ray's samples (32 lanes of a half; both halves hold identical per-sample data)
   acc_w = half_sum(acc_w);
   acc_wt = half_sum(acc_wt);
@@ -2751,14 +2656,10 @@ template <typename K, typename A>
 static int launch_fused(K kernel, const A& args, int work_items, hipStream_t s, int lds_floats = LDS_FLOATS_RENDER) {
   static_assert(sizeof(A) <= 4096, "kernel args too large");
   const int grid = (work_items + NJF_WAVES - 1) / NJF_WAVES;
-#ifdef NJF_ABLATE_ONE_WG_PER_CU  // experiment builds only: pad LDS so a single 4-wave workgroup owns the CU
-  const size_t lds = 100 * 1024;
-#else
 #ifdef NJF_STAMPS
   const size_t lds = (size_t)(lds_floats + NJF_STAMP_SLOTS) * sizeof(float);
 #else
   const size_t lds = (size_t)lds_floats * sizeof(float);
-#endif
 #endif
   if (!lds_attribute_known((const void*)kernel)) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2892,11 +2793,7 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
   // spill path -- 104-119 spilled VGPRs -> 45-68 -- and measured them SLOWER or equal on the C4 shard (1 x 8,192 rays: action step
   // 8.56 vs 8.34 ms, perception 13.63 vs 13.67 ms, two repetitions each, profiles/r05_spills_ab.txt): the spills are not what
   // these kernels wait for.  -DNJF_TRAIN_NO_AF rebuilds the A/B.
-#ifdef NJF_TRAIN_NO_AF
-  constexpr bool TRAIN_AF = false;
-#else
   constexpr bool TRAIN_AF = true;
-#endif
   const bool training_forward = out->jac_act != nullptr || out->jac_pe != nullptr || out->den_act != nullptr;
   if (!TRAIN_AF && training_forward && out->action_features != nullptr) return NJF_E_MODE;
   if (out->jac_act != nullptr || (out->jac_pe != nullptr && out->den_act == nullptr)) {
