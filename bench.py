@@ -55,7 +55,26 @@ HEADLINE_PRECISION = "f32"        # the reference's arithmetic; see the module d
 
 # Algorithmic work (hoisted-lin_z formulation), MACs per point
 MAC_PROPOSAL = 172_032
-MAC_DENSITY, MAC_JACOBIAN, MAC_COLOR = 173_952, 174_976, 6_272
+MAC_DENSITY, MAC_COLOR = 173_952, 6_272
+
+
+def mac_jacobian(decoder: str, action_dim: int) -> dict:
+    """MACs per point of the Jacobian head (SURVEY 8d's table).  `canonical` prices the roofline block.
+
+    jacobian_mlp (action_decoder_jacobian.py:324-337): ResnetFC with d_out = 3A, hoisted lin_z: 8,064 + 163,840 + 128 * 3A
+    (A = 8: SURVEY's 174,976).
+    jacobian_transformer (action_decoder_jacobian.py:418-446): SURVEY prices the reference formulation at 284,096 (A = 8).  The
+    build evaluates an algebraically FOLDED form (decoder.py::ActionDecoderJacobianTransformer.packed: query projection hoisted
+    into the feature map like lin_z; to_q, the keys, the LayerNorm affine and the softmax scale folded into one 64 x 8A matrix per
+    layer, values and to_out into another): 63 * 64 (encoding part of the query) + 3 * (2 * 64 * 8A + 2 * 64 * 64) + 64 * 3A
+    = 28,608 + 3,264 A (A = 8: 54,720).  The canonical figure is the MINIMAL (folded) count, as for the hoisted ResnetFC;
+    `reference_formulation` scores the same time against SURVEY's count for comparison."""
+    if decoder == "jacobian_mlp":
+        return {"canonical": 8_064 + 163_840 + 128 * 3 * action_dim, "reference_formulation": 371_584 - 128 * 3 * (8 - action_dim)}
+    folded = 63 * 64 + 3 * (2 * 64 * 8 * action_dim + 2 * 64 * 64) + 64 * 3 * action_dim
+    # reference formulation per point: query MLP 575 x 64, per layer to_q 64 x 512 + dots / attn @ V 2 * 512 * A + to_out 512 x 64 +
+    # feed-forward 2 * 64 * 64, head 64 x 3A  (= SURVEY's 284,096 at A = 8)
+    return {"canonical": folded, "reference_formulation": 284_096 - (8 - action_dim) * (3 * 2 * 512 + 64 * 3)}
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  "f16f6" issues f16 MFMAs (2.5 PFLOP/s) for the main product and
 # fp6 block-scaled MFMAs (10 PFLOP/s) for the correction terms; it is priced against the f16 peak, the slower of the two.
 PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "f16f6": 2500.0, "f16": 2500.0}
@@ -109,6 +128,11 @@ def parse():
                     help=f"MFMA precision in the headline slot (default {HEADLINE_PRECISION}: the reference's fp32 arithmetic; the "
                          "package default, hip.DEFAULT_PRECISION, is always measured next to it as value_default_precision)")
     ap.add_argument("--no-other-precisions", action="store_true")
+    ap.add_argument("--decoder", choices=["jacobian_mlp", "jacobian_transformer"], default="jacobian_mlp",
+                    help="Jacobian head of the frame (models/decoder/__init__.py:11-44): the ResnetFC head the headline is quoted on, or "
+                         "the attention head configurations/model/model_allegro.yaml:26 selects")
+    ap.add_argument("--action-dim", type=int, default=ACTION_DIM,
+                    help="A: 8 = Allegro (C2 / C3), 6 = the pneumatic hand of C5 (inference/jacobian_color_map.py:42-49)")
     ap.add_argument("--dry-launch", metavar="STANDINS.py", default=None,
                     help="launcher self-test WITHOUT a GPU (tests/test_host_cpu.py): the same launch / world check / barriers / "
                          "rank evidence / one JSON line, over the gloo backend, with parallel.ShardedFrameStep driven by the "
@@ -316,13 +340,15 @@ def main():
     strong = args.scaling == "strong"
     sim_world = args.simulate_world if (world == 1 and args.simulate_world > 1) else 0
     HH, WW, BB, SS = args.height, args.width, args.batch, args.samples
+    DEC, AD = args.decoder, args.action_dim
+    macj = mac_jacobian(DEC, AD)
     dev = lambda t: t.to(device)
     # ---- synthetic frame: seeded weights / cameras replicated on every rank; the feature map is the same on
     # every rank under strong scaling (one image) and differs per rank under weak scaling (one image each) ---------------
-    params = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", ACTION_DIM, with_encoder=False), seed=0)
+    params = synthetic.seeded_state_dict(synthetic.model_shapes(DEC, AD, with_encoder=False), seed=0)
     cams = synthetic.synthetic_cameras(BB)
     feats_cpu = synthetic.synthetic_features(BB, HH, WW, seed=1 + (0 if strong else rank))
-    action_cpu = synthetic.synthetic_action(BB, ACTION_DIM, seed=2)
+    action_cpu = synthetic.synthetic_action(BB, AD, seed=2)
     ctxt_c2w, ctxt_k, trgt_c2w = dev(cams["ctxt_c2w"]), dev(cams["ctxt_k_norm"]), dev(cams["trgt_c2w"])
     z_near, z_far, action = dev(cams["z_near"]), dev(cams["z_far"]), dev(action_cpu)
     origins, directions, _ = geometry.full_frame_rays(HH, WW, dev(cams["trgt_k_norm"]), trgt_c2w)  # the HIP ray-generation kernel
@@ -339,9 +365,9 @@ def main():
     rgb_loc, flow_loc = trgt_rgb[:, lo:hi].contiguous(), trgt_flow[:, lo:hi].contiguous()
     local_rays = BB * (hi - lo)
 
-    cfg = model_cfg_from_dict({"action_dim": ACTION_DIM, "encoder": {"name": "precomputed"},
+    cfg = model_cfg_from_dict({"action_dim": AD, "encoder": {"name": "precomputed"},
                                "rendering": {"num_proposal_samples": [SS], "num_nerf_samples": SS},
-                               "action_decoder": {"name": "jacobian_mlp"}})
+                               "action_decoder": {"name": DEC}})
     precision = args.precision or HEADLINE_PRECISION
     default_precision = hip.DEFAULT_PRECISION
     wanted = [precision] + ([] if args.no_other_precisions else [p for p in (default_precision, "f16f6", "f16x2", "f32", "f16")])
@@ -466,12 +492,13 @@ def main():
                         "SAME step function (graph replay included when the step was captured)"}
 
     total_rays = local_rays if sim_world else (frame_rays if strong else world * frame_rays)
-    render_flop = 2.0 * local_rays * SS * (MAC_DENSITY + MAC_JACOBIAN + MAC_COLOR)
+    render_flop = 2.0 * local_rays * SS * (MAC_DENSITY + macj["canonical"] + MAC_COLOR)
+    render_flop_reference = 2.0 * local_rays * SS * (370_560 + macj["reference_formulation"] + MAC_COLOR)
 
     def roofline(prec: str, run: dict) -> dict:
         achieved = render_flop / (run["kernel_ms"]["render"] * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        if local_rays == H * W and SS == S_FINAL:
+        if local_rays == H * W and SS == S_FINAL and (DEC, AD) == ("jacobian_mlp", ACTION_DIM):
             for rnd in PROFILE_ROUNDS:
                 pmc = os.path.join(ROOT, "profiles", f"{rnd}_render_kernel_hbm_bytes_{prec}.json")
                 if os.path.exists(pmc):
@@ -480,18 +507,27 @@ def main():
                     traffic_source = (f"NOT measured in this run: read from profiles/{os.path.basename(pmc)} (rocprofv3 --pmc passes "
                                       "of this command on an earlier box, tools/profile_rNN.sh + tools/summarize_profile.py)")
                     break
-        return {"kernel": f"render_kernel<jacobian_mlp, {prec}> (density+colour+Jacobian MLPs + compositing)",
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[prec], 4), "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_flop_per_launch": render_flop, "mfma_issue_factor": ISSUE_FACTOR[prec],
-                "timing": run["timing_note"]}
+        block = {"kernel": f"render_kernel<{DEC}, {prec}> (density ResnetFC + colour head + Jacobian head + compositing)",
+                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                 "frac": round(achieved / PEAK_TFLOPS[prec], 4), "traffic": traffic, "traffic_source": traffic_source,
+                 "algorithmic_flop_per_launch": render_flop, "mfma_issue_factor": ISSUE_FACTOR[prec],
+                 "timing": run["timing_note"]}
+        if DEC == "jacobian_transformer":   # the head is evaluated in a folded form: say so, and score SURVEY's count beside it
+            block["mac_per_point"] = {"density": MAC_DENSITY, "colour": MAC_COLOR, "jacobian_folded": macj["canonical"],
+                                      "jacobian_reference_formulation_SURVEY_8d": macj["reference_formulation"]}
+            ach_ref = render_flop_reference / (run["kernel_ms"]["render"] * 1e-3) / 1e12
+            block["against_reference_formulation"] = {
+                "flop_per_launch": render_flop_reference, "achieved": round(ach_ref, 2), "frac": round(ach_ref / PEAK_TFLOPS[prec], 4),
+                "note": "the same launch duration scored against SURVEY 8d's NON-hoisted counts (density 370,560 + colour 6,272 + "
+                        "transformer 284,096 MAC/pt): work the folded evaluation does not perform -- context, not the roofline fraction"}
+        return block
 
     if rank == 0:
         ms_step = 1e3 * head["elapsed"] / head["steps"]
         value = total_rays * head["steps"] / head["elapsed"]
         mode = "strong" if strong else "weak"
-        workload = ("C2: " if (BB, HH, WW, SS) == (1, 256, 256, 64) else "") + (
-            f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final samples/ray, jacobian_mlp, A=8, "
+        workload = ("C2: " if (BB, HH, WW, SS, DEC, AD) == (1, 256, 256, 64, "jacobian_mlp", ACTION_DIM) else "") + (
+            f"Allegro single-view PixelNeRF, B={BB}, {HH}x{WW} rays, {SS} proposal + {SS} final samples/ray, {DEC}, A={AD}, "
             "eval-mode Model.forward (encoder excluded: 'precomputed' encoder entry returning the synthetic feature map; the "
             "per-image lin_z projection is inside the timed call) + rgb/flow loss")
         if world > 1:
@@ -504,7 +540,7 @@ def main():
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": mode, "vs_baseline": None,
             "dtype": DTYPE_TEXT[precision], "data": "synthetic",
-            "config": {"workload": workload, "precision": precision, "rays_per_gpu": local_rays,
+            "config": {"workload": workload, "precision": precision, "rays_per_gpu": local_rays, "decoder": DEC, "action_dim": AD,
                        "parallelism": f"dp{world} ({'one frame, rays sharded' if strong else 'one frame per rank'}, replicated weights "
                                       "and feature map)"},
             "kernel_ms": {k: round(v, 3) for k, v in head["kernel_ms"].items()},
@@ -555,7 +591,7 @@ def main():
                               "1e-4, in EVERY precision including exact fp32 arithmetic")
         if world == 1 and not sim_world and not args.no_cpu_baseline and (BB, HH, WW, SS) == (1, 256, 256, 64):
             case = {"params": params, "feats": feats_cpu, "cams": cams, "origins": origins.cpu(), "directions": directions.cpu(),
-                    "k_pix": k_pix.cpu(), "action": action_cpu}
+                    "k_pix": k_pix.cpu(), "action": action_cpu, "decoder_kind": DEC}
             stride = max(1, (HH * WW) // args.cpu_sample_rays)
             ray_index = torch.arange(0, HH * WW, stride)[: args.cpu_sample_rays]
             out["cpu_baseline"], ref, ref64, sub_case = cpu_baseline(case, ray_index, args.cpu_passes)

@@ -1270,6 +1270,48 @@ __device__ __forceinline__ void color_tile(ST& st, const float* __restrict__ bia
 // Weight stream: 14 half-chunks of 4096 floats [query | (Mqk, Nov, W1', W2) x 3 | head] = 7 chunks.
 // bias (LDS): [bqk | bo | b1' | b2] (64 each) x 3 | head (32).
 // ------------------------------------------------------------------------------------------
+// erf(a) without a branch: both polynomial pieces of the classic single-precision evaluation (split at |a| = 0.927734375:
+// a * P(a^2) below, 1 - exp(Q(|a|)) above; each piece is within 1 ulp of erf) are computed and one is selected.  The device
+// library's erff branches per element; in a tile whose 32 lanes x 32 values straddle the split both sides of all 32 branches run
+// (~50 VALU instructions + the exec-mask bookkeeping per value: ~1,600 per layer -- the largest item of the head's instruction
+// stream, profiles/r06_transformer_valu_budget.txt).  The exponential is the hardware's v_exp_f32 on the argument scaled by log2(e):
+// the argument is in [-17, -0.8], so the scaling's rounding costs <= 1e-6 relative on a term that is <= 0.19 of the result.
+__device__ __forceinline__ float erf_branchless(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float hi = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.4426950408889634f), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float lo = fmaf(q, a, a);
+  return t > 0.927734375f ? hi : lo;
+}
+
+// The same function to 5.2e-7 ABSOLUTE (Abramowitz & Stegun 7.1.26 evaluated in fp32: 1.5e-7 of the formula + the cancellation of 1 - p e near 0) in 16
+// instead of 29 VALU instructions: one v_rcp_f32, five fmas, one v_exp_f32.  GELU reads 1 + erf, so an absolute bound is a relative
+// bound on its result; used by the precisions whose own product error is above it (f16x2: 4e-7 per network, f16f6: 1.5e-5, f16:
+// 5e-4), never by the exact-fp32 mode.
+__device__ __forceinline__ float erf_as7126(float a) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(a), 1.0f));
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f((a * a) * -1.4426950408889634f);
+  return copysignf(fmaf(-p, e, 1.0f), a);
+}
+
 __device__ __forceinline__ void norm64(const f32x16 (&x)[2], f32x16 (&n)[2]) {
   float s = 0.f;
 #pragma unroll
@@ -1287,11 +1329,13 @@ __device__ __forceinline__ void norm64(const f32x16 (&x)[2], f32x16 (&n)[2]) {
       v = fmaf(d, d, v);
     }
   v += __shfl_xor(v, 32, 64);
-  const float rstd = 1.0f / sqrtf(v / 64.0f + 1e-5f);
+  // v_rsq_f32 (1 ulp) instead of an IEEE square root and an IEEE division (~25 VALU instructions, six times per tile)
+  const float rstd = __builtin_amdgcn_rsqf(v / 64.0f + 1e-5f);
+  const float shift = -mean * rstd;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) n[m][r] = (x[m][r] - mean) * rstd;
+    for (int r = 0; r < 16; ++r) n[m][r] = fmaf(x[m][r], rstd, shift);   // (x - mean) * rstd as one fma
 }
 
 template <int PREC, class ST>
@@ -1318,14 +1362,18 @@ __device__ __forceinline__ void transformer_tile(ST& st, const float* __restrict
 #pragma unroll
         for (int a = 0; a < 8; ++a)
           if (a < keys) mx = fmaxf(mx, t[m][8 * h8 + a]);
+        // exp(d) = v_exp_f32(d * log2 e), d <= 0 (1 ulp of the hardware + |d| * 6e-8 relative from the scaling, on terms that are
+        // e^d of the row's largest); one v_rcp_f32 (1 ulp) and eight multiplications instead of eight IEEE divisions: the 32
+        // softmax rows of a tile were ~630 VALU instructions per layer, ~190 now
         float e[8], sum = 0.f;
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-          e[a] = (a < keys) ? expf(t[m][8 * h8 + a] - mx) : 0.f;
+          e[a] = (a < keys) ? __builtin_amdgcn_exp2f((t[m][8 * h8 + a] - mx) * 1.4426950408889634f) : 0.f;
           sum += e[a];
         }
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) t[m][8 * h8 + a] = e[a] / sum;
+        for (int a = 0; a < 8; ++a) t[m][8 * h8 + a] = e[a] * inv;
       }
     }
     wl = stream_step(st, wave, lane);
@@ -1339,7 +1387,9 @@ __device__ __forceinline__ void transformer_tile(ST& st, const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = t[m][r];
-        t[m][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (nn.GELU default)
+        const float z = v * 0.70710678118654752440f;
+        const float ef = PREC == PREC_F32 ? erf_branchless(z) : erf_as7126(z);
+        t[m][r] = 0.5f * v * (1.0f + ef);  // exact GELU (nn.GELU default)
       }
     wl = stream_step(st, wave, lane);
     bias_init<2, false, PREC>(bl + 192, hh, x);

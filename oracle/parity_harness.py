@@ -198,8 +198,8 @@ def oracle_forward(case, s_prop, s_final, anneal: float = 1.0):
     return orc.model_forward(case["params"], features=case["feats"], ctxt_c2w=c["ctxt_c2w"], ctxt_k_norm=c["ctxt_k_norm"],
                              trgt_c2w=c["trgt_c2w"], trgt_k_pix=case["k_pix"], origins=case["origins"],
                              directions=case["directions"], z_near=c["z_near"], z_far=c["z_far"], action=case["action"],
-                             num_proposal_samples=[s_prop], num_nerf_samples=s_final, decoder_kind="jacobian_mlp",
-                             anneal=anneal)
+                             num_proposal_samples=[s_prop], num_nerf_samples=s_final,
+                             decoder_kind=case.get("decoder_kind", "jacobian_mlp"), anneal=anneal)
 
 
 def _to64(x):
