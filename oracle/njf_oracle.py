@@ -76,11 +76,15 @@ def _r16(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.to(torch.float16).to(t.dtype)
 
 
-def _affine(params: Params, name: str, x: Tensor) -> Tensor:
+def _affine(params: Params, name: str, x: Tensor, extra_bias: Optional[Tensor] = None, drop_bias: bool = False) -> Tensor:
+    """``extra_bias`` / ``drop_bias``: operand-rounding model only -- a bias the build folds into ANOTHER layer's stored values
+    (resnet_fc below) is added there before that layer's rounding and left out where the reference adds it."""
     w, b = params[name + ".weight"], params.get(name + ".bias")
+    if drop_bias:
+        b = None
     if _OPERAND_ROUNDING == "f16":
         if name.startswith("lin_z."):
-            return _r16(F.linear(x, w, b))
+            return _r16(F.linear(x, w, b if extra_bias is None else b + extra_bias))
         if name == "lin_in" or name == "color_head.0":
             b = _r16(b)
         return F.linear(_r16(x), _r16(w), b)
@@ -383,11 +387,15 @@ def sh4_encoding(dirs01: Tensor) -> Tensor:
 def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_layer: int = 3) -> Tensor:
     """NJF/model_components/resnet_fc.py:130-154 (ResnetFC.forward) with ResnetBlockFC (:69-79), ReLU (beta=0)."""
     h = _affine(params, "lin_in", x)
+    # operand-rounding model: the build folds fc_1's bias of blocks 0 and 1 into the hoisted map of the NEXT block's latent
+    # (bilerp(G + b) = bilerp(G) + b), so it is part of what the map's fp16 rounding sees (csrc: njf_pack_resnetfc / njf_pack_linz)
+    fold = _OPERAND_ROUNDING == "f16"
     for i in range(n_blocks):
         if i < combine_layer:
-            h = h + _affine(params, f"lin_z.{i}", z)
+            carried = params[f"blocks.{i - 1}.fc_1.bias"] if (fold and i >= 1) else None
+            h = h + _affine(params, f"lin_z.{i}", z, extra_bias=carried)
         net = _affine(params, f"blocks.{i}.fc_0", torch.relu(h))
-        dx = _affine(params, f"blocks.{i}.fc_1", torch.relu(net))
+        dx = _affine(params, f"blocks.{i}.fc_1", torch.relu(net), drop_bias=fold and i + 1 < combine_layer)
         h = h + dx
     return _affine(params, "lin_out", torch.relu(h))
 

@@ -122,15 +122,37 @@ TRUTH_MIN_ELEMENTS = 1024   # below this a tensor's maximum is one or two ill-co
 #       rms e_hip <= max(1.5 x rms e_ref, 5e-6)   and   max e_hip <= max(2 x max e_ref, 5e-5)
 #   i.e. a compensated mode may exceed the reference's own fp32 noise only while its total error stays below 5 % (rms) / 50 %
 #   (max) of north_star's 1e-4.  On every forward tensor of >= TRUTH_MIN_ELEMENTS elements of every parity case.
-# reduced modes ("f16"): not asserted through truth columns (their rows are bounded by the operand-rounding model, below).
+# reduced modes ("f16"; round 6, VERDICT r05 "next" #2a): e_ref of their truth rows is the error of the OPERAND-ROUNDING MODEL (the
+#   CPU oracle evaluated with plain-fp16 operands) against float64, so a ratio of 1 means "as accurate as plain fp16 arithmetic can
+#   be" and a kernel that lost a bit of precision somewhere shows up as a ratio of 2.  Asserted on every tensor of >= TRUTH_MIN_ELEMENTS
+#   elements (the norm-wise rows with their factors 2 / 4 stay, they are what small tensors have):
+#       per-network / per-sample tensors (s_*, prop_weights, final_bins; and the PIXELS when the proposal pass is not reduced, i.e.
+#       sample placement is fp32-class):      rms e_hip <= 1.5 x rms e_model   and   max e_hip <= 2 x max e_model
+#       end-to-end pixels with a plain-fp16 proposal pass (rgb / depth / optical_flow: dominated by where the inverse CDF PLACES a
+#       few rays' samples, a heavy-tailed draw on both sides -- recorded rms ratios 0.84 ... 2.1, max ratios up to 3.7 at 6,144
+#       elements):                            median e_hip <= 1.5 x median e_model  (the bulk: this is what a lost bit doubles),
+#                                             rms e_hip <= 2.5 x rms e_model,  max e_hip <= 4 x max e_model
 ACCEL_RMS_FACTOR, ACCEL_RMS_ABS, ACCEL_MAX_FACTOR, ACCEL_MAX_ABS = 1.5, 5e-6, 2.0, 5e-5
+REDUCED_RMS_FACTOR, REDUCED_MAX_FACTOR = 1.5, 2.0
+REDUCED_E2E_P50_FACTOR, REDUCED_E2E_RMS_FACTOR, REDUCED_E2E_MAX_FACTOR = 1.5, 2.5, 4.0
+E2E_PIXEL_KEYS = ("rgb", "depth", "optical_flow")
 
 
-def truth_asserted(cols: Dict, precision: Optional[str]) -> Optional[bool]:
+def truth_asserted(cols: Dict, precision: Optional[str], placement_reduced: bool = True) -> Optional[bool]:
     """The asserted criterion of ``precision`` on one truth row: True / False, or None where nothing is asserted (tensors of
-    fewer than TRUTH_MIN_ELEMENTS elements, reduced-precision modes)."""
-    if cols.get("elements", 0) < TRUTH_MIN_ELEMENTS or precision in REDUCED_PRECISIONS:
+    fewer than TRUTH_MIN_ELEMENTS elements).  ``placement_reduced``: reduced modes only -- the proposal pass runs in the reduced
+    arithmetic too (False for set_precision("f16", proposal_precision="f16x2"))."""
+    if cols.get("elements", 0) < TRUTH_MIN_ELEMENTS:
         return None
+    if precision in REDUCED_PRECISIONS:
+        ulp = TRUTH_ULPS * 2.0 ** -24
+        key = str(cols.get("key", "")).replace("truth:", "")
+        if key in E2E_PIXEL_KEYS and placement_reduced:
+            return bool(cols["e_hip_p50"] <= max(REDUCED_E2E_P50_FACTOR * cols["e_ref_p50"], ulp)
+                        and cols["e_hip_rms"] <= max(REDUCED_E2E_RMS_FACTOR * cols["e_ref_rms"], ulp)
+                        and cols["e_hip_max"] <= max(REDUCED_E2E_MAX_FACTOR * cols["e_ref_max"], ulp))
+        return bool(cols["e_hip_rms"] <= max(REDUCED_RMS_FACTOR * cols["e_ref_rms"], ulp)
+                    and cols["e_hip_max"] <= max(REDUCED_MAX_FACTOR * cols["e_ref_max"], ulp))
     if precision == "f32":
         return bool(cols["truth_ok"])
     return bool(cols["e_hip_rms"] <= max(ACCEL_RMS_FACTOR * cols["e_ref_rms"], ACCEL_RMS_ABS)
@@ -151,6 +173,7 @@ def truth_columns(hip: torch.Tensor, ref32: torch.Tensor, ref64: torch.Tensor, t
     rms = lambda e: float(e.pow(2).mean().sqrt())
     ulp_floor = TRUTH_ULPS * 2.0 ** -24
     hm, rm, hp, rp, hr, rr = float(e_hip.max()), float(e_ref.max()), p(e_hip), p(e_ref), rms(e_hip), rms(e_ref)
+    h50, r50 = float(e_hip.median()), float(e_ref.median())   # the BULK of the error (round 6: what the reduced mode's pixels are held to)
     within = lambda f: bool(hm <= max(f * rm, ulp_floor) and hp <= max(f * rp, ulp_floor))
     strict = within(TRUTH_FACTOR)
     tail = bool(not strict and within(TRUTH_TAIL_FACTOR) and hr <= max(TRUTH_FACTOR * rr, ulp_floor))
@@ -158,7 +181,8 @@ def truth_columns(hip: torch.Tensor, ref32: torch.Tensor, ref64: torch.Tensor, t
     sig = lambda v: float(f"{v:.3e}")
     return {"e_hip_max": sig(hm), "e_ref_max": sig(rm), "e_hip_p999": sig(hp), "e_ref_p999": sig(rp), "e_hip_rms": sig(hr),
             "e_ref_rms": sig(rr), "ratio_max": sig(hm / max(rm, 1e-300)), "ratio_p999": sig(hp / max(rp, 1e-300)),
-            "ratio_rms": sig(hr / max(rr, 1e-300)), "frac_within_1e-4_of_ref32": sig(frac), "elements": int(h.numel()),
+            "ratio_rms": sig(hr / max(rr, 1e-300)), "e_hip_p50": sig(h50), "e_ref_p50": sig(r50), "ratio_p50": sig(h50 / max(r50, 1e-300)),
+            "frac_within_1e-4_of_ref32": sig(frac), "elements": int(h.numel()),
             "truth_ok_strict": strict, "tail_outlier": tail, "truth_ok": bool(strict or tail),
             "on_ulp_floor": bool(strict and (hm > TRUTH_FACTOR * rm or hp > TRUTH_FACTOR * rp))}
 
@@ -238,6 +262,7 @@ def oracle_forward_fp64(case, s_prop, s_final, anneal: float = 1.0):
 # every mode, with e_ref = the MODEL's error: ratio ~1 means "as accurate as plain fp16 arithmetic can be".
 REDUCED_TOL = 2e-3
 REDUCED_FACTOR, REDUCED_FACTOR_SMALL = 2.0, 4.0
+REDUCED_E2E_SMALL_ABS = 3e-2   # end-to-end depth / flow of the all-fp16 mode on C2 / C3 / C5 at full size: 7e-3 ... 2.5e-2
 
 
 def oracle_forward_f16model(case, s_prop, s_final, anneal: float = 1.0):
@@ -419,6 +444,11 @@ def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32
     truth_ok = all(r["truth_ok"] for r in truth_rows)
 
     reduced = precision in REDUCED_PRECISIONS
+    # set_precision("f16", proposal_precision="f16x2"): only the FINAL pass is reduced; sample placement is fp32-class, so the
+    # yardstick of the end-to-end pixels is the model's final stage at the fp32 oracle's sample locations (`ms` below, the one the
+    # s_* rows use) and the proposal-stage rows are held to the fp32 rule
+    mixed = reduced and proposal_precision is not None and proposal_precision not in REDUCED_PRECISIONS
+    PLACEMENT_KEYS = ("prop_weights", "final_bins", "ref_final_bins")
     model = {}
     if reduced:
         mkey = None if key is None else ("f16model",) + key
@@ -440,11 +470,15 @@ def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32
                  "s_action_features": rel_err(ms.action_features, ref.action_features),
                  "s_pos": rel_err(ms.ray_positions, ref.ray_positions),
                  "s_pos_warped": rel_err(ms.ray_positions_warped, ref.ray_positions_warped)}
+        if mixed:
+            model.update(rgb=model["s_rgb"], depth=model["s_depth"], optical_flow=model["s_optical_flow"])
         for k in ("rgb", "depth", "optical_flow", "final_bins"):
             model["ref_" + k] = model[k]
         # truth columns of a reduced mode: e_ref = the MODEL's error against float64 (not the fp32 reference's)
-        mt = {"rgb": me.rgb, "depth": me.depth, "optical_flow": me.optical_flow, "final_bins": me_bins,
-              "prop_weights": me.weights_list[0], "s_rgb": ms.rgb, "s_depth": ms.depth, "s_optical_flow": ms.optical_flow,
+        e2e_model = ms if mixed else me
+        mt = {"rgb": e2e_model.rgb, "depth": e2e_model.depth, "optical_flow": e2e_model.optical_flow,
+              "final_bins": ref_bins if mixed else me_bins, "prop_weights": ref.weights_list[0] if mixed else me.weights_list[0],
+              "s_rgb": ms.rgb, "s_depth": ms.depth, "s_optical_flow": ms.optical_flow,
               "s_weights": ms.weights_list[0], "s_density": ms.density, "s_color": ms.color, "s_sample_flow": ms.flow,
               "s_jacobian": ms.jacobian, "s_action_features": ms.action_features, "s_pos": ms.ray_positions,
               "s_pos_warped": ms.ray_positions_warped}
@@ -458,14 +492,21 @@ def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32
     rows = []
     for k, v in errs.items():
         f64 = floor.get(k, 0.0)
-        if reduced:
+        if reduced and not (mixed and k in PLACEMENT_KEYS):
             mk = model.get(k, 0.0)
             base_key = k[4:] if k.startswith("ref_") else k
             n_el = truth_in[base_key][1].numel() if base_key in truth_in else 0
             # end-to-end pixels depend on where the inverse CDF PLACES samples: their error is placement noise through the
-            # positional encoding's gain, an extreme value of a few rays at any frame size (REDUCED_FACTOR_SMALL, see above)
-            e2e = base_key in ("rgb", "depth", "optical_flow")
+            # positional encoding's gain, an extreme value of a few rays at any frame size (REDUCED_FACTOR_SMALL, see above) --
+            # unless the proposal pass is not reduced (`mixed`): then they are per-network quantities like the s_* rows
+            e2e = base_key in E2E_PIXEL_KEYS and not mixed
             limit = max(REDUCED_TOL, (REDUCED_FACTOR if (n_el >= TRUTH_MIN_ELEMENTS and not e2e) else REDUCED_FACTOR_SMALL) * mk)
+            if e2e and n_el < TRUTH_MIN_ELEMENTS:
+                # a handful of rays (the ragged-shape cases: 1 ... 37 rays): the model's own draw of placement noise can be 5 x
+                # below or above the kernel's by chance (measured: depth 1.2e-2 against a model draw of 2.3e-3 on 5 rays, against
+                # 9e-3 with another rounding order of the model), so these rows are held to the level the all-fp16 mode shows on
+                # the FULL-SIZE frames, where the element-wise criterion does the judging
+                limit = max(limit, REDUCED_E2E_SMALL_ABS)
             good = math.isfinite(v) and v <= limit
             ok = ok and good
             rows.append({"key": k, "err": float(f"{v:.3e}"), "floor": float(f"{mk:.3e}"), "floor_fp64": float(f"{f64:.3e}"),
@@ -488,12 +529,15 @@ def run_parity_case(batch=1, height=16, width=16, rays=96, s_prop=32, s_final=32
     from neural_jacobian_field_amd import hip as _hip
     mode = _hip.DEFAULT_PRECISION if precision is None else precision
     for r in truth_rows:
-        r["asserted_ok"] = truth_asserted(r, mode)
+        placement_row = mixed and r["key"].replace("truth:", "") in PLACEMENT_KEYS
+        r["asserted_ok"] = truth_asserted(r, proposal_precision if placement_row else mode, placement_reduced=not mixed)
     asserted_failed = [r["key"] for r in truth_rows if r["asserted_ok"] is False]
     return {"truth_asserted_ok": not asserted_failed, "truth_asserted_failed": asserted_failed,
-            "truth_asserted_rows": sum(r["asserted_ok"] is not None for r in truth_rows), "precision": mode,
+            "truth_asserted_rows": sum(r["asserted_ok"] is not None for r in truth_rows), "precision": mode if not mixed else f"{mode}+{proposal_precision}",
             "ok": bool(ok), "tol": REDUCED_TOL if reduced else tol, "worst": worst, "model_floor": {k: float(f"{v:.3e}") for k, v in model.items()}, "errors": {k: float(f"{v:.3e}") for k, v in errs.items()},
             "fp32_noise_floor": {k: float(f"{v:.3e}") for k, v in floor.items()}, "floor_source": floor_source, "rows": rows,
             "truth_ok": bool(truth_ok), "truth_rows": truth_rows,
             # (the fp32-noise-ratio criterion, RECORDED for every mode; what is asserted of a mode is truth_asserted_*)
-            "truth_ratio_criterion_not_met": [r["key"] for r in truth_rows if not r["truth_ok"]]}
+            "truth_ratio_criterion_not_met": [r["key"] for r in truth_rows if not r["truth_ok"]],
+            # (alias of the line above under its round-4 name, kept for consumers of that key)
+            "truth_failed": [r["key"] for r in truth_rows if not r["truth_ok"]]}

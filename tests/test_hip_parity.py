@@ -69,9 +69,35 @@ def test_plain_f16_mode_within_stated_tolerance(device, case_id, margins):
     name = ph.FULL_SIZE_CASES.get(case_id)
     tag = f"{name}[f16]" if name else f"parity[{case_id}:f16]"
     margins.record(tag, rep["rows"])
-    margins.record_truth(tag, rep["truth_rows"], asserted=False)
+    margins.record_truth(tag, rep["truth_rows"], asserted=True)
     assert rep["tol"] == ph.REDUCED_TOL
     assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
+    # round 6 (VERDICT r05 "next" #2a): the element-wise criterion against the operand-rounding model -- what a lost bit of
+    # precision would break (oracle/parity_harness.py::truth_asserted, reduced modes): rms <= 1.5 x / max <= 2 x the model's error on
+    # per-network and per-sample tensors; median <= 1.5 x, rms <= 2.5 x, max <= 4 x on the placement-dominated pixels
+    assert rep["truth_asserted_ok"], [r for r in rep["truth_rows"] if r["asserted_ok"] is False]
+
+
+@pytest.mark.parametrize("case_id", sorted(_ph.FULL_SIZE_CASES))
+def test_f16_shading_with_compensated_placement_at_full_size(device, case_id, margins):
+    """``set_precision("f16", proposal_precision="f16x2")`` on BASELINE's full-size frames (C2, C3, C5), against the oracle AND the
+    reference's fixture outputs (VERDICT r05 "next" #2b): the proposal pass keeps fp32-class sample PLACEMENT, only the final pass
+    runs in plain fp16.  The end-to-end pixels are then per-network quantities: held to the operand-rounding model of the FINAL STAGE
+    at the fp32 run's sample locations with the tight factors (norm-wise max(2e-3, 2 x model); element-wise rms <= 1.5 x, max <= 2 x),
+    the proposal-stage rows (prop_weights, final_bins) to the fp32 rule, and in absolute terms rgb / depth to 4e-3 and the flow to
+    1e-2 of their scales (the all-fp16 mode: 7e-3 ... 3e-2 on depth / flow)."""
+    import parity_harness as ph
+    cfg = ph.PARITY_CASES[case_id]
+    rep = ph.run_parity_case(device=device, tol=TOL, precision="f16", proposal_precision="f16x2", case_id=case_id, **cfg)
+    tag = f"{ph.FULL_SIZE_CASES[case_id]}[f16+f16x2prop]"
+    margins.record(tag, rep["rows"])
+    margins.record_truth(tag, rep["truth_rows"], asserted=True)
+    assert rep["precision"] == "f16+f16x2"
+    assert rep["ok"], {k: v for k, v in rep.items() if k not in ("rows", "truth_rows")}
+    assert rep["truth_asserted_ok"], [r for r in rep["truth_rows"] if r["asserted_ok"] is False]
+    e = rep["errors"]
+    assert e["rgb"] <= 4e-3 and e["depth"] <= 4e-3 and e["optical_flow"] <= 1e-2, e
+    assert e["ref_rgb"] <= 4e-3 and e["ref_depth"] <= 4e-3 and e["ref_optical_flow"] <= 1e-2, e
 
 
 def test_plain_f16_mode_is_refused_where_it_does_not_exist(device):

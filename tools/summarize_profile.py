@@ -30,7 +30,9 @@ shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
 PCODE = {"f32": 0, "f16x2": 1, "f16f6": 2, "f16": 3}[prec]    # template argument of this precision's instantiations
 PROP = 1 if prec == "f16f6" else PCODE              # under f16f6 the proposal networks stay on f16x2 (Model.set_precision)
-KERNELS = {f"render_kernel<1, {PCODE}": "render", f"proposal_kernel<{PROP},": "proposal",
+JKIND = 2 if "jacobian_transformer" in bench_args else 1   # round 6: `--decoder jacobian_transformer` profiles (folded attention head)
+HEAD = "jacobian_transformer" if JKIND == 2 else "jacobian_mlp"
+KERNELS = {f"render_kernel<{JKIND}, {PCODE}": "render", f"proposal_kernel<{PROP},": "proposal",
            ("project_kernel_f32_lds(" if prec == "f32" else "project_kernel_f16x2<"): "project"}   # (rounds 1-4: "project_kernel(")
 agg = collections.defaultdict(list)
 meta = {}
@@ -91,7 +93,7 @@ for k in ("proposal", "render"):
                   f"over 256 CUs = {100 * ta / 256 / xcd_cycles:.0f} % of the kernel's cycles per CU"
                   + (f"; TA_BUSY_avr {mean[(k, 'TA_BUSY_avr')]:.3g}, TA_BUSY_max {mean[(k, 'TA_BUSY_max')]:.3g}" if (k, "TA_BUSY_avr") in mean else ""), ""]
     if k == "render":
-        out_json = {"kernel": f"render_kernel<jacobian_mlp, {prec}>", "hbm_bytes_per_launch": hbm, "fetch_size_bytes_raw": fetch,
+        out_json = {"kernel": f"render_kernel<{HEAD}, {prec}>", "hbm_bytes_per_launch": hbm, "fetch_size_bytes_raw": fetch,
                     "write_size_bytes": write, "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), rocprofv3 --pmc, "
                     "separate passes; counts L2 memory-side requests incl. Infinity-Cache hits and scratch traffic",
                     "avg_duration_s": dur[k], "mfma_util": mfma_util_insts, "mfma_util_counter_ratio": mfma_util}
