@@ -498,7 +498,7 @@ def main():
             full = prec == default_precision
             runs[prec] = measure(prec, args.steps if full else max(2, args.steps // 4), args.warmup if full else 1)
     head = runs[precision]
-    evidence = launch.rank_evidence(dist, device, head["local_ms"], graph=head["graphed"])
+    evidence = launch.rank_evidence(dist, device, head["local_ms"], graph=head["graphed"], kernel_ms=head["kernel_ms"])
     # One more UNTIMED step of the headline mode on every rank: the digest of what it produced (assembled frame + the six clip /
     # loss scalars).  The kernels are bit-reproducible, so a one-rank run WITH the collective (--force-dist, eager or --graph)
     # must print the digest of the plain run (tests/test_rccl_gpu.py).

@@ -242,6 +242,19 @@ def map_dtype(precision: Optional[str]) -> torch.dtype:
     return torch.float16 if (DEFAULT_PRECISION if precision is None else precision) == "f16" else torch.float32
 
 
+def _check_map_dtype(fmap, *precisions: Optional[str]) -> None:
+    """The forward kernels read the hoisted map with the element type of their MFMA precision (fp16 maps for "f16", fp32 maps
+    otherwise) and the C side cannot tell what an allocation holds: a half map read as fp32 is an out-of-bounds read of twice the
+    allocation, an fp32 map read as halves is silent garbage.  Checked here, where the tensor is still known."""
+    keep = getattr(fmap, "_keep", None)
+    if keep is None:
+        return
+    for p in precisions:
+        if keep.dtype != map_dtype(p):
+            raise ValueError(f"njf_hip: the hoisted map is {keep.dtype} but a network of precision "
+                             f"{DEFAULT_PRECISION if p is None else p!r} reads {map_dtype(p)} maps (project it with that precision)")
+
+
 def _ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype: torch.dtype = torch.float32) -> Optional[int]:
     if t is None:
         return None
@@ -493,6 +506,7 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
                                           _ptr(dump["foot_w"])))
     _note_device(cams, "cameras")
     _note_device(fmap, "feature map")
+    _check_map_dtype(fmap, precision)
     _launch("njf_proposal_forward", load_library().njf_proposal_forward, 
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), gmap_offset,
         _ptr(w_pack), _ptr(b_pack), _ptr(bins_in), int(bins_in.dim() > 1), s_in, _ptr(u), int(u.dim() > 1), s_out,
@@ -519,6 +533,7 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     w_j = w_c + 4 * COLOR_W_FLOATS if with_j else None
     _note_device(cams, "cameras")
     _note_device(fmap, "feature map")
+    _check_map_dtype(fmap, precision, precision if jacobian_precision is None else jacobian_precision)
     _launch("njf_render_forward", load_library().njf_render_forward, 
         _ptr(origins), _ptr(directions), rays_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian,
         jacobian_kind, base, _ptr(b_density), w_c, _ptr(b_color), w_j, _ptr(b_jacobian) if with_j else None,
@@ -536,6 +551,7 @@ def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int
     w_j = (w_c + 4 * COLOR_W_FLOATS) if with_j else None
     _note_device(cams, "cameras")
     _note_device(fmap, "feature map")
+    _check_map_dtype(fmap, precision, precision if jacobian_precision is None else jacobian_precision)
     _launch("njf_points_forward", load_library().njf_points_forward, 
         _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
         jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,

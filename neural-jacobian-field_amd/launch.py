@@ -61,9 +61,13 @@ def ensure_world(gpus: int, script: str, argv: Sequence[str], need_devices: bool
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def init_process_group(backend: str, device: Optional[torch.device] = None):
+def init_process_group(backend: str, device: Optional[torch.device] = None, reserve: bool = False):
     """torch.distributed for this rank (``nccl`` IS RCCL on ROCm).  A plain single process (``--force-dist``) becomes a world
-    of one on 127.0.0.1.  Returns the ``torch.distributed`` module."""
+    of one on 127.0.0.1.  Returns the ``torch.distributed`` module.
+
+    ``reserve``: RCCL prints its version banner on stdout when the first communicator is created (lazily, at the first
+    collective).  A caller whose stdout is a protocol (the benches' ONE JSON line) calls ``reserve_stdout()`` itself before this
+    function, or passes ``reserve=True``; by default this library helper leaves the process's descriptors alone."""
     import torch.distributed as dist
 
     kw = {}
@@ -72,7 +76,8 @@ def init_process_group(backend: str, device: Optional[torch.device] = None):
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         kw = dict(store=dist.TCPStore("127.0.0.1", 0, 1, is_master=True), rank=0, world_size=1)
     if backend == "nccl":
-        reserve_stdout()   # RCCL prints its version banner on stdout when the first communicator is created
+        if reserve:
+            reserve_stdout()
         dist.init_process_group("nccl", device_id=device, **kw)
     else:
         dist.init_process_group(backend, **kw)
@@ -93,7 +98,7 @@ def _device_record(device: torch.device) -> Dict:
     return rec
 
 
-def rank_evidence(dist, device: torch.device, local_step_ms: float, graph: bool = False) -> Dict:
+def rank_evidence(dist, device: torch.device, local_step_ms: float, graph: bool = False, kernel_ms: Optional[Dict] = None) -> Dict:
     """What every rank contributes to the line rank 0 prints -- gathered THROUGH the process group, so the list can only be
     as long as the world that really exchanged data: device identity per rank (PCI bus id, uuid), its own step time
     (clock stopped after its own device synchronisation, before the closing barrier), backend and library version.
@@ -102,6 +107,8 @@ def rank_evidence(dist, device: torch.device, local_step_ms: float, graph: bool 
     otherwise produce a well-formed "N-GPU" line measured on fewer GPUs)."""
     rec = _device_record(device)
     rec["step_ms"] = round(float(local_step_ms), 4)
+    if kernel_ms is not None:   # this rank's own per-launch kernel durations (HIP events): compute vs collective, from the line alone
+        rec["kernel_ms"] = {k: round(float(v), 4) for k, v in kernel_ms.items()}
     if dist is None:
         recs, backend, world = [rec], None, 1
     else:
@@ -123,6 +130,11 @@ def rank_evidence(dist, device: torch.device, local_step_ms: float, graph: bool 
     out = {"backend": backend, "world_size": world, "graph": bool(graph), "devices": recs,
            "self_launched": os.environ.get(LAUNCH_MARK) == "1",
            "rank_step_ms": {"min": min(steps), "max": max(steps), "per_rank": steps}}
+    if all("kernel_ms" in r for r in recs):
+        # per rank: the sum of its kernels' durations next to its step time; step - kernels = launch gaps + the ONE collective + assemble
+        ksum = [round(sum(r["kernel_ms"].values()), 4) for r in recs]
+        out["rank_kernel_ms"] = {"per_rank": [r["kernel_ms"] for r in recs], "sum_per_rank": ksum,
+                                 "step_minus_kernels_ms": [round(s - k, 4) for s, k in zip(steps, ksum)]}
     if backend == "nccl":
         try:
             out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

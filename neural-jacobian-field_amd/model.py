@@ -620,9 +620,16 @@ class Model(nn.Module):
         which lets those be built with or without the 16 action-feature accumulators (-DNJF_TRAIN_NO_AF; the A/B of round 5,
         profiles/r05_spills_ab.txt, kept the accumulators: the leaner build was not faster) -- and the visualisation pays for
         itself on the steps that ask for it (the reference's validation / logging steps)."""
-        with torch.no_grad():
-            vis, *_ = self._fused_render(camera_input, rendering_input, robot_input, features, want_lists=False, want_vis=True,
-                                         want_samples=False, final_bins=bins)
+        # ... and a SEPARATE no-grad render: `weights` / positions of a training step's vis_output come from this pass, not from the
+        # differentiated one (same samples, same weights).  It must not see a caller's frame_io (parallel.ShardedFrameStep): that
+        # would overwrite caller-owned pixel buffers and skip the depth clip (ADVICE r05)
+        prev_io, self.frame_io = self.frame_io, None
+        try:
+            with torch.no_grad():
+                vis, *_ = self._fused_render(camera_input, rendering_input, robot_input, features, want_lists=False, want_vis=True,
+                                             want_samples=False, final_bins=bins)
+        finally:
+            self.frame_io = prev_io
         return ModelVisOutput(action_features=vis["action_features"], steps=((smp.starts + smp.ends) / 2).squeeze(-1),
                               weights=vis["weights"], ray_positions=vis["pos"], ray_positions_warped=vis["pos_warped"])
 

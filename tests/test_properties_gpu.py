@@ -708,3 +708,70 @@ def test_invert_4x4_vs_lapack(dev):
         assert err < 2e-7 * max(cond, 1.0), (name, err, cond)
     eye = torch.eye(4, device=dev).repeat(3, 2, 1, 1)
     assert torch.equal(hip.inverse(eye), eye) and hip.inverse(eye).shape == eye.shape
+
+
+@pytest.mark.parametrize("precision", ["f32", None])
+@pytest.mark.parametrize("world", [8, 7])
+def test_c2_frame_from_its_ray_shards_digest(dev, world, precision):
+    """SURVEY 8(e) at BASELINE's size (VERDICT r05 "next" #7a): the C2 frame (256 x 256 rays, 64 + 64 samples) rendered as the
+    `world` ray shards of `bench.py --gpus world` -- one after the other on this GPU, each through parallel.ShardedFrameStep exactly
+    as a rank would run it (`--simulate-world`: no exchange), eager AND as a replayed HIP graph; 7 ranks = the ragged split
+    (65,536 = 2 x 9,363 + 5 x 9,362) -- then assembled from the per-rank packets.  The SHA-256 of the assembled frame [B,R,6] (rgb | clipped depth
+    | flow) equals the one-rank step's, in the exact-fp32 headline precision and in the package default: sharding changes nothing but
+    where a ray is computed (the loss scalars agree to the rounding of their sums' order)."""
+    import hashlib
+    from neural_jacobian_field_amd import hip, parallel, synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    B, H, W, S, A = 1, 256, 256, 64, 8
+    case = synthetic.synthetic_case(B, H, W, None, A, seed=0, device=dev)
+    c = case["cams"]
+    cfg = model_cfg_from_dict({"action_dim": A, "encoder": {"name": "precomputed"},
+                               "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                               "action_decoder": {"name": "jacobian_mlp"}})
+    model = Model(cfg).to(dev).eval().requires_grad_(False)
+    model.load_state_dict({k: v.to(dev) for k, v in case["params"].items()}, strict=True)
+    model.set_precision(precision or hip.DEFAULT_PRECISION)
+    model.encoder.set_features(case["feats"])
+    cam = CameraInput(None, c["ctxt_c2w"], c["ctxt_k_norm"], c["trgt_c2w"], case["k_pix"])
+    rob = RobotInput(case["action"])
+    o, dr = case["origins"], case["directions"]
+    R = o.shape[1]
+    g = torch.Generator().manual_seed(100)
+    trgt_rgb, trgt_flow = torch.rand(B, R, 3, generator=g).to(dev), torch.randn(B, R, 2, generator=g).to(dev)
+
+    def digest(frame):
+        return hashlib.sha256(frame.detach().float().cpu().numpy().tobytes()).hexdigest()
+
+    one = parallel.ShardedFrameStep(model, B, R, dev, world_size=1, rank=0)
+    one.set_targets(trgt_rgb, trgt_flow)
+    one.new_image_each_step = True
+    f1, s1, _ = one(cam, RenderingInput(o, dr, c["z_near"], c["z_far"]), rob)
+    f1, s1 = f1.clone(), s1.clone()
+    want = digest(f1)
+
+    for graphed in (False, True):
+        packets, scales, sizes = [], None, []
+        for k in range(world):
+            st = parallel.ShardedFrameStep(model, B, R, dev, world_size=world, rank=k, collective=False)
+            st.new_image_each_step = True
+            st.set_targets(trgt_rgb[:, st.lo:st.hi], trgt_flow[:, st.lo:st.hi])
+            rin = RenderingInput(o[:, st.lo:st.hi].contiguous(), dr[:, st.lo:st.hi].contiguous(), c["z_near"], c["z_far"])
+            if graphed:
+                st.capture(cam, rin, rob)
+                st.packet.zero_()
+                st()                      # replay: local step of this rank (no exchange: collective=False)
+            else:
+                st.local(cam, rin, rob)
+            torch.cuda.synchronize()
+            packets.append(st.packets[k].clone())
+            sizes.append(st.hi - st.lo)
+            scales = (st.rgb_scale, st.flow_scale)
+        assert sum(sizes) == R and (len(set(sizes)) == 2) == (R % world != 0)      # the 7-way split is ragged, the 8-way even
+        frame, scal = torch.empty(B, R, 6, device=dev), torch.empty(6, device=dev)
+        hip.assemble_frame(torch.stack(packets), B, R, frame, scal, *scales)
+        torch.cuda.synchronize()
+        assert digest(frame) == want, ("graph" if graphed else "eager", world, precision)
+        # the depth-clip bounds are exact; the two loss SUMS are folded per rank and then over ranks, i.e. in another order than the
+        # one-rank step folds its workgroups: equal to fp32 rounding of a 196,608-term sum, not bit for bit
+        assert torch.equal(scal[:2], s1[:2]) and torch.allclose(scal[2:], s1[2:], rtol=1e-5, atol=0)
