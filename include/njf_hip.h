@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 16
+#define NJF_ABI_VERSION 17
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -228,6 +228,9 @@ typedef struct NjfActivationDump {
   float* pe;       /* [P, 64] positional encoding in slot order [sin 30 | x | y | cos 30 | z | 1] */
   int* foot_idx;   /* [P, 4] texel indices (b*Hf*Wf + y*Wf + x) of the bilinear footprint */
   float* foot_w;   /* [P, 4] bilinear weights (nw, ne, sw, se) */
+  unsigned* mask;  /* ABI v17, may be NULL: [11, P, 4] ReLU masks of `act` -- bit i of the 128 bits of (layer, point) says whether
+                    * one of that layer input's 128 values is > 0, in an order only njf_resnetfc_backward needs to know (its
+                    * `masks` argument): the backward chain reads these 16 bytes per point and layer instead of the 512 of `act` */
 } NjfActivationDump;
 
 /* ---- fused proposal pass: ray_samplers.py:497-552 (level loop body) ------------------------ */
@@ -279,6 +282,9 @@ typedef struct NjfRenderOutputs {
   float* frame_partials;
   const float* trgt_rgb;  /* [B*R,3] target colours of the rays, or NULL */
   const float* trgt_flow; /* [B*R,2] target optical flow of the rays, or NULL */
+  /* ABI v17, training forwards, may be NULL: ReLU masks [11, P, 4] of jac_act / den_act (NjfActivationDump.mask) */
+  unsigned* jac_mask;
+  unsigned* den_mask;
 } NjfRenderOutputs;
 
 /* bins [B*R, S+1] are spacing-domain bin edges in [0,1] (output of njf_proposal_forward or a
@@ -364,11 +370,14 @@ int njf_scatter_footprint(const float* grad, int slices, long long slice_stride,
  * (lin_z outputs) and deltas[0] also w.r.t. lin_in's output.  Exact-fp32 MFMA.
  * `colsum_partial` (may be NULL) [ceil(P / 32), 11, 128]: per 32-point tile, the column sums of every deltas slice (the
  * bias gradients are their sum over the tiles: 32x less data than re-reading deltas; fixed summation order inside a
- * tile). */
+ * tile).
+ * `masks` (ABI v17, may be NULL) [11,P,4]: the ReLU masks the same training forward dumped next to the activations
+ * (NjfActivationDump.mask / NjfRenderOutputs.jac_mask / den_mask).  The chain needs only the SIGN of activations[l]; with `masks`
+ * it does not read `activations` at all (which may then be NULL): 16 instead of 512 bytes per point and layer. */
 #define NJF_RESNET_BACKWARD_CHUNKS 21
 int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, void* stream);
 int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward, int points,
-                          float* deltas, float* colsum_partial, void* stream);
+                          float* deltas, float* colsum_partial, const unsigned* masks, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

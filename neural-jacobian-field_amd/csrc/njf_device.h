@@ -1099,10 +1099,13 @@ struct ActDump {
   float* act;     // [11][P][128] : r0_b = 2b, r1_b = 2b+1 (b = 0..4), r_out = 10
   float* pe;      // [P][64] slot order
   size_t stride;  // P * 128
+  // ReLU masks (round 6): [11][P][4] words, this lane's two words of its point (+ 2*hh); layer stride = P * 4.  What the fused
+  // backward chain reads instead of the activations themselves (njf_resnetfc_backward), nullptr = not dumped
+  unsigned* mask = nullptr;
 };
 
 template <bool DO_RELU>
-__device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x16 (&v)[4]) {
+__device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x16 (&v)[4], unsigned* __restrict__ mask = nullptr) {
   if (dst == nullptr) return;
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -1113,6 +1116,23 @@ __device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x1
       for (int e = 0; e < 4; ++e) o[e] = DO_RELU ? fmaxf(v[m][4 * q + e], 0.f) : v[m][4 * q + e];
       *(f32x4*)(dst + 16 * m + 4 * q) = o;
     }
+  if (mask != nullptr) {
+    // bit 16*(m & 1) + r of word (m >> 1) = [v[m][r] > 0]: the ReLU mask of this lane's 64 features (8 bytes per lane and layer
+    // instead of the 256 the backward chain used to read back: its loads were 1.05 of its 2.81 ms, profiles/r06_training_c4.json)
+    unsigned w[2] = {0u, 0u};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // [x > 0] as clamp(bits(x), 0, 1): positive floats are positive integers, zeros and negatives are not (one v_med3_i32),
+        // shifted into place and merged by one v_lshl_or_b32 -- two VALU instructions per value (NaNs with a clear sign bit count
+        // as positive; the ReLU'd value the same lane dumps for the weight-gradient GEMM is NaN then anyway)
+        const unsigned b = (unsigned)min(max(__float_as_int(v[m][r]), 0), 1);
+        w[m >> 1] |= b << (16 * (m & 1) + r);
+      }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *(u32x2*)mask = u32x2{w[0], w[1]};
+  }
 }
 
 // SHARED (PREC_F16 inference only), bits: 1 = lin_in reads the packed encoding of `share` instead of `pe` (which is then not
@@ -1174,7 +1194,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
       add_hoisted_latent<4, PREC>(gz + blk * 128, g, lane, h);
       NJF_STAMP(st, 5);  // gather folded into h
     }
-    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h);
+    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h, dump.mask ? dump.mask + (size_t)(2 * blk) * (dump.stride / 32) : nullptr);
     const float* bl = bias + blk * 256;
     bias_init<4, true, PREC>(bl, hh, net);
     {
@@ -1187,7 +1207,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, h, net);
       }
     }
-    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net);
+    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net, dump.mask ? dump.mask + (size_t)(2 * blk + 1) * (dump.stride / 32) : nullptr);
     bias_init<4, false, PREC>(bl + 128, hh, h);
     {
       {
@@ -1200,7 +1220,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
       }
     }
   }
-  if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h);
+  if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h, dump.mask ? dump.mask + (size_t)10 * (dump.stride / 32) : nullptr);
   bias_init<1, true, PREC>(bias + 1280, hh, out);
   {
     const float* wl = stream_step(st, wave, lane);

@@ -1250,7 +1250,8 @@ struct ProposalArgs {
 // this lane's share of a point's backward-pass inputs: activations / encoding (both halves), footprint (half 0)
 __device__ __forceinline__ ActDump point_dump(const NjfActivationDump& d, size_t pidx, size_t points, int hh,
                                               const PointGeom& g, int tex0, int texel_stride) {
-  ActDump dump{d.act ? d.act + pidx * 128 + 64 * hh : nullptr, d.pe + pidx * 64 + 32 * hh, points * 128};
+  ActDump dump{d.act ? d.act + pidx * 128 + 64 * hh : nullptr, d.pe + pidx * 64 + 32 * hh, points * 128,
+               d.mask ? d.mask + pidx * 4 + 2 * hh : nullptr};
   if (hh == 0 && d.foot_idx != nullptr) {
     Footprint f;
     point_footprint(g, f);
@@ -1549,7 +1550,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     ColorDump cdump{nullptr, nullptr, 0};
     if (DUMP != 0 && store) {
       const size_t points = (size_t)a.rc.total_rays * S;
-      const NjfActivationDump d{DUMP == 1 ? a.out.jac_act : a.out.den_act, a.out.jac_pe, a.out.foot_idx, a.out.foot_w};
+      const NjfActivationDump d{DUMP == 1 ? a.out.jac_act : a.out.den_act, a.out.jac_pe, a.out.foot_idx, a.out.foot_w,
+                                DUMP == 1 ? a.out.jac_mask : a.out.den_mask};
       dump = point_dump(d, si, points, hh, g, b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
       if (DUMP == 2) cdump = ColorDump{a.out.col_in + si * 32 + 16 * hh, a.out.col_act + si * 64 + 32 * hh, points * 64};
     }
@@ -2269,6 +2271,7 @@ struct BackwardArgs {
   int points;
   float* deltas;        // [11, P, 128]
   float* colsum;        // [tiles, 11, 128] per-tile column sums of deltas, or nullptr
+  const unsigned* masks;  // [11, P, 4] ReLU masks the training forward dumped (then `act` is not read), or nullptr
 };
 
 // Sum over the 32 points of a tile (lanes of one wave half) of every accumulator register, in DPP: rotate-and-add inside
@@ -2301,20 +2304,32 @@ __device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __res
     }
 }
 
-// acc = [act > 0] * acc (+ base), written to `dst`; act / dst address this lane's 64 features of its point
+// acc = [act > 0] * acc (+ base), written to `dst`; act / dst address this lane's 64 features of its point.  `mask` (this lane's
+// two words of the forward pass's ReLU-mask dump, dump_vec128) replaces the 16 loads of the activations by one 8-byte load: the
+// chain needs the SIGN of an activation only, and reading the fp32 values back was 1.05 of the kernel's 2.81 ms on the C4 shard
 template <bool ADD>
-__device__ __forceinline__ void mask_store(const float* __restrict__ act, float* __restrict__ dst, bool ok, f32x16 (&acc)[4],
-                                           const f32x16 (&base)[4]) {
+__device__ __forceinline__ void mask_store(const float* __restrict__ act, const unsigned* __restrict__ mask, float* __restrict__ dst,
+                                           bool ok, f32x16 (&acc)[4], const f32x16 (&base)[4]) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 bits = {0u, 0u};
+  if (mask != nullptr && ok) bits = *(const u32x2*)mask;
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (ok) a = *(const f32x4*)(act + 16 * m + 4 * q);
+      if (mask == nullptr && ok) a = *(const f32x4*)(act + 16 * m + 4 * q);
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = a[e] > 0.f ? acc[m][4 * q + e] : 0.f;
+        float v;
+        if (mask != nullptr) {
+          // the mask bit as an all-ones / all-zeros word (v_bfe_i32: a sign-extended 1-bit field) ANDed onto the gradient's bits
+          const int keep = ((int)(bits[m >> 1] << (31 - (16 * (m & 1) + 4 * q + e)))) >> 31;
+          v = __int_as_float(__float_as_int(acc[m][4 * q + e]) & keep);
+        } else {
+          v = a[e] > 0.f ? acc[m][4 * q + e] : 0.f;
+        }
         if (ADD) v += base[m][4 * q + e];
         acc[m][4 * q + e] = v;
         o[e] = v;
@@ -2333,7 +2348,9 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
   const bool ok = p < a.points;
   const size_t pc = (size_t)min(p, a.points - 1);
   const size_t layer = (size_t)a.points * 128;
-  const float* act = a.act + pc * 128 + 64 * hh;
+  const float* act = a.act ? a.act + pc * 128 + 64 * hh : nullptr;
+  const unsigned* msk = a.masks ? a.masks + pc * 4 + 2 * hh : nullptr;
+  const size_t mlayer = (size_t)a.points * 4;
   float* out = a.deltas + pc * 128 + 64 * hh;
   float* sums = a.colsum ? a.colsum + (size_t)tile * (11 * 128) + 64 * hh : nullptr;
   WeightStream st;
@@ -2351,7 +2368,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 4, 1, 0, false, 1>(st, wl, lane, din, delta);   // lin_out^T (first half of the chunk)
   }
-  mask_store<false>(act + 10 * layer, out + 10 * layer, ok, delta, delta);
+  mask_store<false>(act + 10 * layer, msk ? msk + 10 * mlayer : nullptr, out + 10 * layer, ok, delta, delta);
   const bool live = tile * 32 < a.points;  // wave-uniform
   if (sums && live) tile_colsum(delta, sums + 10 * 128, lane);
   for (int blk = 4; blk >= 0; --blk) {
@@ -2365,7 +2382,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, delta, t);
     }
-    mask_store<false>(act + (size_t)(2 * blk + 1) * layer, out + (size_t)(2 * blk + 1) * layer, ok, t, t);
+    mask_store<false>(act + (size_t)(2 * blk + 1) * layer, msk ? msk + (size_t)(2 * blk + 1) * mlayer : nullptr,
+                      out + (size_t)(2 * blk + 1) * layer, ok, t, t);
     if (sums && live) tile_colsum(t, sums + (2 * blk + 1) * 128, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) u[m] = (f32x16)(0.f);
@@ -2377,7 +2395,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, t, u);
     }
-    mask_store<true>(act + (size_t)(2 * blk) * layer, out + (size_t)(2 * blk) * layer, ok, u, delta);
+    mask_store<true>(act + (size_t)(2 * blk) * layer, msk ? msk + (size_t)(2 * blk) * mlayer : nullptr,
+                     out + (size_t)(2 * blk) * layer, ok, u, delta);
     if (sums && live) tile_colsum(u, sums + (2 * blk) * 128, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) delta[m] = u[m];
@@ -2729,7 +2748,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   a.bins_out = bins_out;
   a.weights_out = weights_out;
   a.density_out = density_out;
-  a.dump = NjfActivationDump{nullptr, nullptr, nullptr, nullptr};
+  a.dump = NjfActivationDump{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (dump != nullptr && dump->act != nullptr) {  // training forward: inputs of the proposal net's backward pass
     if (!dump->pe || !dump->foot_idx || !dump->foot_w) return NJF_E_NULL;
     a.dump = *dump;
@@ -2876,10 +2895,10 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
 }
 
 extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward,
-                                     int points, float* deltas, float* colsum_partial, void* stream) {
-  if (!d_out || !activations || !w_backward || !deltas) return NJF_E_NULL;
+                                     int points, float* deltas, float* colsum_partial, const unsigned* masks, void* stream) {
+  if (!d_out || (!activations && !masks) || !w_backward || !deltas) return NJF_E_NULL;
   if (points < 1 || (long long)points * 11 * 128 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
-  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial};
+  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial, masks};
   return launch_fused(resnetfc_backward_kernel<PREC_F32>, a, (points + 31) / 32, (hipStream_t)stream);
 }

@@ -98,7 +98,7 @@ class RenderOutputs(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "rgb", "depth", "step_minmax", "flow", "pos", "pos_warped", "action_features",
         "weights", "density", "color", "sample_flow", "jacobian", "jac_act", "jac_pe", "foot_idx", "foot_w",
-        "den_act", "col_in", "col_act", "frame_partials", "trgt_rgb", "trgt_flow")]
+        "den_act", "col_in", "col_act", "frame_partials", "trgt_rgb", "trgt_flow", "jac_mask", "den_mask")]
 
 
 class PyramidLevel(C.Structure):
@@ -106,7 +106,7 @@ class PyramidLevel(C.Structure):
 
 
 class ActivationDump(C.Structure):
-    _fields_ = [("act", _vp), ("pe", _vp), ("foot_idx", _vp), ("foot_w", _vp)]
+    _fields_ = [("act", _vp), ("pe", _vp), ("foot_idx", _vp), ("foot_w", _vp), ("mask", _vp)]
 
 
 _lib = None
@@ -137,7 +137,7 @@ _SIGNATURES = {
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, _vp], C.c_int),
-    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
+    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
@@ -489,7 +489,7 @@ def generate_rays(coords, height, width, k_inv, c2w, origins, directions, z) -> 
 def _int_ptr(t: torch.Tensor) -> int:
     if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
         _call.device = None
-        raise ValueError("njf_hip: foot_idx must be a contiguous int32 device tensor")
+        raise ValueError("njf_hip: foot_idx / mask tensors must be contiguous int32 device tensors")
     _note_device(t, "foot_idx")
     return t.data_ptr()
 
@@ -503,7 +503,7 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
     dump_ref = None
     if dump is not None:
         dump_ref = C.byref(ActivationDump(_ptr(dump["act"]), _ptr(dump["pe"]), _int_ptr(dump["foot_idx"]),
-                                          _ptr(dump["foot_w"])))
+                                          _ptr(dump["foot_w"]), _int_ptr(dump["mask"]) if dump.get("mask") is not None else None))
     _note_device(cams, "cameras")
     _note_device(fmap, "feature map")
     _check_map_dtype(fmap, precision)
@@ -523,7 +523,7 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     out = RenderOutputs()
     for name, _ in RenderOutputs._fields_:
         t = outputs.get(name)
-        if name == "foot_idx" and t is not None:  # the only non-float output
+        if name in ("foot_idx", "jac_mask", "den_mask") and t is not None:  # the int32 outputs
             setattr(out, name, _int_ptr(t))
         else:
             setattr(out, name, _ptr(t, name))
@@ -607,17 +607,22 @@ def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: 
     _launch("njf_pack_resnetfc_backward", load_library().njf_pack_resnetfc_backward, C.byref(src), _ptr(w_out, "w_out"))
 
 
-def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor, want_colsum: bool = False):
+def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor, want_colsum: bool = False,
+                      mask: Optional[torch.Tensor] = None):
     """deltas [11,P,128] of one ResnetFC's backward pass (include/njf_hip.h: njf_resnetfc_backward): d_out [P,d_out],
     act [11,P,128] (dumped ReLU'd layer inputs), w_backward from pack_resnetfc_backward.  ``want_colsum``: also return
-    the column sums [11,128] of every deltas slice (the bias gradients), reduced from the kernel's per-tile partials."""
+    the column sums [11,128] of every deltas slice (the bias gradients), reduced from the kernel's per-tile partials.
+    ``mask`` [11,P,4] int32: the ReLU masks the same forward dumped (ABI v17) -- the chain then reads them instead of ``act``."""
     points = d_out.shape[0]
     if tuple(act.shape) != (11, points, 128) or w_backward.numel() != RESNET_BACKWARD_W_FLOATS:
         raise ValueError("njf_hip: resnetfc_backward shape mismatch")
+    if mask is not None and tuple(mask.shape) != (11, points, 4):
+        raise ValueError("njf_hip: resnetfc_backward mask must be [11, P, 4] int32")
     deltas = torch.empty_like(act)
     partial = torch.empty((points + 31) // 32, 11, 128, dtype=torch.float32, device=act.device) if want_colsum else None
     _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out.contiguous(), "d_out"), d_out.shape[1],
-            _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"), _ptr(partial, "colsum_partial"))
+            _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"), _ptr(partial, "colsum_partial"),
+            _int_ptr(mask) if mask is not None else None)
     return (deltas, partial.sum(0)) if want_colsum else deltas
 
 

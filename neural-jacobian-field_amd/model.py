@@ -509,6 +509,7 @@ class Model(nn.Module):
             outs["pos_warped"] = outs.get("pos_warped", torch.empty(b, r, 3, **f32))
             if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:  # the transformer head is recomputed from pe + footprint
                 outs["jac_act"] = torch.empty(11, pts, 128, **f32)
+                outs["jac_mask"] = torch.empty(11, pts, 4, dtype=torch.int32, device=dev)   # ReLU masks: what the backward chain reads
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
             outs["foot_w"] = torch.empty(pts, 4, **f32)
@@ -519,6 +520,7 @@ class Model(nn.Module):
             outs["density"] = outs.get("density", torch.empty(b, r, s, 1, **f32))
             outs["color"] = torch.empty(b, r, s, 3, **f32)
             outs["den_act"] = torch.empty(11, pts, 128, **f32)
+            outs["den_mask"] = torch.empty(11, pts, 4, dtype=torch.int32, device=dev)
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
             outs["foot_w"] = torch.empty(pts, 4, **f32)

@@ -263,7 +263,8 @@ class ProposalNetworkSampler(Sampler):
                 dump = {"act": torch.empty(11, pts, 128, dtype=torch.float32, device=dev),
                         "pe": torch.empty(pts, 64, dtype=torch.float32, device=dev),
                         "foot_idx": torch.empty(pts, 4, dtype=torch.int32, device=dev),
-                        "foot_w": torch.empty(pts, 4, dtype=torch.float32, device=dev)}
+                        "foot_w": torch.empty(pts, 4, dtype=torch.float32, device=dev),
+                        "mask": torch.empty(11, pts, 4, dtype=torch.int32, device=dev)}   # ReLU masks for the backward chain (ABI v17)
                 dump_out.append({**dump, "density": sigma, "updated": updated})
             hip.proposal_forward(o, d, cams, fmap, goff, w, bias, bins.contiguous(), s_in, u, s_out, self._anneal, bins_out,
                                  w_out, sigma, precision=net.precision, dump=dump)

@@ -74,20 +74,23 @@ def _tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out.reshape(layers, groups, n, -1).sum(1)
 
 
-def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, want_colsum: bool = False):
+def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, want_colsum: bool = False,
+                            mask: torch.Tensor = None):
     """The data-gradient chain of one ResnetFC as ONE fused launch (njf_resnetfc_backward): deltas [11,P,128], see
     include/njf_hip.h for the meaning of each slice (with ``want_colsum`` also their column sums [11,128], from the
     kernel's per-tile partial sums).  The transposed weights are packed per call (eleven small launches: the weights
     change with every optimiser step)."""
     w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
     hip.pack_resnetfc_backward(p, "", w_t)
-    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum)
+    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum, mask=mask)
 
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
                       foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
-                      d_feats: torch.Tensor = None, samples_per_ray: int = 1) -> Dict[str, torch.Tensor]:
-    """Backward pass of one ResnetFC (resnet_fc.py:130-154) from the activations the HIP forward dumped.
+                      d_feats: torch.Tensor = None, samples_per_ray: int = 1, mask: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+    """Backward pass of one ResnetFC (resnet_fc.py:130-154) from the activations the HIP forward dumped.  ``mask`` [11,P,4] int32:
+    the ReLU masks the same forward dumped -- the fused data-gradient chain then reads 16 instead of 512 bytes per point and layer
+    (the weight-gradient GEMMs below are what still reads ``act``).
 
     ``p``: the net's parameters by reference name; ``d_out`` [P, d_out]; ``act`` [11,P,128] (ReLU'd layer inputs),
     ``pe`` [P,64] (slot order), ``foot_idx``/``foot_w`` [P,4] bilinear footprint on the flattened texel grid,
@@ -100,7 +103,7 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     with; the weight gradients themselves are sums over ALL points of outer products (K = points) and are one batched
     library GEMM on those matrices; the bias gradients one column-sum reduction."""
     grads: Dict[str, torch.Tensor] = {}
-    deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True)   # sums [11,128]: deltas[l+1] <-> bias of layer l
+    deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True, mask=mask)   # sums [11,128]: deltas[l+1] <-> bias of layer l
     w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
     for l, name in enumerate(_LAYER_NAMES):
         grads[name + ".weight"] = w_grads[l]
@@ -211,7 +214,7 @@ class ActionFlowFunction(torch.autograd.Function):
             cut = ctx.names[0].index(".") + 1
             p = {n[cut:]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
             grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat,
-                                      samples_per_ray=s)
+                                      samples_per_ray=s, mask=outs.get("jac_mask"))
             result = tuple(grads[n[cut:]] for n in ctx.names)
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
@@ -306,7 +309,7 @@ class FieldFunction(torch.autograd.Function):
             if g_sigma is not None:
                 d_out[:, 15] = g_sigma.reshape(pts) * clamp_exp(outs["density"].reshape(pts))
             grads = resnetfc_backward(den, d_out, outs["den_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"],
-                                      feats_flat, d_feats, samples_per_ray=outs["weights"].shape[-1])
+                                      feats_flat, d_feats, samples_per_ray=outs["weights"].shape[-1], mask=outs.get("den_mask"))
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[i] = grads[k]
         for lvl in range(ctx.n_prop):
@@ -317,7 +320,7 @@ class FieldFunction(torch.autograd.Function):
             net = dict(zip(JACOBIAN_PARAM_ORDER, params[n + 6 + lvl * n:n + 6 + (lvl + 1) * n]))
             d_out = (g.reshape(-1) * clamp_exp(d["density"].reshape(-1)))[:, None]
             grads = resnetfc_backward(net, d_out, d["act"], d["pe"], d["foot_idx"], d["foot_w"], feats_flat, d_feats,
-                                      samples_per_ray=d["density"].shape[-1])
+                                      samples_per_ray=d["density"].shape[-1], mask=d.get("mask"))
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[n + 6 + lvl * n + i] = grads[k]
         ctx.outs = None
