@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 H = W = 256
 S_PROP, S_FINAL, ACTION_DIM = 64, 64, 8
-PROFILE_ROUNDS = ("r05", "r04", "r03")   # newest first: where roofline.traffic (PMC passes, never taken in the timed run) is looked up
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")   # newest first: where roofline.traffic (PMC passes, never taken in the timed run) is looked up
 HEADLINE_PRECISION = "f32"        # the reference's arithmetic; see the module docstring
 
 # Algorithmic work (hoisted-lin_z formulation), MACs per point

@@ -373,11 +373,16 @@ int njf_scatter_footprint(const float* grad, int slices, long long slice_stride,
  * tile).
  * `masks` (ABI v17, may be NULL) [11,P,4]: the ReLU masks the same training forward dumped next to the activations
  * (NjfActivationDump.mask / NjfRenderOutputs.jac_mask / den_mask).  The chain needs only the SIGN of activations[l]; with `masks`
- * it does not read `activations` at all (which may then be NULL): 16 instead of 512 bytes per point and layer. */
+ * it does not read `activations` at all (which may then be NULL): 16 instead of 512 bytes per point and layer.
+ * `precision` (ABI v17, of BOTH entry points: the blob is packed for it): NJF_PRECISION_F32 -- exact fp32 products, the default of
+ * the host side -- or NJF_PRECISION_F16X2: hi*hi + hi*lo + lo*hi of fp16 halves (fp32-class: 2^-22 per product) on gradients the
+ * kernel scales by a power of two taken from `d_out_absmax` (device scalar max|d_out|, required then) and scales back on the way
+ * out.  (The reference trains on TF32 products, train.py:64-65.) */
 #define NJF_RESNET_BACKWARD_CHUNKS 21
-int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, void* stream);
+int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, int precision, void* stream);
 int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward, int points,
-                          float* deltas, float* colsum_partial, const unsigned* masks, void* stream);
+                          float* deltas, float* colsum_partial, const unsigned* masks, int precision,
+                          const float* d_out_absmax, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

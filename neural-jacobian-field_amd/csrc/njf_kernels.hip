@@ -2272,6 +2272,7 @@ struct BackwardArgs {
   float* deltas;        // [11, P, 128]
   float* colsum;        // [tiles, 11, 128] per-tile column sums of deltas, or nullptr
   const unsigned* masks;  // [11, P, 4] ReLU masks the training forward dumped (then `act` is not read), or nullptr
+  const float* absmax;    // PREC_F16X2 only: device scalar max|d_out| (the chain runs on gradients scaled by a power of two)
 };
 
 // Sum over the 32 points of a tile (lanes of one wave half) of every accumulator register, in DPP: rotate-and-add inside
@@ -2284,7 +2285,7 @@ __device__ __forceinline__ float dpp_add(float v) {
   return v + __builtin_bit_cast(float, moved);
 }
 
-__device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __restrict__ dst, int lane) {
+__device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __restrict__ dst, int lane, float unscale = 1.0f) {
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -2298,7 +2299,7 @@ __device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __res
         v = dpp_add<0x122, 0xf>(v);  // row_ror:2
         v = dpp_add<0x121, 0xf>(v);  // row_ror:1
         v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-        o[e] = v;
+        o[e] = v * unscale;
       }
       if ((lane & 31) == 16 + 4 * m + q) *(f32x4*)(dst + 16 * m + 4 * q) = o;
     }
@@ -2307,9 +2308,9 @@ __device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __res
 // acc = [act > 0] * acc (+ base), written to `dst`; act / dst address this lane's 64 features of its point.  `mask` (this lane's
 // two words of the forward pass's ReLU-mask dump, dump_vec128) replaces the 16 loads of the activations by one 8-byte load: the
 // chain needs the SIGN of an activation only, and reading the fp32 values back was 1.05 of the kernel's 2.81 ms on the C4 shard
-template <bool ADD>
+template <bool ADD, bool SCALED = false>
 __device__ __forceinline__ void mask_store(const float* __restrict__ act, const unsigned* __restrict__ mask, float* __restrict__ dst,
-                                           bool ok, f32x16 (&acc)[4], const f32x16 (&base)[4]) {
+                                           bool ok, f32x16 (&acc)[4], const f32x16 (&base)[4], float unscale = 1.0f) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   u32x2 bits = {0u, 0u};
   if (mask != nullptr && ok) bits = *(const u32x2*)mask;
@@ -2332,7 +2333,7 @@ __device__ __forceinline__ void mask_store(const float* __restrict__ act, const 
         }
         if (ADD) v += base[m][4 * q + e];
         acc[m][4 * q + e] = v;
-        o[e] = v;
+        o[e] = SCALED ? v * unscale : v;   // (a power of two: exact)
       }
       if (ok) *(f32x4*)(dst + 16 * m + 4 * q) = o;
     }
@@ -2355,11 +2356,29 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
   float* sums = a.colsum ? a.colsum + (size_t)tile * (11 * 128) + 64 * hh : nullptr;
   WeightStream st;
   stream_begin(st, a.w_pack, 21, 1, wave, lane);
+  // PREC_F16X2 (opt-in; training.py: backward_precision): every product is hi*hi + hi*lo + lo*hi of fp16 halves, fp32-class (2^-22)
+  // only inside fp16's range -- gradients are 1e-3 ... 1e-9.  The chain is LINEAR in d_out, so it runs on d_out * 2^k with k chosen
+  // from max|d_out| (device scalar `absmax`, one reduction in front of the launch) such that the largest entry becomes 64: 2^9 of
+  // head room before fp16's 65504, full 22 bits for entries down to 2^-9 of the largest and >= 11 bits down to 2^-20 of it (what
+  // the smaller ones contribute to a weight gradient is below that in absolute terms); results are scaled back on the way out
+  // (powers of two: exact).  The reference itself trains on TF32 products (train.py:64-65: 10 mantissa bits).
+  constexpr bool SCALED = PREC != PREC_F32;
+  float scale = 1.0f, unscale = 1.0f;
+  if constexpr (SCALED) {
+    const float mx = a.absmax ? *a.absmax : 0.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+      int e;
+      frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)
+      const int k = max(min(6 - e, 120), -120);
+      scale = ldexpf(1.0f, k);
+      unscale = ldexpf(1.0f, -k);
+    }
+  }
   f32x16 din[1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int d = 16 * hh + r;
-    din[0][r] = (ok && d < a.d_out_dim) ? a.d_out[pc * a.d_out_dim + d] : 0.f;
+    din[0][r] = (ok && d < a.d_out_dim) ? a.d_out[pc * a.d_out_dim + d] * scale : 0.f;
   }
   f32x16 delta[4], t[4], u[4];
 #pragma unroll
@@ -2368,9 +2387,9 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 4, 1, 0, false, 1>(st, wl, lane, din, delta);   // lin_out^T (first half of the chunk)
   }
-  mask_store<false>(act + 10 * layer, msk ? msk + 10 * mlayer : nullptr, out + 10 * layer, ok, delta, delta);
+  mask_store<false, SCALED>(act + 10 * layer, msk ? msk + 10 * mlayer : nullptr, out + 10 * layer, ok, delta, delta, unscale);
   const bool live = tile * 32 < a.points;  // wave-uniform
-  if (sums && live) tile_colsum(delta, sums + 10 * 128, lane);
+  if (sums && live) tile_colsum(delta, sums + 10 * 128, lane, unscale);
   for (int blk = 4; blk >= 0; --blk) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) t[m] = (f32x16)(0.f);
@@ -2382,9 +2401,9 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, delta, t);
     }
-    mask_store<false>(act + (size_t)(2 * blk + 1) * layer, msk ? msk + (size_t)(2 * blk + 1) * mlayer : nullptr,
-                      out + (size_t)(2 * blk + 1) * layer, ok, t, t);
-    if (sums && live) tile_colsum(t, sums + (2 * blk + 1) * 128, lane);
+    mask_store<false, SCALED>(act + (size_t)(2 * blk + 1) * layer, msk ? msk + (size_t)(2 * blk + 1) * mlayer : nullptr,
+                              out + (size_t)(2 * blk + 1) * layer, ok, t, t, unscale);
+    if (sums && live) tile_colsum(t, sums + (2 * blk + 1) * 128, lane, unscale);
 #pragma unroll
     for (int m = 0; m < 4; ++m) u[m] = (f32x16)(0.f);
     {
@@ -2395,22 +2414,23 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       const float* wl = stream_step(st, wave, lane);
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, t, u);
     }
-    mask_store<true>(act + (size_t)(2 * blk) * layer, msk ? msk + (size_t)(2 * blk) * mlayer : nullptr,
-                     out + (size_t)(2 * blk) * layer, ok, u, delta);
-    if (sums && live) tile_colsum(u, sums + (2 * blk) * 128, lane);
+    mask_store<true, SCALED>(act + (size_t)(2 * blk) * layer, msk ? msk + (size_t)(2 * blk) * mlayer : nullptr,
+                             out + (size_t)(2 * blk) * layer, ok, u, delta, unscale);
+    if (sums && live) tile_colsum(u, sums + (2 * blk) * 128, lane, unscale);
 #pragma unroll
     for (int m = 0; m < 4; ++m) delta[m] = u[m];
   }
 }
 
-extern "C" int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, void* stream) {
+extern "C" int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, int precision, void* stream) {
   if (!src || !w_out) return NJF_E_NULL;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   if (src->d_out < 1 || src->d_out > 32) return NJF_E_DOUT;
   if (!src->lin_out_w) return NJF_E_NULL;
   for (int i = 0; i < 5; ++i)
     if (!src->fc0_w[i] || !src->fc1_w[i]) return NJF_E_NULL;
   hipStream_t s = (hipStream_t)stream;
-  const int P = NJF_PRECISION_F32;
+  const int P = precision;
   // chunk 0: lin_out^T  [128 x d_out -> 32], half a chunk; the other half is never read but is moved by the DMA
   launch_pack(src->lin_out_w, nullptr, 128, src->d_out, 4, 1, 3, P, w_out, nullptr, s);
   fill_kernel<<<16, 256, 0, s>>>(w_out + 4096, 4096, 0.f);
@@ -2895,10 +2915,16 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
 }
 
 extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward,
-                                     int points, float* deltas, float* colsum_partial, const unsigned* masks, void* stream) {
+                                     int points, float* deltas, float* colsum_partial, const unsigned* masks, int precision,
+                                     const float* d_out_absmax, void* stream) {
   if (!d_out || (!activations && !masks) || !w_backward || !deltas) return NJF_E_NULL;
   if (points < 1 || (long long)points * 11 * 128 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
-  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial, masks};
+  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial, masks, d_out_absmax};
+  if (precision == NJF_PRECISION_F16X2) {
+    if (!d_out_absmax) return NJF_E_NULL;
+    return launch_fused(resnetfc_backward_kernel<PREC_F16X2>, a, (points + 31) / 32, (hipStream_t)stream);
+  }
+  if (precision != NJF_PRECISION_F32) return NJF_E_MODE;
   return launch_fused(resnetfc_backward_kernel<PREC_F32>, a, (points + 31) / 32, (hipStream_t)stream);
 }

@@ -136,8 +136,8 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), C.c_int, _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
-    "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, _vp], C.c_int),
-    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp], C.c_int),
+    "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, C.c_int, _vp], C.c_int),
+    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
@@ -594,8 +594,14 @@ def scatter_footprint(grad, foot_idx, foot_w, out, run_length: int = 1) -> None:
 RESNET_BACKWARD_W_FLOATS = 21 * 8192
 
 
-def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor) -> None:
-    """Transposed weights of one ResnetFC in the chunk order njf_resnetfc_backward streams them (include/njf_hip.h)."""
+BACKWARD_PRECISIONS = ("f32", "f16x2")
+
+
+def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: torch.Tensor, precision: str = "f32") -> None:
+    """Transposed weights of one ResnetFC in the chunk order njf_resnetfc_backward streams them (include/njf_hip.h), packed for
+    the chain's product form (``precision``: "f32" exact, or "f16x2")."""
+    if precision not in BACKWARD_PRECISIONS:
+        raise ValueError(f"njf_hip: backward precision must be one of {BACKWARD_PRECISIONS} (got {precision!r})")
     def p(name):
         return _ptr(params[prefix + name].detach().contiguous(), prefix + name)
 
@@ -604,11 +610,12 @@ def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: 
         src.fc0_w[i], src.fc1_w[i] = p(f"blocks.{i}.fc_0.weight"), p(f"blocks.{i}.fc_1.weight")
     src.lin_out_w = p("lin_out.weight")
     src.d_out = params[prefix + "lin_out.weight"].shape[0]
-    _launch("njf_pack_resnetfc_backward", load_library().njf_pack_resnetfc_backward, C.byref(src), _ptr(w_out, "w_out"))
+    _launch("njf_pack_resnetfc_backward", load_library().njf_pack_resnetfc_backward, C.byref(src), _ptr(w_out, "w_out"),
+            PRECISIONS[precision])
 
 
 def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor, want_colsum: bool = False,
-                      mask: Optional[torch.Tensor] = None):
+                      mask: Optional[torch.Tensor] = None, precision: str = "f32"):
     """deltas [11,P,128] of one ResnetFC's backward pass (include/njf_hip.h: njf_resnetfc_backward): d_out [P,d_out],
     act [11,P,128] (dumped ReLU'd layer inputs), w_backward from pack_resnetfc_backward.  ``want_colsum``: also return
     the column sums [11,128] of every deltas slice (the bias gradients), reduced from the kernel's per-tile partials.
@@ -618,11 +625,16 @@ def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.
         raise ValueError("njf_hip: resnetfc_backward shape mismatch")
     if mask is not None and tuple(mask.shape) != (11, points, 4):
         raise ValueError("njf_hip: resnetfc_backward mask must be [11, P, 4] int32")
+    if precision not in BACKWARD_PRECISIONS:
+        raise ValueError(f"njf_hip: backward precision must be one of {BACKWARD_PRECISIONS} (got {precision!r})")
     deltas = torch.empty_like(act)
     partial = torch.empty((points + 31) // 32, 11, 128, dtype=torch.float32, device=act.device) if want_colsum else None
-    _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out.contiguous(), "d_out"), d_out.shape[1],
+    d_out = d_out.contiguous()
+    # "f16x2": the chain runs on d_out scaled by a power of two taken from its largest entry (one reduction, no host round trip)
+    absmax = d_out.abs().amax().reshape(1) if precision == "f16x2" else None
+    _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out, "d_out"), d_out.shape[1],
             _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"), _ptr(partial, "colsum_partial"),
-            _int_ptr(mask) if mask is not None else None)
+            _int_ptr(mask) if mask is not None else None, PRECISIONS[precision], _ptr(absmax, "d_out_absmax"))
     return (deltas, partial.sum(0)) if want_colsum else deltas
 
 

@@ -21,6 +21,8 @@ from __future__ import annotations
 import math
 from typing import Callable, Dict, List, Sequence
 
+import os
+
 import torch
 
 from . import hip
@@ -74,6 +76,25 @@ def _tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out.reshape(layers, groups, n, -1).sum(1)
 
 
+# Product form of the fused backward chain (njf_resnetfc_backward): "f32" = exact fp32 MFMA products (default; what every gradient
+# row of the test-suite is held to its fp64 floor with), "f16x2" = split fp16 products on power-of-two-scaled gradients (fp32-class,
+# 2^-22 per product where the reference's own training runs TF32 products, train.py:64-65; measured against the exact chain in
+# tests/test_training_gpu.py::test_backward_chain_f16x2_against_exact).  Process-wide, like the reference's
+# torch.set_float32_matmul_precision.
+_BACKWARD_PRECISION = os.environ.get("NJF_BACKWARD_PRECISION", "f32")
+
+
+def set_backward_precision(name: str) -> None:
+    global _BACKWARD_PRECISION
+    if name not in hip.BACKWARD_PRECISIONS:
+        raise ValueError(f"backward precision must be one of {hip.BACKWARD_PRECISIONS} (got {name!r})")
+    _BACKWARD_PRECISION = name
+
+
+def backward_precision() -> str:
+    return _BACKWARD_PRECISION
+
+
 def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, want_colsum: bool = False,
                             mask: torch.Tensor = None):
     """The data-gradient chain of one ResnetFC as ONE fused launch (njf_resnetfc_backward): deltas [11,P,128], see
@@ -81,8 +102,8 @@ def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act
     kernel's per-tile partial sums).  The transposed weights are packed per call (eleven small launches: the weights
     change with every optimiser step)."""
     w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
-    hip.pack_resnetfc_backward(p, "", w_t)
-    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum, mask=mask)
+    hip.pack_resnetfc_backward(p, "", w_t, precision=_BACKWARD_PRECISION)
+    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum, mask=mask, precision=_BACKWARD_PRECISION)
 
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,

@@ -541,3 +541,38 @@ def test_fused_backward_chain_equals_the_gemm_chain(setup):
     for k, r in ref_grads.items():
         err = (grads[k].double() - r).abs().max().item() / (r.abs().max().item() + 1e-30)
         assert err < 5e-6, (k, err)
+
+
+def test_backward_chain_f16x2_against_exact():
+    """The opt-in product form of the fused backward chain (training.set_backward_precision("f16x2"): hi*hi + hi*lo + lo*hi of fp16
+    halves on gradients scaled by a power of two taken from max|d_out|) against the exact-fp32 chain on the SAME dumped activations,
+    masks and upstream gradient, for upstream gradients of three very different magnitudes (a loss-scale independence check: the
+    scaling is by powers of two and must cancel exactly).  Stated tolerance: every deltas slice and every bias column sum within
+    2e-5 of the exact chain's, norm-wise -- the reference's own training arithmetic is TF32 (train.py:64-65: 2^-11 per operand)."""
+    from neural_jacobian_field_amd import hip, synthetic
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    P = 4096 + 17                                        # ragged last tile
+    params = synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", 8, with_encoder=False), seed=0)
+    net = {k[len("decoder.jacobian_head."):]: v.to(dev) for k, v in params.items() if k.startswith("decoder.jacobian_head.")}
+    act = torch.relu(torch.randn(11, P, 128, generator=g)).to(dev).contiguous()
+    bits = (act > 0).reshape(11, P, 2, 2, 2, 16)         # [layer, point, hh, word, m & 1, r]: feature = 64 hh + 32 word + 16 (m & 1) + r
+    weights = (1 << torch.arange(32, dtype=torch.int64, device=dev)).reshape(2, 16)
+    mask = (bits.to(torch.int64) * weights).sum((-1, -2))                      # [11, P, 2, 2] -> word index 2 hh + word
+    mask = mask.reshape(11, P, 4)
+    mask = torch.where(mask >= 2 ** 31, mask - 2 ** 32, mask).to(torch.int32).contiguous()
+    w32 = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, device=dev)
+    w16 = torch.empty_like(w32)
+    hip.pack_resnetfc_backward(net, "", w32, precision="f32")
+    hip.pack_resnetfc_backward(net, "", w16, precision="f16x2")
+    base = torch.randn(P, 24, generator=g).to(dev) * torch.rand(P, 1, generator=g).to(dev) ** 8     # per-point magnitudes over 8 decades
+    for scale in (1.0, 3.7e-9, 5.0e6):
+        d_out = (base * scale).contiguous()
+        ref, ref_sums = hip.resnetfc_backward(d_out, act, w32, want_colsum=True, mask=mask, precision="f32")
+        via_act, _ = hip.resnetfc_backward(d_out, act, w32, want_colsum=True, precision="f32")
+        assert torch.equal(ref, via_act)                 # the mask route IS the activation route, bit for bit
+        got, got_sums = hip.resnetfc_backward(d_out, act, w16, want_colsum=True, mask=mask, precision="f16x2")
+        assert torch.isfinite(got).all()
+        for l in range(11):
+            assert rel(got[l], ref[l]) < 2e-5, (scale, l, rel(got[l], ref[l]))
+            assert rel(got_sums[l], ref_sums[l]) < 2e-5, (scale, l)

@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234, help="torch seed of every rank (stratified jitter): the same step twice gives the same loss")
     ap.add_argument("--start-step", type=int, default=0,
                     help="global step of the first iteration (20000: steady state -- anneal exponent 1, proposal nets updated every sixth step)")
+    ap.add_argument("--backward-precision", choices=["f32", "f16x2"], default="f32",
+                    help="product form of the fused backward chain (training.set_backward_precision): exact fp32 (default) or split fp16 "
+                         "on scaled gradients (fp32-class; the reference trains on TF32 products)")
     args = ap.parse_args()
     mode = args.mode or args.mode_pos or "action"
     launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -58,7 +61,8 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    from neural_jacobian_field_amd import model_wrapper as mw, synthetic
+    from neural_jacobian_field_amd import model_wrapper as mw, synthetic, training
+    training.set_backward_precision(args.backward_precision)
     from neural_jacobian_field_amd.config import model_cfg_from_dict
     from neural_jacobian_field_amd.model import CameraInput, Model, ModelTarget, RenderingInput, RobotInput
     from neural_jacobian_field_amd.parallel import data_parallel_step
@@ -145,7 +149,9 @@ def main():
                 "final_loss": float(loss), "gradient_bucket_bytes": bucket, "start_step": args.start_step,
                 "mode": {"action": "action (Jacobian head only), encoder fwd included",
                          "perception": "perception (all parameters), encoder fwd+bwd included"}[mode],
-                "dtype": "forward: package default precision; backward chain: exact fp32 MFMA", "data": "synthetic",
+                "dtype": "forward: package default precision; backward chain: "
+                         + ("exact fp32 MFMA" if args.backward_precision == "f32" else "f16x2 (split fp16 products on power-of-two-scaled gradients)"),
+                "data": "synthetic",
                 "config": {"workload": "C4: Allegro training step, ray-batch DP, one flattened gradient all-reduce per step",
                            "parallelism": f"dp{world}"},
                 "rccl": evidence}
