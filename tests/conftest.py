@@ -132,7 +132,11 @@ def pytest_sessionfinish(session, exitstatus):
                              "frac_within_1e-4_of_ref32 = share of elements with |hip - ref32| <= 1e-4 max|ref32|",
                "truth_rows": len(_TRUTH_ROWS), "truth_rows_asserted": sum(r["asserted"] for r in _TRUTH_ROWS),
                "truth_rows_not_ok": sum(not r["truth_ok"] for r in _TRUTH_ROWS),
-               "truth_rows_asserted_not_ok": sum(r["asserted"] and not r["truth_ok"] for r in _TRUTH_ROWS),
+               # what was ASSERTED of a row is its mode's own criterion (parity_harness.truth_asserted: `asserted_ok`, None = not
+               # asserted for that tensor); rows recorded by margins(...) carry truth_ok only, which is then the asserted criterion
+               "truth_rows_asserted_not_ok": sum(bool(r["asserted"]) and ((r["asserted_ok"] is False) if "asserted_ok" in r else (not r["truth_ok"]))
+                                                 for r in _TRUTH_ROWS),
+               "truth_rows_asserted_by_mode_criterion": sum(bool(r["asserted"]) and r.get("asserted_ok") is not None for r in _TRUTH_ROWS),
                "truth_rows_tail_outlier": sum(bool(r.get("tail_outlier")) for r in _TRUTH_ROWS),
                "truth_rows_asserted_tail_outlier": sum(bool(r["asserted"] and r.get("tail_outlier")) for r in _TRUTH_ROWS),
                "truth_table": _TRUTH_ROWS}

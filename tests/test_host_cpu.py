@@ -754,3 +754,54 @@ def test_reserved_stdout_carries_the_json_line_and_nothing_else():
     assert r.stdout.splitlines() == ["before", json.dumps({"metric": "x", "value": 1}), "after"]
     for noise in ("python noise", "descriptor noise", "native noise"):
         assert noise in r.stderr
+
+
+def test_bench_roofline_work_counts_follow_survey_8d():
+    """bench.py's algorithmic MAC counts (roofline.achieved numerator): SURVEY 8d's table for the ResnetFC Jacobian head at A = 8,
+    their dependence on A, and the folded / reference-formulation counts of the transformer head (bench.mac_jacobian)."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.mac_jacobian("jacobian_mlp", 8) == {"canonical": 174_976, "reference_formulation": 371_584}
+    assert bench.mac_jacobian("jacobian_mlp", 6)["canonical"] == 8_064 + 163_840 + 128 * 18
+    t8, t6 = bench.mac_jacobian("jacobian_transformer", 8), bench.mac_jacobian("jacobian_transformer", 6)
+    assert t8["reference_formulation"] == 284_096 == 575 * 64 + 3 * (64 * 512 + 2 * 512 * 8 + 512 * 64 + 2 * 64 * 64) + 64 * 24
+    assert t8["canonical"] == 63 * 64 + 3 * (2 * 64 * 64 + 2 * 64 * 64) + 64 * 24 == 54_720
+    assert t6["canonical"] == 63 * 64 + 3 * (2 * 64 * 48 + 2 * 64 * 64) + 64 * 18
+    assert t6["reference_formulation"] == 575 * 64 + 3 * (64 * 512 + 2 * 512 * 6 + 512 * 64 + 2 * 64 * 64) + 64 * 18
+
+
+def test_unifdef_lite_resolves_only_the_named_macros():
+    """tools/unifdef_lite.py (what moved the retired experiment macros into tools/probes/*.patch): conditionals on the named macros are
+    resolved as undefined -- #ifdef / #ifndef / #if defined() with &&, ||, !, #elif, #else, nested -- everything else stays verbatim."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import unifdef_lite
+    src = """a
+#ifdef X
+x1
+#else
+x0
+#endif
+#ifndef X
+nx
+#endif
+#if defined(X) && X == 2
+x2
+#elif defined(Y)
+y
+#else
+none
+#endif
+#ifdef KEEP
+k
+#ifdef X
+kx
+#endif
+#endif
+#if defined(X) || defined(KEEP)
+mixed
+#endif
+z
+""".splitlines(keepends=True)
+    out = "".join(unifdef_lite.run(src, {"X", "Y"}))
+    assert out == "a\nx0\nnx\nnone\n#ifdef KEEP\nk\n#endif\n#if defined(X) || defined(KEEP)\nmixed\n#endif\nz\n"
