@@ -231,6 +231,8 @@ typedef struct NjfActivationDump {
   unsigned* mask;  /* ABI v17, may be NULL: [11, P, 4] ReLU masks of `act` -- bit i of the 128 bits of (layer, point) says whether
                     * one of that layer input's 128 values is > 0, in an order only njf_resnetfc_backward needs to know (its
                     * `masks` argument): the backward chain reads these 16 bytes per point and layer instead of the 512 of `act` */
+  int act_f16;     /* ABI v17: non-zero = `act` addresses [11, P, 128] HALVES (16-bit training storage: the weight-gradient GEMMs
+                    * then read fp16 operands with fp32 accumulation; the reference trains on TF32 products) */
 } NjfActivationDump;
 
 /* ---- fused proposal pass: ray_samplers.py:497-552 (level loop body) ------------------------ */
@@ -285,6 +287,7 @@ typedef struct NjfRenderOutputs {
   /* ABI v17, training forwards, may be NULL: ReLU masks [11, P, 4] of jac_act / den_act (NjfActivationDump.mask) */
   unsigned* jac_mask;
   unsigned* den_mask;
+  int dump_f16;           /* non-zero: jac_act / den_act address halves (NjfActivationDump.act_f16) */
 } NjfRenderOutputs;
 
 /* bins [B*R, S+1] are spacing-domain bin edges in [0,1] (output of njf_proposal_forward or a
@@ -377,12 +380,15 @@ int njf_scatter_footprint(const float* grad, int slices, long long slice_stride,
  * `precision` (ABI v17, of BOTH entry points: the blob is packed for it): NJF_PRECISION_F32 -- exact fp32 products, the default of
  * the host side -- or NJF_PRECISION_F16X2: hi*hi + hi*lo + lo*hi of fp16 halves (fp32-class: 2^-22 per product) on gradients the
  * kernel scales by a power of two taken from `d_out_absmax` (device scalar max|d_out|, required then) and scales back on the way
- * out.  (The reference trains on TF32 products, train.py:64-65.) */
+ * out.  (The reference trains on TF32 products, train.py:64-65.)
+ * `deltas16` (ABI v17, may be NULL; needs `masks` and `d_out_absmax`): 16-bit training storage -- [11,P,128] HALVES receive
+ * deltas x 2^k, k = 6 - exponent(max|d_out|) (the caller divides the weight-gradient products by 2^k), and `deltas` is then a
+ * compact [3,P,128] fp32 array that receives slices 0, 2, 4 only (the latent gradients njf_scatter_footprint reads). */
 #define NJF_RESNET_BACKWARD_CHUNKS 21
 int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, int precision, void* stream);
 int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward, int points,
                           float* deltas, float* colsum_partial, const unsigned* masks, int precision,
-                          const float* d_out_absmax, void* stream);
+                          const float* d_out_absmax, void* deltas16, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

@@ -1102,11 +1102,33 @@ struct ActDump {
   // ReLU masks (round 6): [11][P][4] words, this lane's two words of its point (+ 2*hh); layer stride = P * 4.  What the fused
   // backward chain reads instead of the activations themselves (njf_resnetfc_backward), nullptr = not dumped
   unsigned* mask = nullptr;
+  // 16-bit training storage (round 6, opt-in): `act` addresses HALVES ([11][P][128] fp16: what the weight-gradient GEMM reads with
+  // fp32 accumulation -- the reference trains on TF32 products, 10 mantissa bits as well); the stride stays a count of elements
+  bool half = false;
 };
 
+// this lane's slot of layer `l` in the activation dump (elements are floats, or halves when dump.half)
+__device__ __forceinline__ float* dump_layer(const ActDump& d, int l) {
+  if (d.act == nullptr) return nullptr;
+  return d.half ? (float*)((_Float16*)d.act + (size_t)l * d.stride) : d.act + (size_t)l * d.stride;
+}
+
 template <bool DO_RELU>
-__device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x16 (&v)[4], unsigned* __restrict__ mask = nullptr) {
+__device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x16 (&v)[4], unsigned* __restrict__ mask = nullptr,
+                                            bool half = false) {
   if (dst == nullptr) return;
+  if (half) {   // (wave-uniform) 8 stores of 16 bytes: this lane's 64 values as fp16
+    _Float16* d16 = (_Float16*)dst;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_pair_f16<DO_RELU>(v[m][8 * q + 2 * e], v[m][8 * q + 2 * e + 1]);
+        *(u32x4*)(d16 + 16 * m + 8 * q) = o;
+      }
+  } else {
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1116,6 +1138,7 @@ __device__ __forceinline__ void dump_vec128(float* __restrict__ dst, const f32x1
       for (int e = 0; e < 4; ++e) o[e] = DO_RELU ? fmaxf(v[m][4 * q + e], 0.f) : v[m][4 * q + e];
       *(f32x4*)(dst + 16 * m + 4 * q) = o;
     }
+  }
   if (mask != nullptr) {
     // bit 16*(m & 1) + r of word (m >> 1) = [v[m][r] > 0]: the ReLU mask of this lane's 64 features (8 bytes per lane and layer
     // instead of the 256 the backward chain used to read back: its loads were 1.05 of its 2.81 ms, profiles/r06_training_c4.json)
@@ -1194,7 +1217,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
       add_hoisted_latent<4, PREC>(gz + blk * 128, g, lane, h);
       NJF_STAMP(st, 5);  // gather folded into h
     }
-    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk) * dump.stride : nullptr, h, dump.mask ? dump.mask + (size_t)(2 * blk) * (dump.stride / 32) : nullptr);
+    if (DUMP) dump_vec128<true>(dump_layer(dump, 2 * blk), h, dump.mask ? dump.mask + (size_t)(2 * blk) * (dump.stride / 32) : nullptr, dump.half);
     const float* bl = bias + blk * 256;
     bias_init<4, true, PREC>(bl, hh, net);
     {
@@ -1207,7 +1230,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, h, net);
       }
     }
-    if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)(2 * blk + 1) * dump.stride : nullptr, net, dump.mask ? dump.mask + (size_t)(2 * blk + 1) * (dump.stride / 32) : nullptr);
+    if (DUMP) dump_vec128<true>(dump_layer(dump, 2 * blk + 1), net, dump.mask ? dump.mask + (size_t)(2 * blk + 1) * (dump.stride / 32) : nullptr, dump.half);
     bias_init<4, false, PREC>(bl + 128, hh, h);
     {
       {
@@ -1220,7 +1243,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
       }
     }
   }
-  if (DUMP) dump_vec128<true>(dump.act ? dump.act + (size_t)10 * dump.stride : nullptr, h, dump.mask ? dump.mask + (size_t)10 * (dump.stride / 32) : nullptr);
+  if (DUMP) dump_vec128<true>(dump_layer(dump, 10), h, dump.mask ? dump.mask + (size_t)10 * (dump.stride / 32) : nullptr, dump.half);
   bias_init<1, true, PREC>(bias + 1280, hh, out);
   {
     const float* wl = stream_step(st, wave, lane);

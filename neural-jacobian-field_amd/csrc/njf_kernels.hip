@@ -1250,8 +1250,9 @@ struct ProposalArgs {
 // this lane's share of a point's backward-pass inputs: activations / encoding (both halves), footprint (half 0)
 __device__ __forceinline__ ActDump point_dump(const NjfActivationDump& d, size_t pidx, size_t points, int hh,
                                               const PointGeom& g, int tex0, int texel_stride) {
-  ActDump dump{d.act ? d.act + pidx * 128 + 64 * hh : nullptr, d.pe + pidx * 64 + 32 * hh, points * 128,
-               d.mask ? d.mask + pidx * 4 + 2 * hh : nullptr};
+  float* act = nullptr;   // this lane's 64 values of layer 0 (floats, or halves under the 16-bit training storage)
+  if (d.act) act = d.act_f16 ? (float*)((_Float16*)d.act + pidx * 128 + 64 * hh) : d.act + pidx * 128 + 64 * hh;
+  ActDump dump{act, d.pe + pidx * 64 + 32 * hh, points * 128, d.mask ? d.mask + pidx * 4 + 2 * hh : nullptr, d.act_f16 != 0};
   if (hh == 0 && d.foot_idx != nullptr) {
     Footprint f;
     point_footprint(g, f);
@@ -1551,7 +1552,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
     if (DUMP != 0 && store) {
       const size_t points = (size_t)a.rc.total_rays * S;
       const NjfActivationDump d{DUMP == 1 ? a.out.jac_act : a.out.den_act, a.out.jac_pe, a.out.foot_idx, a.out.foot_w,
-                                DUMP == 1 ? a.out.jac_mask : a.out.den_mask};
+                                DUMP == 1 ? a.out.jac_mask : a.out.den_mask, a.out.dump_f16};
       dump = point_dump(d, si, points, hh, g, b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
       if (DUMP == 2) cdump = ColorDump{a.out.col_in + si * 32 + 16 * hh, a.out.col_act + si * 64 + 32 * hh, points * 64};
     }
@@ -2272,7 +2273,9 @@ struct BackwardArgs {
   float* deltas;        // [11, P, 128]
   float* colsum;        // [tiles, 11, 128] per-tile column sums of deltas, or nullptr
   const unsigned* masks;  // [11, P, 4] ReLU masks the training forward dumped (then `act` is not read), or nullptr
-  const float* absmax;    // PREC_F16X2 only: device scalar max|d_out| (the chain runs on gradients scaled by a power of two)
+  const float* absmax;    // device scalar max|d_out|: PREC_F16X2 (the chain runs on gradients scaled by a power of two) and deltas16
+  _Float16* deltas16;     // 16-bit training storage: [11, P, 128] halves = deltas x 2^k (k from absmax as in PREC_F16X2); `deltas`
+                          // is then [3, P, 128] and receives slices 0, 2, 4 only (the latent gradients the footprint scatter reads)
 };
 
 // Sum over the 32 points of a tile (lanes of one wave half) of every accumulator register, in DPP: rotate-and-add inside
@@ -2310,7 +2313,8 @@ __device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __res
 // chain needs the SIGN of an activation only, and reading the fp32 values back was 1.05 of the kernel's 2.81 ms on the C4 shard
 template <bool ADD, bool SCALED = false>
 __device__ __forceinline__ void mask_store(const float* __restrict__ act, const unsigned* __restrict__ mask, float* __restrict__ dst,
-                                           bool ok, f32x16 (&acc)[4], const f32x16 (&base)[4], float unscale = 1.0f) {
+                                           bool ok, f32x16 (&acc)[4], const f32x16 (&base)[4], float unscale = 1.0f,
+                                           _Float16* __restrict__ dst16 = nullptr, float scale16 = 1.0f) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   u32x2 bits = {0u, 0u};
   if (mask != nullptr && ok) bits = *(const u32x2*)mask;
@@ -2335,8 +2339,20 @@ __device__ __forceinline__ void mask_store(const float* __restrict__ act, const 
         acc[m][4 * q + e] = v;
         o[e] = SCALED ? v * unscale : v;   // (a power of two: exact)
       }
-      if (ok) *(f32x4*)(dst + 16 * m + 4 * q) = o;
+      if (ok && dst != nullptr) *(f32x4*)(dst + 16 * m + 4 * q) = o;
     }
+  if (dst16 != nullptr && ok) {   // (wave-uniform) the same values x 2^k as fp16: 8 stores of 16 bytes
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_pair_f16<false>(acc[m][8 * q + 2 * e] * scale16, acc[m][8 * q + 2 * e + 1] * scale16);
+        *(u32x4*)(dst16 + 16 * m + 8 * q) = o;
+      }
+  }
 }
 
 template <int PREC>
@@ -2363,17 +2379,24 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
   // the smaller ones contribute to a weight gradient is below that in absolute terms); results are scaled back on the way out
   // (powers of two: exact).  The reference itself trains on TF32 products (train.py:64-65: 10 mantissa bits).
   constexpr bool SCALED = PREC != PREC_F32;
-  float scale = 1.0f, unscale = 1.0f;
-  if constexpr (SCALED) {
+  float scale = 1.0f, unscale = 1.0f;   // of the chain's own arithmetic
+  float pow2 = 1.0f;                    // 2^k of max|d_out| (what the fp16 deltas are scaled by, in either product form)
+  if (SCALED || a.deltas16 != nullptr) {
     const float mx = a.absmax ? *a.absmax : 0.f;
     if (mx > 0.f && mx < 3.0e38f) {
       int e;
       frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)
       const int k = max(min(6 - e, 120), -120);
-      scale = ldexpf(1.0f, k);
-      unscale = ldexpf(1.0f, -k);
+      pow2 = ldexpf(1.0f, k);
+      if (SCALED) {
+        scale = pow2;
+        unscale = ldexpf(1.0f, -k);
+      }
     }
   }
+  const float scale16 = SCALED ? 1.0f : pow2;   // the accumulators already carry 2^k in the split-precision form
+  _Float16* out16 = a.deltas16 ? a.deltas16 + pc * 128 + 64 * hh : nullptr;
+  const bool compact = a.deltas16 != nullptr;   // fp32 deltas: slices 0, 2, 4 only, stored as [3, P, 128]
   f32x16 din[1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -2387,7 +2410,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
     const float* wl = stream_step(st, wave, lane);
     mma_chunk<PREC, 4, 1, 0, false, 1>(st, wl, lane, din, delta);   // lin_out^T (first half of the chunk)
   }
-  mask_store<false, SCALED>(act + 10 * layer, msk ? msk + 10 * mlayer : nullptr, out + 10 * layer, ok, delta, delta, unscale);
+  mask_store<false, SCALED>(act + 10 * layer, msk ? msk + 10 * mlayer : nullptr, compact ? nullptr : out + 10 * layer, ok, delta, delta,
+                            unscale, out16 ? out16 + 10 * layer : nullptr, scale16);
   const bool live = tile * 32 < a.points;  // wave-uniform
   if (sums && live) tile_colsum(delta, sums + 10 * 128, lane, unscale);
   for (int blk = 4; blk >= 0; --blk) {
@@ -2402,7 +2426,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, delta, t);
     }
     mask_store<false, SCALED>(act + (size_t)(2 * blk + 1) * layer, msk ? msk + (size_t)(2 * blk + 1) * mlayer : nullptr,
-                              out + (size_t)(2 * blk + 1) * layer, ok, t, t, unscale);
+                              compact ? nullptr : out + (size_t)(2 * blk + 1) * layer, ok, t, t, unscale,
+                              out16 ? out16 + (size_t)(2 * blk + 1) * layer : nullptr, scale16);
     if (sums && live) tile_colsum(t, sums + (2 * blk + 1) * 128, lane, unscale);
 #pragma unroll
     for (int m = 0; m < 4; ++m) u[m] = (f32x16)(0.f);
@@ -2415,7 +2440,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) resnetfc_backward_kernel(Backw
       mma_chunk<PREC, 4, 2, 2, false, 4>(st, wl, lane, t, u);
     }
     mask_store<true, SCALED>(act + (size_t)(2 * blk) * layer, msk ? msk + (size_t)(2 * blk) * mlayer : nullptr,
-                             out + (size_t)(2 * blk) * layer, ok, u, delta, unscale);
+                             compact ? (blk < 3 ? out + (size_t)blk * layer : nullptr) : out + (size_t)(2 * blk) * layer, ok, u, delta,
+                             unscale, out16 ? out16 + (size_t)(2 * blk) * layer : nullptr, scale16);
     if (sums && live) tile_colsum(u, sums + (2 * blk) * 128, lane, unscale);
 #pragma unroll
     for (int m = 0; m < 4; ++m) delta[m] = u[m];
@@ -2768,7 +2794,7 @@ extern "C" int njf_proposal_forward(const float* origins, const float* direction
   a.bins_out = bins_out;
   a.weights_out = weights_out;
   a.density_out = density_out;
-  a.dump = NjfActivationDump{nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.dump = NjfActivationDump{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (dump != nullptr && dump->act != nullptr) {  // training forward: inputs of the proposal net's backward pass
     if (!dump->pe || !dump->foot_idx || !dump->foot_w) return NJF_E_NULL;
     a.dump = *dump;
@@ -2916,11 +2942,12 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
 
 extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward,
                                      int points, float* deltas, float* colsum_partial, const unsigned* masks, int precision,
-                                     const float* d_out_absmax, void* stream) {
+                                     const float* d_out_absmax, void* deltas16, void* stream) {
   if (!d_out || (!activations && !masks) || !w_backward || !deltas) return NJF_E_NULL;
+  if (deltas16 && (!masks || !d_out_absmax)) return NJF_E_NULL;   // the 16-bit storage form reads masks and needs the scale
   if (points < 1 || (long long)points * 11 * 128 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
-  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial, masks, d_out_absmax};
+  BackwardArgs a{d_out, d_out_dim, activations, w_backward, points, deltas, colsum_partial, masks, d_out_absmax, (_Float16*)deltas16};
   if (precision == NJF_PRECISION_F16X2) {
     if (!d_out_absmax) return NJF_E_NULL;
     return launch_fused(resnetfc_backward_kernel<PREC_F16X2>, a, (points + 31) / 32, (hipStream_t)stream);

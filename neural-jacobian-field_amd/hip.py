@@ -98,7 +98,7 @@ class RenderOutputs(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "rgb", "depth", "step_minmax", "flow", "pos", "pos_warped", "action_features",
         "weights", "density", "color", "sample_flow", "jacobian", "jac_act", "jac_pe", "foot_idx", "foot_w",
-        "den_act", "col_in", "col_act", "frame_partials", "trgt_rgb", "trgt_flow", "jac_mask", "den_mask")]
+        "den_act", "col_in", "col_act", "frame_partials", "trgt_rgb", "trgt_flow", "jac_mask", "den_mask")] + [("dump_f16", C.c_int)]
 
 
 class PyramidLevel(C.Structure):
@@ -106,7 +106,7 @@ class PyramidLevel(C.Structure):
 
 
 class ActivationDump(C.Structure):
-    _fields_ = [("act", _vp), ("pe", _vp), ("foot_idx", _vp), ("foot_w", _vp), ("mask", _vp)]
+    _fields_ = [("act", _vp), ("pe", _vp), ("foot_idx", _vp), ("foot_w", _vp), ("mask", _vp), ("act_f16", C.c_int)]
 
 
 _lib = None
@@ -137,7 +137,7 @@ _SIGNATURES = {
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, C.c_int, _vp], C.c_int),
-    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
+    "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
@@ -502,8 +502,10 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
     rays_per_batch = origins.shape[1]
     dump_ref = None
     if dump is not None:
-        dump_ref = C.byref(ActivationDump(_ptr(dump["act"]), _ptr(dump["pe"]), _int_ptr(dump["foot_idx"]),
-                                          _ptr(dump["foot_w"]), _int_ptr(dump["mask"]) if dump.get("mask") is not None else None))
+        half = dump["act"].dtype == torch.float16   # 16-bit training storage (training.set_storage_precision)
+        dump_ref = C.byref(ActivationDump(_ptr(dump["act"], "act", dump["act"].dtype), _ptr(dump["pe"]), _int_ptr(dump["foot_idx"]),
+                                          _ptr(dump["foot_w"]), _int_ptr(dump["mask"]) if dump.get("mask") is not None else None,
+                                          int(half)))
     _note_device(cams, "cameras")
     _note_device(fmap, "feature map")
     _check_map_dtype(fmap, precision)
@@ -521,12 +523,19 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
     (default: ``precision``) is the MFMA precision the Jacobian head's blob was packed for."""
     rays_per_batch = origins.shape[1]
     out = RenderOutputs()
+    dump_f16 = 0
     for name, _ in RenderOutputs._fields_:
+        if name == "dump_f16":
+            continue
         t = outputs.get(name)
         if name in ("foot_idx", "jac_mask", "den_mask") and t is not None:  # the int32 outputs
             setattr(out, name, _int_ptr(t))
+        elif name in ("jac_act", "den_act") and t is not None and t.dtype == torch.float16:   # 16-bit training storage
+            setattr(out, name, _ptr(t, name, torch.float16))
+            dump_f16 = 1
         else:
             setattr(out, name, _ptr(t, name))
+    out.dump_f16 = dump_f16
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS
     with_j = jacobian_kind != JACOBIAN_NONE
@@ -614,6 +623,34 @@ def pack_resnetfc_backward(params: Dict[str, torch.Tensor], prefix: str, w_out: 
             PRECISIONS[precision])
 
 
+def power_of_two_unscale(absmax: torch.Tensor) -> torch.Tensor:
+    """2^-k for the k = 6 - exponent(max|d_out|) that njf_resnetfc_backward scales by (device-side, no host round trip)."""
+    _, e = torch.frexp(absmax)                      # absmax = f * 2^e, f in [0.5, 1): the kernel's frexpf
+    k = torch.clamp(6 - e, -120, 120)
+    ok = (absmax > 0) & (absmax < 3.0e38)
+    return torch.where(ok, torch.ldexp(torch.ones_like(absmax), -k), torch.ones_like(absmax))
+
+
+def resnetfc_backward_f16_storage(d_out: torch.Tensor, w_backward: torch.Tensor, mask: torch.Tensor, precision: str = "f32"):
+    """The chain under the 16-bit training storage: -> (latent deltas [3,P,128] fp32 = slices 0, 2, 4, deltas16 [11,P,128] fp16 =
+    deltas x 2^k, column sums [11,128] fp32, 2^-k as a device scalar)."""
+    points = d_out.shape[0]
+    if tuple(mask.shape) != (11, points, 4) or w_backward.numel() != RESNET_BACKWARD_W_FLOATS:
+        raise ValueError("njf_hip: resnetfc_backward shape mismatch")
+    if precision not in BACKWARD_PRECISIONS:
+        raise ValueError(f"njf_hip: backward precision must be one of {BACKWARD_PRECISIONS} (got {precision!r})")
+    dev = d_out.device
+    latent = torch.empty(3, points, 128, dtype=torch.float32, device=dev)
+    deltas16 = torch.empty(11, points, 128, dtype=torch.float16, device=dev)
+    partial = torch.empty((points + 31) // 32, 11, 128, dtype=torch.float32, device=dev)
+    d_out = d_out.contiguous()
+    absmax = d_out.abs().amax().reshape(1)
+    _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out, "d_out"), d_out.shape[1], None,
+            _ptr(w_backward, "w_backward"), points, _ptr(latent, "deltas"), _ptr(partial, "colsum_partial"), _int_ptr(mask),
+            PRECISIONS[precision], _ptr(absmax, "d_out_absmax"), _ptr(deltas16, "deltas16", torch.float16))
+    return latent, deltas16, partial.sum(0), power_of_two_unscale(absmax)
+
+
 def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.Tensor, want_colsum: bool = False,
                       mask: Optional[torch.Tensor] = None, precision: str = "f32"):
     """deltas [11,P,128] of one ResnetFC's backward pass (include/njf_hip.h: njf_resnetfc_backward): d_out [P,d_out],
@@ -634,7 +671,7 @@ def resnetfc_backward(d_out: torch.Tensor, act: torch.Tensor, w_backward: torch.
     absmax = d_out.abs().amax().reshape(1) if precision == "f16x2" else None
     _launch("njf_resnetfc_backward", load_library().njf_resnetfc_backward, _ptr(d_out, "d_out"), d_out.shape[1],
             _ptr(act, "act"), _ptr(w_backward, "w_backward"), points, _ptr(deltas, "deltas"), _ptr(partial, "colsum_partial"),
-            _int_ptr(mask) if mask is not None else None, PRECISIONS[precision], _ptr(absmax, "d_out_absmax"))
+            _int_ptr(mask) if mask is not None else None, PRECISIONS[precision], _ptr(absmax, "d_out_absmax"), None)
     return (deltas, partial.sum(0)) if want_colsum else deltas
 
 

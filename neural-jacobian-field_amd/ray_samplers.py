@@ -260,7 +260,8 @@ class ProposalNetworkSampler(Sampler):
             if dump_out is not None:
                 pts = b * r * s_in
                 sigma = torch.empty(b, r, s_in, dtype=torch.float32, device=dev)
-                dump = {"act": torch.empty(11, pts, 128, dtype=torch.float32, device=dev),
+                from . import training as _tr   # (fp16 under the opt-in 16-bit training storage)
+                dump = {"act": torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(), device=dev),
                         "pe": torch.empty(pts, 64, dtype=torch.float32, device=dev),
                         "foot_idx": torch.empty(pts, 4, dtype=torch.int32, device=dev),
                         "foot_w": torch.empty(pts, 4, dtype=torch.float32, device=dev),

@@ -95,6 +95,41 @@ def backward_precision() -> str:
     return _BACKWARD_PRECISION
 
 
+# Storage of what the weight-gradient GEMMs read (the K = points contractions deltas[l+1]^T act[l]: 2.95 GB per network and operand
+# on SURVEY's C4 shard).  "f32" (default): fp32 activations from the training forward, fp32 deltas from the chain, fp32 GEMMs.
+# "f16" (opt-in): the forward dumps the activations as fp16, the chain writes deltas x 2^k as fp16 (k from max|d_out|; its masks make
+# it independent of the activations' format), and the GEMMs run with fp16 operands and FP32 ACCUMULATION (torch.bmm(..., out_dtype=
+# float32)) -- 10 mantissa bits per operand, which is what the reference's own training arithmetic keeps (TF32: train.py:64-65).
+# Stated tolerance: tests/test_training_gpu.py::test_f16_training_storage_against_fp32_storage.
+_STORAGE_PRECISION = os.environ.get("NJF_TRAINING_STORAGE", "f32")
+
+
+def set_storage_precision(name: str) -> None:
+    global _STORAGE_PRECISION
+    if name not in ("f32", "f16"):
+        raise ValueError(f"training storage must be 'f32' or 'f16' (got {name!r})")
+    _STORAGE_PRECISION = name
+
+
+def storage_precision() -> str:
+    return _STORAGE_PRECISION
+
+
+def activation_dump_dtype() -> torch.dtype:
+    return torch.float16 if _STORAGE_PRECISION == "f16" else torch.float32
+
+
+def _tn_batched_f16(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
+    """a[l]^T b[l] for fp16 operands [L,K,128] with fp32 accumulation and fp32 results (K split into groups as in _tn_batched)."""
+    layers, k, n = a16.shape
+    groups = 64
+    while groups > 1 and (k % groups or k // groups < 256):
+        groups //= 2
+    out = torch.bmm(a16.reshape(layers * groups, k // groups, n).transpose(1, 2), b16.reshape(layers * groups, k // groups, -1),
+                    out_dtype=torch.float32)
+    return out.reshape(layers, groups, n, -1).sum(1)
+
+
 def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, want_colsum: bool = False,
                             mask: torch.Tensor = None):
     """The data-gradient chain of one ResnetFC as ONE fused launch (njf_resnetfc_backward): deltas [11,P,128], see
@@ -124,25 +159,39 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     with; the weight gradients themselves are sums over ALL points of outer products (K = points) and are one batched
     library GEMM on those matrices; the bias gradients one column-sum reduction."""
     grads: Dict[str, torch.Tensor] = {}
-    deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True, mask=mask)   # sums [11,128]: deltas[l+1] <-> bias of layer l
-    w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
+    if act.dtype == torch.float16:
+        # 16-bit training storage: fp16 activations (dumped by the forward) x fp16 deltas (scaled by 2^k), fp32 accumulation
+        if mask is None:
+            raise ValueError("the 16-bit training storage needs the forward's ReLU masks")
+        w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
+        hip.pack_resnetfc_backward(p, "", w_t, precision=_BACKWARD_PRECISION)
+        latent, deltas16, sums, unscale = hip.resnetfc_backward_f16_storage(d_out, w_t, mask, precision=_BACKWARD_PRECISION)
+        w_grads = _tn_batched_f16(deltas16[1:11], act[0:10]) * unscale
+        deltas_latent = latent                                        # [3,P,128]: gradients w.r.t. the three hoisted latents
+        delta0 = latent[0]
+        grads["lin_out.weight"] = _tn(d_out, act[10].float())
+    else:
+        deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True, mask=mask)   # sums [11,128]: deltas[l+1] <-> bias of layer l
+        w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
+        deltas_latent = deltas[0:6:2]
+        delta0 = deltas[0]
+        grads["lin_out.weight"] = _tn(d_out, act[10])
     for l, name in enumerate(_LAYER_NAMES):
         grads[name + ".weight"] = w_grads[l]
         grads[name + ".bias"] = sums[l + 1]
-    grads["lin_out.weight"] = _tn(d_out, act[10])
     grads["lin_out.bias"] = d_out.sum(0)
     # lin_z[blk](bilinear(F)) was added to h in front of block blk: its gradient is deltas[2 blk].  grid_sample's input
     # gradient of all three latents is ONE launch into [T,384] (points are ray-major: neighbouring samples share texels),
     # the three weight gradients one GEMM against the channels-last features
-    d_g = torch.zeros(feats_flat.shape[0], 3 * 128, dtype=deltas.dtype, device=deltas.device)
-    hip.scatter_footprint(deltas[0:6:2], foot_idx, foot_w, d_g, run_length=samples_per_ray)
+    d_g = torch.zeros(feats_flat.shape[0], 3 * 128, dtype=torch.float32, device=d_out.device)
+    hip.scatter_footprint(deltas_latent, foot_idx, foot_w, d_g, run_length=samples_per_ray)
     wz_grad = _tn(d_g, feats_flat)                                   # [384,512]
     for blk in range(3):
         grads[f"lin_z.{blk}.weight"] = wz_grad[128 * blk:128 * (blk + 1)]
         grads[f"lin_z.{blk}.bias"] = sums[2 * blk]
     if d_feats is not None:
         d_feats.addmm_(d_g, torch.cat([p[f"lin_z.{blk}.weight"] for blk in range(3)]))
-    d_in = _tn(deltas[0], pe)  # [128, 64] in slot order
+    d_in = _tn(delta0, pe)  # [128, 64] in slot order
     grads["lin_in.weight"] = d_in.new_zeros(d_in.shape[0], 63).index_copy_(
         1, _slot_to_channel(d_in.device), d_in[:, :63])
     grads["lin_in.bias"] = d_in[:, 63].clone()

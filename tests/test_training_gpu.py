@@ -576,3 +576,67 @@ def test_backward_chain_f16x2_against_exact():
         for l in range(11):
             assert rel(got[l], ref[l]) < 2e-5, (scale, l, rel(got[l], ref[l]))
             assert rel(got_sums[l], ref_sums[l]) < 2e-5, (scale, l)
+
+
+@pytest.mark.parametrize("mode", ["action", "perception"])
+def test_f16_training_storage_against_fp32_storage(mode):
+    """The opt-in 16-bit training storage (training.set_storage_precision("f16"): fp16 activation dumps, fp16 deltas x 2^k, weight-
+    gradient GEMMs with fp32 accumulation) against the default fp32 storage on the SAME batch and weights, with a 'precomputed'
+    encoder and un-jittered sampling so that the two forwards are the same bits (MIOpen's convolutions are not run-to-run
+    reproducible, and the flow's conditioning turns that into per-cent differences between ANY two runs).  Then
+
+        * loss and pixels identical (the dumps' format does not enter the forward arithmetic);
+        * every weight gradient contracted from 16-bit operands within  max |g16 - g32| <= 2e-3 x max |g32|  (operands rounded to
+          11 significant bits; the reference's own training arithmetic, TF32, rounds to the same 11 bits: train.py:64-65);
+        * what the chain itself produces in fp32 -- bias gradients (column sums of deltas), lin_z and lin_in weights -- within 1e-5."""
+    from neural_jacobian_field_amd import model_wrapper as mw, synthetic, training
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.model import CameraInput, Model, ModelTarget, RenderingInput, RobotInput
+    dev = torch.device("cuda:0")
+    B, H, W, R, S, A = 2, 64, 64, 256, 64, 8
+    b = synthetic.synthetic_training_batch(B, H, W, R, A, seed=5, device=dev)
+    feats = synthetic.synthetic_features(B, H, W, seed=3).to(dev)
+    cam = CameraInput(None, b["ctxt_c2w"], b["ctxt_k_norm"], b["trgt_c2w"], b["trgt_k_pix"])
+    rin = RenderingInput(b["origins"], b["directions"], b["z_near"], b["z_far"])
+    rob = RobotInput(b["action"])
+    ptarget = ModelTarget(rgb=b["target_rgb"], depth=b["target_depth"], optical_flow=None, visible_mask=None)
+    grads, losses, pixels = {}, {}, {}
+    try:
+        for storage in ("f32", "f16"):
+            training.set_storage_precision(storage)
+            model = Model(model_cfg_from_dict({"action_dim": A, "encoder": {"name": "precomputed"},
+                                               "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
+                                               "action_decoder": {"name": "jacobian_mlp"}}))
+            model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", A, with_encoder=False), seed=0))
+            model.to(dev).train()
+            model.encoder.set_features(feats)
+            if mode == "action":
+                model.decoder.freeze_non_action_parameters()
+                for n, p in model.named_parameters():
+                    if "decoder" not in n:
+                        p.requires_grad = False
+            for smp in (model.proposal_sampler.initial_sampler, model.proposal_sampler.pdf_sampler):
+                smp.train_stratified = False
+            model.step_before_iter(20000)
+            out = model.forward(cam, rin, rob)
+            if mode == "action":
+                loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, b["target_flow"])
+            else:
+                tr = out.training_output
+                loss = (mw.rgb_loss(out, ptarget) + mw.depth_loss(out, ptarget) + mw.interlevel_loss(tr.weights_list, tr.ray_samples_list)
+                        + 0.01 * mw.distortion_loss(tr.weights_list, tr.ray_samples_list))
+            loss.backward()
+            torch.cuda.synchronize()
+            losses[storage] = float(loss.detach())
+            pixels[storage] = out.standard_output.optical_flow.detach().clone()
+            grads[storage] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        training.set_storage_precision("f32")
+    assert losses["f16"] == losses["f32"] and torch.equal(pixels["f16"], pixels["f32"]), losses
+    assert set(grads["f16"]) == set(grads["f32"]) and len(grads["f32"]) > 0
+    worst = {n: rel(grads["f16"][n], g32) for n, g32 in grads["f32"].items()}
+    bad = {n: v for n, v in worst.items() if not v <= 2e-3}
+    assert not bad, bad
+    fp32_made = {n: v for n, v in worst.items() if ("density_head" in n or "jacobian_head" in n) and
+                 (n.endswith(".bias") or ".lin_z." in n or ".lin_in." in n)}
+    assert fp32_made and all(v <= 1e-5 for v in fp32_made.values()), fp32_made

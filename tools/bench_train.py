@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--backward-precision", choices=["f32", "f16x2"], default="f32",
                     help="product form of the fused backward chain (training.set_backward_precision): exact fp32 (default) or split fp16 "
                          "on scaled gradients (fp32-class; the reference trains on TF32 products)")
+    ap.add_argument("--storage", choices=["f32", "f16"], default="f32",
+                    help="what the weight-gradient GEMMs read (training.set_storage_precision): fp32 activations / deltas (default) or fp16 "
+                         "ones with fp32 accumulation (the reference trains on TF32 products)")
     args = ap.parse_args()
     mode = args.mode or args.mode_pos or "action"
     launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -63,6 +66,7 @@ def main():
 
     from neural_jacobian_field_amd import model_wrapper as mw, synthetic, training
     training.set_backward_precision(args.backward_precision)
+    training.set_storage_precision(args.storage)
     from neural_jacobian_field_amd.config import model_cfg_from_dict
     from neural_jacobian_field_amd.model import CameraInput, Model, ModelTarget, RenderingInput, RobotInput
     from neural_jacobian_field_amd.parallel import data_parallel_step
@@ -150,7 +154,9 @@ def main():
                 "mode": {"action": "action (Jacobian head only), encoder fwd included",
                          "perception": "perception (all parameters), encoder fwd+bwd included"}[mode],
                 "dtype": "forward: package default precision; backward chain: "
-                         + ("exact fp32 MFMA" if args.backward_precision == "f32" else "f16x2 (split fp16 products on power-of-two-scaled gradients)"),
+                         + ("exact fp32 MFMA" if args.backward_precision == "f32" else "f16x2 (split fp16 products on power-of-two-scaled gradients)")
+                         + ("; weight-gradient GEMMs: fp32 operands" if args.storage == "f32" else
+                            "; weight-gradient GEMMs: fp16 activations x fp16 scaled deltas, fp32 accumulation (16-bit training storage)"),
                 "data": "synthetic",
                 "config": {"workload": "C4: Allegro training step, ray-batch DP, one flattened gradient all-reduce per step",
                            "parallelism": f"dp{world}"},
