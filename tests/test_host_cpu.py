@@ -566,8 +566,9 @@ def test_ctypes_structs_match_the_header():
     for name, mirror in pairs.items():
         assert fields(name) == [f[0] for f in mirror._fields_], name
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    stub = re.search(r"class RenderOutputs\(C\.Structure\):.*?_fields_ = \[\(n, vp\) for n in \((.*?)\)\]", doc, flags=re.S).group(1)
-    assert re.findall(r'"(\w+)"', stub) == fields("NjfRenderOutputs")
+    m = re.search(r"class RenderOutputs\(C\.Structure\):.*?_fields_ = \[\(n, vp\) for n in \((.*?)\)\]( \+ \[(.*?)\])?", doc, flags=re.S)
+    names = re.findall(r'"(\w+)"', m.group(1)) + re.findall(r'"(\w+)"', m.group(3) or "")   # pointer fields + trailing int fields
+    assert names == fields("NjfRenderOutputs")
 
 
 def test_jacobian_colour_mapping_matches_reference_golden(golden):
