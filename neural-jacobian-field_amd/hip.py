@@ -502,6 +502,8 @@ def proposal_forward(origins, directions, cams: Cameras, fmap: FeatureMap, gmap_
     rays_per_batch = origins.shape[1]
     dump_ref = None
     if dump is not None:
+        if dump["act"].dtype not in (torch.float32, torch.float16):
+            raise ValueError(f"njf_hip: activation dumps are float32 or float16 (got {dump['act'].dtype})")
         half = dump["act"].dtype == torch.float16   # 16-bit training storage (training.set_storage_precision)
         dump_ref = C.byref(ActivationDump(_ptr(dump["act"], "act", dump["act"].dtype), _ptr(dump["pe"]), _int_ptr(dump["foot_idx"]),
                                           _ptr(dump["foot_w"]), _int_ptr(dump["mask"]) if dump.get("mask") is not None else None,
