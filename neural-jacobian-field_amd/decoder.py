@@ -282,13 +282,13 @@ class ActionDecoderJacobian(ActionDecoder):
             return "jacobian_head_arm."
         return "jacobian_head." if isinstance(getattr(self, "jacobian_head", None), ResnetFC) else ""
 
-    def _init_common(self, cfg, action_dim: int, encoder_dim: int, max_action: int):
+    def _init_common(self, cfg, action_dim: int, encoder_dim: int, max_action: int, max_arm_action: int = hip.MAX_ACTION_DIM):
         n_freq = cfg.num_frequncies if hasattr(cfg, "num_frequncies") else cfg.num_frequencies
         if n_freq != 10 or cfg.geometry_feature_dim != 15:
             raise ValueError("fused path supports num_frequencies=10 and geometry_feature_dim=15")
         arm = getattr(cfg, "use_arm_model", False)
-        if arm and not (cfg.arm_action_dim is not None and 1 <= cfg.arm_action_dim <= hip.MAX_ACTION_DIM):
-            raise ValueError(f"use_arm_model needs arm_action_dim in [1, {hip.MAX_ACTION_DIM}]")
+        if arm and not (cfg.arm_action_dim is not None and 1 <= cfg.arm_action_dim <= max_arm_action):
+            raise ValueError(f"use_arm_model needs arm_action_dim in [1, {max_arm_action}]")
         self.arm_action_dim = cfg.arm_action_dim if arm else None
         if not (1 <= action_dim <= max_action):
             raise ValueError(f"action_dim must be in [1, {max_action}] for {cfg.name}")
@@ -331,7 +331,7 @@ class ActionDecoderJacobian(ActionDecoder):
             raise ValueError(f"mode must be 'regular' or 'arm', not {mode!r}")
         if mode == "arm":
             if self.arm_action_dim is None:
-                raise AttributeError("switch_mode('arm'): this decoder was built without use_arm_model (no jacobian_head_arm)")
+                raise AttributeError("switch_mode('arm'): this decoder was built without use_arm_model (no arm head)")
             if self.arm_action_dim != self.action_dim:
                 raise ValueError(f"switch_mode('arm'): arm_action_dim = {self.arm_action_dim} but compute_flow contracts the head's "
                                  f"output with the {self.action_dim}-dimensional robot action (action_decoder_jacobian.py:134-140)")
@@ -340,6 +340,11 @@ class ActionDecoderJacobian(ActionDecoder):
     # ---- packed state ----------------------------------------------------------------
     def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):  # pragma: no cover - abstract
         raise NotImplementedError
+
+    def _jacobian_sub_version(self, params):
+        heads = ("density_head.", "color_head.")
+        return tuple((p.data_ptr(), p._version) for k, p in params.items()
+                     if not k.startswith(heads) and k.startswith("jacobian_head_arm.") == (self.mode == "arm"))
 
     def _pack_jacobian(self, params, w_j, b_j, wz, bz):
         if self.mode == "arm":
@@ -370,9 +375,7 @@ class ActionDecoderJacobian(ActionDecoder):
             subs = {"density": (self.precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(heads[0])),
                     "color": (self.precision,) + tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(heads[1])),
                     # the ACTIVE head's parameters only: training one head must not re-pack on the other's (frozen) values
-                    "jacobian": (self.j_precision, self.mode) + tuple(
-                        (p.data_ptr(), p._version) for k, p in params.items()
-                        if not k.startswith(heads) and k.startswith("jacobian_head_arm.") == (self.mode == "arm"))}
+                    "jacobian": (self.j_precision, self.mode) + self._jacobian_sub_version(params)}
             if subs["density"] != self._sub_versions.get("density"):
                 hip.pack_resnetfc(params, heads[0], self._w[:n], self._bd, self._wz, 0, self._bz, precision=self.precision)
             if subs["color"] != self._sub_versions.get("color"):
@@ -496,10 +499,15 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
     the hoisted map (``hoisted_map`` adds it to the flow head's 384 channels).  The kernel then runs the flow head as a
     "Jacobian head" with ONE action channel contracted with the constant 1.0, which returns its three outputs unchanged.
 
+    ``use_arm_model`` registers ``flow_head_arm = ResnetFC(d_latent = encoder_dim + arm_action_dim)`` (:109-116);
+    ``switch_mode("arm")`` routes compute_flow through it (:163-166).  compute_flow concatenates the robot action itself
+    (:168-172), so the reference only runs in arm mode when arm_action_dim == action_dim -- checked in ``switch_mode``.
+    The active flow head trains in the reference's action mode (``action_param_glob_pattern = "flow_head"``; training.py).
+
     Not offered (and why): ``encode_image`` (the reference's own version returns a ``map`` object that
-    ``Model.encode_image`` cannot consume, action_decoder_flow.py:246-279), ``use_arm_model``, training of the flow
-    head, and the 640-channel hidden ``action_features`` of ``DecoderOutput`` (nothing in the reference reads them for
-    this decoder; ``DecoderOutput.action_features`` is None and the composited visualisation slot holds the scene flow).
+    ``Model.encode_image`` cannot consume, action_decoder_flow.py:246-279) and the 640-channel hidden ``action_features``
+    of ``DecoderOutput`` (nothing in the reference reads them for this decoder; ``DecoderOutput.action_features`` is None
+    and the composited visualisation slot holds the scene flow).
     """
 
     action_param_glob_pattern = "flow_head"
@@ -507,14 +515,23 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
 
     def __init__(self, cfg: ActionDecoderFlowMlpCfg, action_dim: int, encoder_dim: int):
         super().__init__(cfg)
-        if cfg.use_arm_model:   # flow_head_arm (action_decoder_flow.py:109-116): part of an ablation decoder no config ships
-            raise NotImplementedError("flow_mlp with use_arm_model (flow_head_arm) is not part of the fused path; the Jacobian "
-                                      "decoders implement their arm head (jacobian_head_arm)")
-        self._init_common(cfg, action_dim, encoder_dim, 1 << 16)  # the kernel sees one channel, any A works
+        self._init_common(cfg, action_dim, encoder_dim, 1 << 16, 1 << 16)  # the kernel sees one channel, any A works
         self.flow_head = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim, extra_latent=action_dim)
         self.flow_head.apply(initialize_flow_weights)
+        if self.arm_action_dim is not None:   # action_decoder_flow.py:109-116 (registered between flow_head and color_head)
+            self.flow_head_arm = ResnetFC(cfg.mlp, d_in=63, d_latent=encoder_dim, d_out=self.spatial_dim,
+                                          extra_latent=self.arm_action_dim)
+            self.flow_head_arm.apply(initialize_flow_weights)
         self.color_head = self._make_color_head(cfg)
         self._ones = None
+
+    @property
+    def active_head_prefix(self) -> str:
+        return "flow_head_arm." if self.mode == "arm" else "flow_head."
+
+    @property
+    def active_head(self) -> ResnetFC:
+        return self.flow_head_arm if self.mode == "arm" else self.flow_head
 
     @property
     def kernel_action_dim(self) -> int:
@@ -525,20 +542,27 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
             self._ones = torch.ones(action.shape[0], 1, dtype=torch.float32, device=action.device)
         return self._ones
 
-    def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):
-        enc_dim = self.flow_head.d_latent - self.action_dim
+    def _jacobian_sub_version(self, params):
+        """The ACTIVE flow head's parameters (both heads' names start with "flow_head")."""
+        prefix = self.active_head_prefix
+        return tuple((p.data_ptr(), p._version) for k, p in params.items() if k.startswith(prefix))
+
+    def _pack_jacobian(self, params, w_j, b_j, wz, bz):
+        prefix = self.active_head_prefix
+        enc_dim = self.active_head.d_latent - self.action_dim
         sliced = dict(params)
         for i in range(3):  # the kernels hoist the 512 feature columns; the action columns become a bias (hoisted_map)
-            sliced[f"flow_head.lin_z.{i}.weight"] = params[f"flow_head.lin_z.{i}.weight"][:, :enc_dim].contiguous()
-        hip.pack_resnetfc(sliced, "flow_head.", w_j, b_j, wz, hip.ZDIM, bz, precision=self.j_precision)
+            sliced[f"{prefix}lin_z.{i}.weight"] = params[f"{prefix}lin_z.{i}.weight"][:, :enc_dim].contiguous()
+        hip.pack_resnetfc(sliced, prefix, w_j, b_j, wz, hip.ZDIM, bz, precision=self.j_precision)
 
     @torch.no_grad()
     def hoisted_map(self, features: torch.Tensor, action: Optional[torch.Tensor] = None) -> torch.Tensor:
         base = super().hoisted_map(features)
         if action is None:
             raise ValueError("flow_mlp: the hoisted map depends on the robot action (PixelEncoding.action)")
-        enc_dim = self.flow_head.d_latent - self.action_dim
-        w_a = torch.stack([lin.weight[:, enc_dim:] for lin in self.flow_head.lin_z])       # [3,128,A]
+        head = self.active_head
+        enc_dim = head.d_latent - self.action_dim
+        w_a = torch.stack([lin.weight[:, enc_dim:] for lin in head.lin_z])                   # [3,128,A]
         delta = torch.einsum("lfa,ba->blf", w_a, action.to(w_a.dtype))                       # [B,3,128] logical order
         pos = hip.hoisted_channel_order(128, delta.device, self.j_precision)                 # njf_hoisted_channel
         permuted = torch.empty_like(delta)

@@ -547,7 +547,7 @@ class Model(nn.Module):
     def forward(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,
                 compute_vis_features: bool = False) -> ModelOutput:
         """model.py:316-396.  With gradients enabled and trainable parameters (reference action mode: only the
-        Jacobian head, model_wrapper.py:75-85) ``optical_flow`` carries an autograd graph (training.py); every other
+        Jacobian head -- the flow head of ``flow_mlp`` --, model_wrapper.py:75-85) ``optical_flow`` carries an autograd graph (training.py); every other
         output, and every call under ``torch.no_grad()`` / with frozen parameters, is a plain inference pass."""
         self._maybe_check_range(camera_input, rendering_input, robot_input)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -557,10 +557,6 @@ class Model(nn.Module):
                 raise RuntimeError(f"the {reduced[0]!r} MFMA precision is an inference mode (no training forward exists for it: "
                                    "activations rounded to fp16 are not the inputs a backward pass may use); call "
                                    "model.set_precision('f16f6') / ('f32') for training, or run under torch.no_grad()")
-            if self.cfg.action_decoder.name == "flow_mlp" and any(
-                    n.startswith("decoder.flow_head") for n in training.trainable_names(self)):
-                raise NotImplementedError("flow_mlp is an inference-only decoder on the fused path: its flow head has no "
-                                          "backward pass here (freeze decoder.flow_head or call under torch.no_grad())")
             if training.is_action_mode(self):
                 return self._forward_action_grad(camera_input, rendering_input, robot_input, compute_vis_features)
             return self._forward_perception_grad(camera_input, rendering_input, robot_input, compute_vis_features)

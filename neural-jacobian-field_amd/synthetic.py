@@ -60,7 +60,9 @@ def decoder_shapes(kind: str, action_dim: int, encoder_dim: int = 512, pe_dim: i
     (models/decoder/action_decoder_jacobian.py:261-322, :340-416); ``arm_action_dim``: the second head of ``use_arm_model``
     (:306-313, :400-407)."""
     out = resnet_fc_shapes(prefix + "density_head.", pe_dim, encoder_dim, geo_dim + 1)
-    if arm_action_dim is not None:
+    if arm_action_dim is not None and kind == "flow_mlp":   # action_decoder_flow.py:109-116
+        out.update(resnet_fc_shapes(prefix + "flow_head_arm.", pe_dim, encoder_dim + arm_action_dim, 3))
+    elif arm_action_dim is not None:
         out.update(resnet_fc_shapes(prefix + "jacobian_head_arm.", pe_dim, encoder_dim, 3 * arm_action_dim))
     if kind == "jacobian_mlp":
         out.update(resnet_fc_shapes(prefix + "jacobian_head.", pe_dim, encoder_dim, 3 * action_dim))
@@ -173,7 +175,8 @@ def seeded_tensor(name: str, shape: Shape, seed: int = 0, linear_std: float = 0.
         t[-1] += 2.0
     # flow_mlp predicts the scene flow itself: keep it at the ~0.1 m scale J.a has for the Jacobian decoders, so the
     # warped points stay in front of the target camera and the projected flow is well conditioned
-    if name.endswith("flow_head.lin_out.weight") or name.endswith("flow_head.lin_out.bias"):
+    if name.endswith(("flow_head.lin_out.weight", "flow_head.lin_out.bias", "flow_head_arm.lin_out.weight",
+                      "flow_head_arm.lin_out.bias")):
         t *= 0.1
     return t
 

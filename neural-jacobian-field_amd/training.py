@@ -143,7 +143,8 @@ def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
                       foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
-                      d_feats: torch.Tensor = None, samples_per_ray: int = 1, mask: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+                      d_feats: torch.Tensor = None, samples_per_ray: int = 1, mask: torch.Tensor = None,
+                      latent_constants: torch.Tensor = None) -> Dict[str, torch.Tensor]:
     """Backward pass of one ResnetFC (resnet_fc.py:130-154) from the activations the HIP forward dumped.  ``mask`` [11,P,4] int32:
     the ReLU masks the same forward dumped -- the fused data-gradient chain then reads 16 instead of 512 bytes per point and layer
     (the weight-gradient GEMMs below are what still reads ``act``).
@@ -153,6 +154,9 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     ``feats_flat`` [T,512] encoder features, channels last.  Returns the parameter gradients; when ``d_feats`` [T,512]
     is given, the gradient w.r.t. the encoder features is accumulated into it (grid_sample's input gradient followed
     by lin_z's, in hoisted order: scatter the [P,128] latent gradient onto the texels, then one GEMM per lin_z).
+    ``latent_constants`` [B,A]: latent columns beyond the encoder channels that are constant per batch element (the robot
+    action of ``flow_mlp``, action_decoder_flow.py:168-172; points are batch-major) -- ``lin_z.*.weight`` is then [128, C + A]
+    and its last A columns receive sum_b a[b] (x) sum_{p in b} delta[p].
 
     The data-gradient chain (transposed-weight products, ReLU masks, residual adds of all 11 layers) is one HIP launch
     that keeps the gradient in MFMA accumulators and emits, per layer, the matrix that layer's weight gradient contracts
@@ -186,11 +190,17 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
     d_g = torch.zeros(feats_flat.shape[0], 3 * 128, dtype=torch.float32, device=d_out.device)
     hip.scatter_footprint(deltas_latent, foot_idx, foot_w, d_g, run_length=samples_per_ray)
     wz_grad = _tn(d_g, feats_flat)                                   # [384,512]
+    if latent_constants is not None:
+        nb = latent_constants.shape[0]
+        per_image = deltas_latent.float().reshape(3, nb, -1, 128).sum(2)                     # [3,B,128]
+        const_grad = torch.einsum("lbf,ba->lfa", per_image, latent_constants.to(per_image.dtype))   # [3,128,A]
+    n_feat = feats_flat.shape[1]
     for blk in range(3):
-        grads[f"lin_z.{blk}.weight"] = wz_grad[128 * blk:128 * (blk + 1)]
+        w_blk = wz_grad[128 * blk:128 * (blk + 1)]
+        grads[f"lin_z.{blk}.weight"] = w_blk if latent_constants is None else torch.cat([w_blk, const_grad[blk]], dim=1)
         grads[f"lin_z.{blk}.bias"] = sums[2 * blk]
     if d_feats is not None:
-        d_feats.addmm_(d_g, torch.cat([p[f"lin_z.{blk}.weight"] for blk in range(3)]))
+        d_feats.addmm_(d_g, torch.cat([p[f"lin_z.{blk}.weight"][:, :n_feat] for blk in range(3)]))
     d_in = _tn(delta0, pe)  # [128, 64] in slot order
     grads["lin_in.weight"] = d_in.new_zeros(d_in.shape[0], 63).index_copy_(
         1, _slot_to_channel(d_in.device), d_in[:, :63])
@@ -249,7 +259,9 @@ def transformer_head(p: Dict[str, torch.Tensor], xyz_features: torch.Tensor, pix
 
 class ActionFlowFunction(torch.autograd.Function):
     """optical_flow = f(Jacobian-head parameters); every other input is a constant captured by ``run``.
-    ``names``: the parameters' names relative to the decoder, ``kind``: ``jacobian_mlp`` | ``jacobian_transformer``."""
+    ``names``: the parameters' names relative to the decoder, ``kind``: ``jacobian_mlp`` | ``jacobian_transformer`` | ``flow_mlp``
+    (a ResnetFC that predicts the scene flow itself from cat[features, action], action_decoder_flow.py:156-176: the kernel
+    contracts its three outputs with the constant 1 and the action is a per-image constant of its latent input)."""
 
     @staticmethod
     def forward(ctx, run: Callable[[], Dict[str, torch.Tensor]], project: Callable, action: torch.Tensor,
@@ -277,14 +289,19 @@ class ActionFlowFunction(torch.autograd.Function):
         with torch.enable_grad():
             xw = outs["pos_warped"].detach().requires_grad_(True)
             (g_xw,) = torch.autograd.grad(ctx.project(xw), xw, g_flow.contiguous())
-        # flow_s = sum_a J[a,:] act[a]  (action_decoder_jacobian.py:128-145)  =>  dJ[s,a,c] = w_s act[a] g_xw[c]
-        d_j = torch.einsum("brs,ba,brc->brsac", weights, action, g_xw).reshape(b * r * s, 3 * a)
         feats_flat = _flat_features(features)
-        if ctx.kind == "jacobian_mlp":   # a ResnetFC head: ``jacobian_head.*``, or ``jacobian_head_arm.*`` in arm mode
+        if ctx.kind == "flow_mlp":
+            # flow_s IS the head's output (action_decoder_flow.py:156-176)  =>  d flow[s,c] = w_s g_xw[c]
+            d_j = torch.einsum("brs,brc->brsc", weights, g_xw).reshape(b * r * s, 3)
+        else:
+            # flow_s = sum_a J[a,:] act[a]  (action_decoder_jacobian.py:128-145)  =>  dJ[s,a,c] = w_s act[a] g_xw[c]
+            d_j = torch.einsum("brs,ba,brc->brsac", weights, action, g_xw).reshape(b * r * s, 3 * a)
+        if ctx.kind in ("jacobian_mlp", "flow_mlp"):   # a ResnetFC head: ``jacobian_head.*`` / ``jacobian_head_arm.*`` / ``flow_head*.*``
             cut = ctx.names[0].index(".") + 1
             p = {n[cut:]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
             grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat,
-                                      samples_per_ray=s, mask=outs.get("jac_mask"))
+                                      samples_per_ray=s, mask=outs.get("jac_mask"),
+                                      latent_constants=action if ctx.kind == "flow_mlp" else None)
             result = tuple(grads[n[cut:]] for n in ctx.names)
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
@@ -468,9 +485,11 @@ class RefuseBackward(torch.autograd.Function):
 
 def is_action_mode(model) -> bool:
     """The reference's action-mode trainable set (ModelWrapper.freeze_parameters, model_wrapper.py:75-85 with
-    ActionDecoderJacobian.freeze_non_action_parameters): only decoder parameters whose name contains "jacobian"."""
+    ActionDecoder*.freeze_non_action_parameters): only decoder parameters whose name contains the decoder's action pattern
+    ("jacobian" for the Jacobian decoders, "flow_head" for flow_mlp, action_decoder_flow.py:67, :281-288)."""
     names = trainable_names(model)
-    return bool(names) and all(n.startswith("decoder.jacobian") for n in names)
+    pattern = "decoder." + model.decoder.action_param_glob_pattern      # "jacobian_head" | "jacobian" | "flow_head"
+    return bool(names) and all(n.startswith(pattern) for n in names)
 
 
 PERCEPTION_MESSAGE = ("optical_flow is differentiable only in the reference's action mode (ModelWrapper.freeze_parameters: "
@@ -487,7 +506,7 @@ def action_params(model):
     ResnetFC layer order for ``jacobian_mlp``, registration order for ``jacobian_transformer`` (index embedding, query
     MLP, attention decoder, output Linear).  Frozen members are included (they simply receive unused gradients)."""
     dec = dict(model.decoder.named_parameters())
-    prefix = model.decoder.active_head_prefix     # "jacobian_head." | "jacobian_head_arm." (switch_mode('arm')) | ""
+    prefix = model.decoder.active_head_prefix     # "jacobian_head." | "jacobian_head_arm." | "flow_head." | "flow_head_arm." | ""
     if prefix:
         names = [prefix + k for k in JACOBIAN_PARAM_ORDER]
     else:
@@ -498,4 +517,6 @@ def action_params(model):
 def action_kind(model) -> str:
     """Which backward ActionFlowFunction runs: the ResnetFC chain for a ResnetFC head (jacobian_mlp, and the arm head of either
     decoder), the recomputed transformer head otherwise."""
+    if model.cfg.action_decoder.name == "flow_mlp":
+        return "flow_mlp"
     return "jacobian_mlp" if model.decoder.active_head_prefix else model.cfg.action_decoder.name

@@ -152,6 +152,54 @@ def test_model_forward_flow_mlp(golden):
     assert (g["optical_flow"] - g["optical_flow_zero_action"]).abs().max() > 1e-3 * g["optical_flow"].abs().max()
 
 
+def _flow_head_as_regular(params, mode):
+    """The oracle evaluates ``flow_head.*``; arm mode (switch_mode, action_decoder_flow.py:163-166) is the same arithmetic on the
+    ``flow_head_arm.*`` weights -- hand them over under the regular names."""
+    if mode == "regular":
+        return dict(params)
+    out = {k: v for k, v in params.items() if not k.startswith("decoder.flow_head.")}
+    for k, v in params.items():
+        if k.startswith("decoder.flow_head_arm."):
+            out["decoder.flow_head." + k[len("decoder.flow_head_arm."):]] = v
+    return out
+
+
+@pytest.mark.parametrize("mode", ["regular", "arm"])
+def test_flow_mlp_arm_head_and_action_mode_gradient(golden, mode):
+    """flow_mlp beyond inference (tests/golden/make_golden_r06_flow.py): the decoder built with ``use_arm_model`` in both modes,
+    and the reference's action-mode training gradient -- 0.01 * mse(optical_flow, target) differentiated w.r.t. the ACTIVE flow head
+    through the whole model -- against autograd through the oracle.  Forward: bit-exact / 1e-6 like test_model_forward_flow_mlp;
+    gradients: each parameter within max(1e-5, 2 x the reference's own fp32-vs-float64 distance) in the max norm."""
+    from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
+    g = golden("model_flow_train")
+    shapes = synthetic.model_shapes("flow_mlp", 5, arm_action_dim=5)
+    import numpy as np
+    with np.load(os.path.join(GOLDEN, "model_flow_train.npz")) as raw:   # (string array: the reference's state-dict keys)
+        assert sorted(k for k in shapes if "flow_head_arm" in k) == [str(k) for k in raw["arm_keys"]]
+    params = _flow_head_as_regular(synthetic.seeded_state_dict(shapes, seed=0), mode)
+    for k, v in params.items():
+        v.requires_grad_(k.startswith("decoder.flow_head."))
+    common = dict(ctxt_c2w=g["ctxt_c2w"], ctxt_k_norm=g["ctxt_k_norm"], trgt_c2w=g["trgt_c2w"], trgt_k_pix=g["trgt_k_pix"],
+                  origins=g["origins"], directions=g["directions"], z_near=g["z_near"], z_far=g["z_far"],
+                  num_proposal_samples=[16], num_nerf_samples=12, decoder_kind="flow_mlp")
+    res = orc.model_forward(params, features=g["features"], action=g["action"], **common)
+    with torch.no_grad():
+        close(res.positions, g[mode + ".final_positions"])
+        close(res.density, g[mode + ".dec_density"]); close(res.color, g[mode + ".dec_color"])
+        close(res.flow, g[mode + ".dec_flow"], tol=1e-6)
+        close(res.rgb, g[mode + ".rgb"]); close(res.depth, g[mode + ".depth"])
+        close(res.optical_flow, g[mode + ".optical_flow"], tol=1e-6)
+    loss = orc.flow_loss(res.optical_flow, g["target"])
+    close(loss.detach().reshape(1), g[mode + ".loss"], tol=1e-6)
+    loss.backward()
+    for name in JACOBIAN_PARAM_ORDER:
+        mine, ref = params["decoder.flow_head." + name].grad, g[f"{mode}.grad.{name}"]
+        err = ((mine - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+        assert err <= max(1e-5, 2 * float(g[f"{mode}.floor64.{name}"])), (mode, name, err)
+    if mode == "arm":   # the two heads must differ, or the test passes on a model that ignores the switch
+        assert (g["arm.optical_flow"] - g["regular.optical_flow"]).abs().max() > 1e-2 * g["regular.optical_flow"].abs().max()
+
+
 def test_composite_and_losses(golden):
     g = golden("composite")
     close(orc.composite_rgb(g["rgb"], g["weights"]), g["out_rgb"])

@@ -640,3 +640,117 @@ def test_f16_training_storage_against_fp32_storage(mode):
     fp32_made = {n: v for n, v in worst.items() if ("density_head" in n or "jacobian_head" in n) and
                  (n.endswith(".bias") or ".lin_z." in n or ".lin_in." in n)}
     assert fp32_made and all(v <= 1e-5 for v in fp32_made.values()), fp32_made
+
+
+@pytest.mark.parametrize("mode", ["regular", "arm"])
+def test_flow_mlp_arm_head_and_action_mode_training_vs_reference_golden(golden, margins, mode):
+    """``flow_mlp`` beyond inference (tests/golden/model_flow_train.npz, produced by the reference itself): the decoder built with
+    ``use_arm_model`` in both modes -- decoder at the reference's sample positions and Model.forward end to end, fp64 floors from
+    the reference's float64 run -- and the reference's ACTION-MODE gradient (parameters frozen like ModelWrapper.freeze_parameters,
+    0.01 * mse(optical_flow, target), autograd through the whole reference model) of the ACTIVE flow head, which the HIP path
+    produces with the ResnetFC backward chain + the action columns of ``lin_z`` (training.resnetfc_backward: latent_constants).
+    Gradient floors per parameter: the reference's own fp32-vs-float64 distance (fixture); where twice that fails, the oracle's
+    movement under one-ulp rays (the same rule as every other gradient row)."""
+    import njf_oracle as orc
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.decoder import PixelEncoding
+    from neural_jacobian_field_amd.model import CameraInput, Model, RenderingInput, RobotInput
+    from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    dev = torch.device("cuda:0")
+    raw = golden("model_flow_train")
+    g = {k[len(mode) + 1:]: v for k, v in raw.items() if k.startswith(mode + ".")}
+    g.update({k: v for k, v in raw.items() if "." not in k})
+    d = lambda t: t.to(dev)
+    A = 5
+    cfg = model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [16], "num_nerf_samples": 12},
+                               "action_decoder": {"name": "flow_mlp", "use_arm_model": True, "arm_action_dim": A}})
+    model = Model(cfg)
+    full = synthetic.seeded_state_dict(synthetic.model_shapes("flow_mlp", A, arm_action_dim=A), seed=0)
+    model.load_state_dict(full, strict=True)
+    model.to(dev).eval().requires_grad_(False)
+    model.set_precision("f32")
+    model.decoder.switch_mode(mode)
+    features = d(g["features"])
+    model._encode_for_render = lambda image: features       # the reference's encoder output: the rendering path alone
+    cam = CameraInput(d(g["image"]), d(g["ctxt_c2w"]), d(g["ctxt_k_norm"]), d(g["trgt_c2w"]), d(g["trgt_k_pix"]))
+    rin = RenderingInput(d(g["origins"]), d(g["directions"]), d(g["z_near"]), d(g["z_far"]))
+    rob = RobotInput(d(g["action"]))
+    # ---- forward: decoder at the reference's positions, Model.forward end to end ---------------------------------------------
+    enc = PixelEncoding(features, cam.ctxt_extrinsics, cam.ctxt_intrinsics, rob.robot_action)
+    pos = d(g["final_positions"])
+    dec = model.decoder.forward(pos, rin.directions[..., None, :].expand(pos.shape).contiguous(), enc)
+    c = f"model_flow_train[{mode}].decoder@ref-positions"
+    margins(c, "flow", dec.flow, g["dec_flow"], g["dec_flow_f64"])
+    margins(c, "density", dec.density, g["dec_density"], g["dec_density_f64"])
+    margins(c, "color", dec.color, g["dec_color"], g["dec_color_f64"])
+    assert dec.action_features is None
+    out = model.forward(cam, rin, rob)
+    c = f"model_flow_train[{mode}].forward"
+    so = out.standard_output
+    # the fixture holds no self-noise figures; the oracle's movement under one-ulp rays supplies them (consulted only on failure)
+    common = dict(ctxt_c2w=g["ctxt_c2w"], ctxt_k_norm=g["ctxt_k_norm"], trgt_c2w=g["trgt_c2w"], trgt_k_pix=g["trgt_k_pix"],
+                  z_near=g["z_near"], z_far=g["z_far"], num_proposal_samples=[16], num_nerf_samples=12, decoder_kind="flow_mlp")
+
+    def as_regular(params):   # the oracle evaluates flow_head.*: arm mode = the same arithmetic on flow_head_arm.*
+        if mode == "regular":
+            return params
+        keep = {k: v for k, v in params.items() if not k.startswith("decoder.flow_head.")}
+        keep.update({"decoder.flow_head." + k[len("decoder.flow_head_arm."):]: v for k, v in params.items()
+                     if k.startswith("decoder.flow_head_arm.")})
+        return keep
+
+    losses = {}
+
+    def oracle_backward(fmode):
+        cv = as_dtype(fmode)
+        params = as_regular({k: cv(v.clone()) for k, v in full.items()})
+        for k in params:
+            if k.startswith("decoder.flow_head."):
+                params[k].requires_grad_(True)
+        origins, directions = moved_rays(g["origins"], g["directions"], fmode)
+        feats = g["features"] if feature_seed(fmode) is None else noisy(g["features"], seed=feature_seed(fmode))
+        ref = orc.model_forward(params, features=cv(feats), origins=cv(origins), directions=cv(directions), action=cv(g["action"]),
+                                **{k: (cv(v) if torch.is_tensor(v) else v) for k, v in common.items()})
+        loss = orc.flow_loss(ref.optical_flow, cv(g["target"]))
+        loss.backward()
+        losses[fmode] = (loss.detach().reshape(1), ref.rgb.detach(), ref.depth.detach(), ref.optical_flow.detach())
+        return {n: params["decoder.flow_head." + n].grad for n in JACOBIAN_PARAM_ORDER}
+
+    _, floor, _ = gradient_floor(oracle_backward, JACOBIAN_PARAM_ORDER)
+    ray_modes = [m for m in FLOOR_MODES if m.startswith("rays")]
+    for i, (key, got) in enumerate((("rgb", so.rgb), ("depth", so.depth), ("optical_flow", so.optical_flow)), start=1):
+        margins(c, key, got, g[key], g[key + "_f64"], self_noise=[rel(losses[m][i], losses[None][i]) for m in ray_modes])
+    # ---- the action-mode step ---------------------------------------------------------------------------------------------------
+    model.requires_grad_(True)
+    model.decoder.freeze_non_action_parameters()           # action_decoder_flow.py:281-288
+    for n, p in model.named_parameters():
+        if "decoder" not in n:
+            p.requires_grad = False                          # model_wrapper.py:79-82
+    from neural_jacobian_field_amd import training
+    assert training.is_action_mode(model) and training.action_kind(model) == "flow_mlp"
+    out = model.forward(cam, rin, rob)
+    assert out.standard_output.optical_flow.requires_grad and not out.standard_output.rgb.requires_grad
+    loss = 0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, d(g["target"]))
+    loss.backward()
+    c = f"train.action[flow_mlp,{mode}]"
+    margins(c, "loss", loss.reshape(1), g["loss"], floor=max(rel(losses[m][0], losses[None][0]) for m in FLOOR_MODES),
+            floor_fp64=rel(g["loss_f64"], g["loss"]))
+    active = "flow_head_arm." if mode == "arm" else "flow_head."
+    idle = "flow_head." if mode == "arm" else "flow_head_arm."
+    named = dict(model.decoder.named_parameters())
+    for name in JACOBIAN_PARAM_ORDER:
+        grad = named[active + name].grad
+        assert grad is not None and torch.isfinite(grad).all() and grad.shape == named[active + name].shape, name
+        margins(c, "grad " + name, grad, g["grad." + name], floor=max(floor[name], float(g["floor64." + name])),
+                floor_fp64=float(g["floor64." + name]))
+    assert all(named[idle + n].grad is None for n in JACOBIAN_PARAM_ORDER)              # the inactive head: no gradient
+    assert all(p.grad is None for n, p in model.named_parameters() if "flow_head" not in n)
+    # one optimiser step moves the loss (the hoisted map's action bias and the packed head are refreshed)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=2e-4)
+    opt.step()
+    with torch.no_grad():
+        after = 0.01 * torch.nn.functional.mse_loss(model.forward(cam, rin, rob).standard_output.optical_flow, d(g["target"]))
+    assert float(after) < float(loss.detach()), (float(after), float(loss.detach()))
