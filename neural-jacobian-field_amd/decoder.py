@@ -504,10 +504,10 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
     (:168-172), so the reference only runs in arm mode when arm_action_dim == action_dim -- checked in ``switch_mode``.
     The active flow head trains in the reference's action mode (``action_param_glob_pattern = "flow_head"``; training.py).
 
-    Not offered (and why): ``encode_image`` (the reference's own version returns a ``map`` object that
-    ``Model.encode_image`` cannot consume, action_decoder_flow.py:246-279) and the 640-channel hidden ``action_features``
-    of ``DecoderOutput`` (nothing in the reference reads them for this decoder; ``DecoderOutput.action_features`` is None
-    and the composited visualisation slot holds the scene flow).
+    ``encode_image`` mirrors the reference's as it is (a ``map`` object yielding the density, :246-279; ``Model.encode_image``
+    cannot consume it on either side).  Not offered: the 640-channel hidden ``action_features`` of ``DecoderOutput`` (nothing in
+    the reference reads them for this decoder; ``DecoderOutput.action_features`` is None and the composited visualisation slot
+    holds the scene flow).
     """
 
     action_param_glob_pattern = "flow_head"
@@ -577,10 +577,14 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
         out = super().forward(world_space_xyz, world_space_dir, pixel_encoding)
         return DecoderOutput(out.density, out.color, out.flow, None)
 
+    @torch.no_grad()
     def encode_image(self, world_space_xyz, pixel_encoding: PixelEncoding):
-        raise NotImplementedError("flow_mlp has no usable encode_image in the reference either "
-                                  "(action_decoder_flow.py:246-279 returns a map object); use a Jacobian decoder for "
-                                  "inverse dynamics")
+        """action_decoder_flow.py:246-279, as it is: the reference computes the density head only (its feature line is commented
+        out) and returns the ``map`` object of its reshape -- an iterator that yields ONE tensor, density [B,R,S,1] -- not a
+        DecoderFeatureOnlyOutput; ``Model.encode_image`` cannot consume it there (model.py:487-492) and refuses here."""
+        b, r, s = world_space_xyz.shape[:3]
+        density = self._points(world_space_xyz.reshape(b, r * s, 3), None, pixel_encoding, False, {})["density"]
+        return map(lambda x: x.reshape(b, r, s, 1), (density,))
 
     def compute_jacobian_at(self, world_space_xyz, pixel_encoding: PixelEncoding):
         raise NotImplementedError("flow_mlp predicts the scene flow directly; it has no Jacobian")

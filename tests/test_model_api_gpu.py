@@ -475,8 +475,9 @@ def test_flow_mlp_decoder_at_reference_sample_locations(flow_model_and_golden, m
     margins(c, "color", dec.color, g["dec_color"], g["dec_color_f64"])
     margins(c, "density", dec.density, g["dec_density"], g["dec_density_f64"])
     assert dec.action_features is None
-    with pytest.raises(NotImplementedError):
-        model.decoder.encode_image(pos, enc)
+    # the reference's flow_mlp.encode_image as it is (action_decoder_flow.py:246-279): a map object yielding the density alone
+    only = list(model.decoder.encode_image(pos, enc))
+    assert len(only) == 1 and only[0].shape == dec.density.shape and rel(only[0], dec.density) < 1e-6
 
 
 def test_flow_mlp_model_forward_vs_reference_golden(flow_model_and_golden, margins):
