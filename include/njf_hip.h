@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 17
+#define NJF_ABI_VERSION 18
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -320,12 +320,17 @@ int njf_assemble_frame(const float* packets, int world, int packet_floats, int b
 /* xyz [B,N,3] world-space points, dirs [B,N,3] or NULL.  mode 0: proposal net -> density [B*N].
  * mode 1: decoder -> density [B*N], color [B*N,3], flow [B*N,3], jacobian [B*N,3A], geo [B*N,15]
  * (any may be NULL); the Jacobian head is selected by jacobian_kind.  The decoder blobs must be
- * one allocation laid out [density | colour | jacobian] (also for njf_render_forward). */
+ * one allocation laid out [density | colour | jacobian] (also for njf_render_forward).
+ * `features` (ABI v18, may be NULL; mode 1 with NJF_JACOBIAN_MLP, not NJF_PRECISION_F16): [5, B*N, 128] -- the head's residual
+ * stream after each of its five blocks, i.e. ResnetFC.forward(compute_features=True).features (model_components/resnet_fc.py:
+ * 141-151) block-major; the 640 hidden "action features" ActionDecoderFlowMlp.compute_flow returns (action_decoder_flow.py:
+ * 168-176) are its transpose [B*N, 5, 128]. */
 int njf_points_forward(const float* xyz, const float* dirs, int points_per_batch, const NjfCameras* cams,
                        const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
                        int jacobian_kind /* NJF_JACOBIAN_* */, const float* w_density, const float* b_density, const float* w_color, const float* b_color,
                        const float* w_jacobian, const float* b_jacobian,
-                       float* density, float* color, float* flow, float* jacobian, float* geo, int precision, void* stream);
+                       float* density, float* color, float* flow, float* jacobian, float* geo, float* features, int precision,
+                       void* stream);
 
 /* ---- stand-alone sampler / compositing ops (API parity with the un-fused reference calls) -- */
 /* RaySamples.get_weights (ray_samplers.py:77-101): deltas, densities [N,S] -> weights [N,S]. */

@@ -1105,6 +1105,10 @@ struct ActDump {
   // 16-bit training storage (round 6, opt-in): `act` addresses HALVES ([11][P][128] fp16: what the weight-gradient GEMM reads with
   // fp32 accumulation -- the reference trains on TF32 products, 10 mantissa bits as well); the stride stays a count of elements
   bool half = false;
+  // ResnetFC.forward(compute_features=True) (resnet_fc.py:141-151; ABI v18): the residual stream AFTER each block, [5][P][128] fp32,
+  // this lane's 64 values of block 0 (layer stride = `stride`); nullptr = not dumped.  Only the point-query kernel asks for it
+  // (the 640 hidden "action features" of the flow_mlp decoder, action_decoder_flow.py:168-176)
+  float* feat = nullptr;
 };
 
 // this lane's slot of layer `l` in the activation dump (elements are floats, or halves when dump.half)
@@ -1242,6 +1246,7 @@ __device__ __forceinline__ void resnet_tile(ST& st, const float* __restrict__ bi
         mma_chunk<PREC, 4, 2, 2, true, 4>(st, wl, lane, net, h);
       }
     }
+    if (DUMP && dump.feat != nullptr) dump_vec128<false>(dump.feat + (size_t)blk * dump.stride, h);
   }
   if (DUMP) dump_vec128<true>(dump_layer(dump, 10), h, dump.mask ? dump.mask + (size_t)10 * (dump.stride / 32) : nullptr, dump.half);
   bias_init<1, true, PREC>(bias + 1280, hh, out);

@@ -1869,11 +1869,13 @@ struct PointsArgs {
   float* flow;
   float* jacobian;
   float* geo;
+  float* features;  // [5, P, 128] or null (FEAT instantiation only)
 };
 
 // MODE 0: proposal net (density only); 1: decoder without Jacobian head; 2: decoder + ResnetFC Jacobian head;
-// 3: decoder + transformer Jacobian head
-template <int MODE, int PREC, int PRECJ = PREC>
+// 3: decoder + transformer Jacobian head.  FEAT (MODE 2): the head also stores its residual stream after every block
+// (ResnetFC.forward(compute_features=True), resnet_fc.py:141-151) through the training instantiation of resnet_tile
+template <int MODE, int PREC, int PRECJ = PREC, bool FEAT = false>
 __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1941,6 +1943,12 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) points_kernel(PointsArgs a) {
       f32x16 jac[1];
       float flow[3];
       // NOTE: `action` is per lane here (tiles may straddle batch elements)
+      if constexpr (FEAT) {
+        static_assert(MODE == 2, "feature dump: ResnetFC head");
+        ActDump fdump{nullptr, nullptr, (size_t)a.total_points * 128};
+        if (ok) fdump.feat = a.features + (size_t)p * 128 + 64 * hh;
+        jacobian_stage<JK, PRECJ, 1>(st, map_at<PRECJ>(a.gmap.data, a.goff_j), g, action, A, wave, lane, jac, flow, fdump);
+      } else
       jacobian_stage<JK, PRECJ, 0>(st, map_at<PRECJ>(a.gmap.data, a.goff_j), g, action, A, wave, lane, jac, flow, nodump);
       if (ok) {
         if (hh == 0 && a.flow) {
@@ -2896,7 +2904,8 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
                                   const NjfFeatureMap* gmap, int gmap_offset_density, int gmap_offset_jacobian, int mode,
                                   int jacobian_kind, const float* w_density, const float* b_density, const float* w_color,
                                   const float* b_color, const float* w_jacobian, const float* b_jacobian, float* density,
-                                  float* color, float* flow, float* jacobian, float* geo, int precision, void* stream) {
+                                  float* color, float* flow, float* jacobian, float* geo, float* features, int precision,
+                                  void* stream) {
   if (!xyz || !cams || !gmap || !w_density || !b_density) return NJF_E_NULL;
   if (!cams->ctxt_w2c || !cams->ctxt_k || !gmap->data) return NJF_E_NULL;
   if (points_per_batch < 1 || cams->batch < 1) return NJF_E_SHAPE;
@@ -2924,6 +2933,10 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   a.flow = flow;
   a.jacobian = jacobian;
   a.geo = geo;
+  a.features = features;
+  // the per-block features exist for a ResnetFC head evaluated next to the decoder (mode 1, NJF_JACOBIAN_MLP)
+  if (features && (mode != 1 || jacobian_kind != NJF_JACOBIAN_MLP)) return NJF_E_MODE;
+  if (features && (long long)a.total_points * 5 * 128 > 0x7fffffffffLL) return NJF_E_SHAPE;
   const int tiles = (a.total_points + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0)
@@ -2935,6 +2948,10 @@ extern "C" int njf_points_forward(const float* xyz, const float* dirs, int point
   if (!with_j)
     return with_precision(density_precision(precision), [&](auto P) { return launch_fused(points_kernel<1, NJF_P>, a, tiles, s); });
   return with_precisions(precision, [&](auto P, auto PJ) {
+    if (features) {   // (the plain-fp16 mode has no training instantiation of resnet_tile: its block biases ride elsewhere)
+      if constexpr (NJF_PJ == PREC_F16) return (int)NJF_E_MODE;
+      else return launch_fused(points_kernel<2, NJF_P, NJF_PJ, true>, a, tiles, s);
+    }
     if (jacobian_kind == NJF_JACOBIAN_MLP) return launch_fused(points_kernel<2, NJF_P, NJF_PJ>, a, tiles, s);
     return launch_fused(points_kernel<3, NJF_P, NJF_PJ>, a, tiles, s);
   });

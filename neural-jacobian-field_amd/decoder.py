@@ -420,6 +420,8 @@ class ActionDecoderJacobian(ActionDecoder):
             out["jacobian"] = torch.empty(b, n, 3 * self.kernel_action_dim, **f32)
             if want.get("flow"):
                 out["flow"] = torch.empty(b, n, 3, **f32)
+            if want.get("features"):   # ResnetFC.forward(compute_features=True): residual stream after each block, block-major
+                out["features"] = torch.empty(5, b * n, 128, **f32)
         hip.points_forward(xyz_flat.contiguous(), None if dirs_flat is None else dirs_flat.contiguous(),
                            _cameras(enc, with_jacobian and want.get("flow", False), action_dim=self.kernel_action_dim,
                                     action=self.kernel_action(enc.action)), fmap,
@@ -505,9 +507,10 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
     The active flow head trains in the reference's action mode (``action_param_glob_pattern = "flow_head"``; training.py).
 
     ``encode_image`` mirrors the reference's as it is (a ``map`` object yielding the density, :246-279; ``Model.encode_image``
-    cannot consume it on either side).  Not offered: the 640-channel hidden ``action_features`` of ``DecoderOutput`` (nothing in
-    the reference reads them for this decoder; ``DecoderOutput.action_features`` is None and the composited visualisation slot
-    holds the scene flow).
+    cannot consume it on either side).  ``DecoderOutput.action_features`` / ``ModelVisOutput.action_features`` are the flow
+    head's 640 hidden features as in the reference (:168-176, model.py:381-390): the point-query kernel stores the head's residual
+    stream after each block (ABI v18), ``composited_features`` weights them along the rays.  (Not in the plain-fp16 mode, which has
+    no such instantiation.)
     """
 
     action_param_glob_pattern = "flow_head"
@@ -573,9 +576,41 @@ class ActionDecoderFlowMlp(ActionDecoderJacobian):
 
     @torch.no_grad()
     def forward(self, world_space_xyz, world_space_dir, pixel_encoding: PixelEncoding) -> DecoderOutput:
-        """action_decoder_flow.py:185-244."""
-        out = super().forward(world_space_xyz, world_space_dir, pixel_encoding)
-        return DecoderOutput(out.density, out.color, out.flow, None)
+        """action_decoder_flow.py:185-244.  ``action_features`` are the flow head's 5 x 128 hidden features
+        (``ResnetFC.forward(compute_features=True)``, resnet_fc.py:141-151: the residual stream after each block, concatenated),
+        stored by the point-query kernel next to the flow."""
+        b, r, s = world_space_xyz.shape[:3]
+        with_features = self.j_precision not in hip.REDUCED_PRECISIONS   # (plain fp16: no such instantiation; None as before)
+        o = self._points(world_space_xyz.reshape(b, r * s, 3), world_space_dir.reshape(b, r * s, 3), pixel_encoding, True,
+                         {"color": True, "flow": True, "features": with_features})
+        sh = lambda t: t.reshape(b, r, s, -1)
+        return DecoderOutput(sh(o["density"]), sh(o["color"]), sh(o["flow"]),
+                             sh(self.hidden_features(o["features"])) if with_features else None)
+
+    @staticmethod
+    def hidden_features(block_major: torch.Tensor) -> torch.Tensor:
+        """[5, P, 128] (the kernel's block-major dump) -> [P, 640] = torch.cat(features, dim=-1) of resnet_fc.py:150-151."""
+        return block_major.permute(1, 0, 2).reshape(block_major.shape[1], -1)
+
+    @torch.no_grad()
+    def composited_features(self, positions: torch.Tensor, weights: torch.Tensor, pixel_encoding: PixelEncoding,
+                            max_points: int = 1 << 20) -> torch.Tensor:
+        """Model.render_action_features (model.py:281-286) of this decoder's hidden features: sum_s w_s f_s -> [B,R,640] from sample
+        positions [B,R,S,3] and weights [B,R,S].  Ray chunks of at most ``max_points`` points (the per-sample features are 2.5 KB
+        per point: a 480 x 640 x 256 patch_render frame would be 200 GB in one piece)."""
+        if self.j_precision in hip.REDUCED_PRECISIONS:
+            raise RuntimeError("flow_mlp: the hidden action features are not produced in the plain-fp16 mode (no feature-storing "
+                               "instantiation of its point-query kernel); call model.set_precision('f16f6') / ('f32') for them")
+        b, r, s = positions.shape[:3]
+        out = torch.empty(b, r, 640, dtype=torch.float32, device=positions.device)
+        step = max(1, max_points // max(1, b * s))
+        for lo in range(0, r, step):
+            hi = min(r, lo + step)
+            n = (hi - lo) * s
+            o = self._points(positions[:, lo:hi].reshape(b, n, 3), None, pixel_encoding, True, {"features": True})
+            feats = self.hidden_features(o["features"]).reshape(b, hi - lo, s, 640)
+            out[:, lo:hi] = torch.einsum("brs,brsc->brc", weights[:, lo:hi], feats)
+        return out
 
     @torch.no_grad()
     def encode_image(self, world_space_xyz, pixel_encoding: PixelEncoding):

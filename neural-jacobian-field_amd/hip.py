@@ -135,7 +135,7 @@ _SIGNATURES = {
     "njf_render_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(RenderOutputs), C.c_int, _vp], C.c_int),
     "njf_points_forward": ([_vp, _vp, C.c_int, C.POINTER(Cameras), C.POINTER(FeatureMap), C.c_int, C.c_int, C.c_int,
-                            C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
+                            C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, C.c_int, _vp], C.c_int),
     "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
@@ -554,8 +554,11 @@ def render_forward(origins, directions, cams: Cameras, fmap: FeatureMap, goff_de
 def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int, goff_jacobian: int, mode: int,
                    w_all, b_density, b_color=None, b_jacobian=None, jacobian_kind: int = JACOBIAN_NONE, density=None,
                    color=None, flow=None, jacobian=None, geo=None, precision: Optional[str] = None,
-                   jacobian_precision: Optional[str] = None) -> None:
+                   jacobian_precision: Optional[str] = None, features=None) -> None:
+    """``features`` [5, B*N, 128] (ABI v18): the ResnetFC head's residual stream after each block (include/njf_hip.h)."""
     points_per_batch = xyz.shape[1]
+    if features is not None and tuple(features.shape) != (5, xyz.shape[0] * points_per_batch, 128):
+        raise ValueError(f"njf_hip: features must be [5, {xyz.shape[0] * points_per_batch}, 128] (got {tuple(features.shape)})")
     base = _ptr(w_all, "w_all")
     w_c = base + 4 * RESNET_W_FLOATS if mode == 1 else None
     with_j = mode == 1 and jacobian_kind != JACOBIAN_NONE
@@ -567,7 +570,7 @@ def points_forward(xyz, dirs, cams: Cameras, fmap: FeatureMap, goff_density: int
         _ptr(xyz), _ptr(dirs), points_per_batch, C.byref(cams), C.byref(fmap), goff_density, goff_jacobian, mode,
         jacobian_kind if mode == 1 else JACOBIAN_NONE, base, _ptr(b_density), w_c, _ptr(b_color), w_j,
         _ptr(b_jacobian) if with_j else None, _ptr(density), _ptr(color), _ptr(flow), _ptr(jacobian), _ptr(geo),
-        precision_code(precision, jacobian_precision))
+        _ptr(features, "features"), precision_code(precision, jacobian_precision))
 
 
 def solve_action(mean_position, jacobian, projection, target_flow, visible_mask, init_action, iterations: int,

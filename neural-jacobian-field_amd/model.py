@@ -495,7 +495,10 @@ class Model(nn.Module):
         if want_vis:
             outs["pos"] = torch.empty(b, r, 3, **f32)
             outs["pos_warped"] = torch.empty(b, r, 3, **f32)
-            if not (dump_jacobian or dump_perception):   # (never requested from a training forward: _vis_at_bins)
+            # flow_mlp: the composited features are the flow head's 640 hidden channels (model.py:381-390 on
+            # action_decoder_flow.py:168-176), weighted below from a point query -- not an output of the render kernel
+            hidden_features = hasattr(self.decoder, "composited_features")
+            if not (dump_jacobian or dump_perception or hidden_features):   # (never requested from a training forward: _vis_at_bins)
                 outs["action_features"] = torch.empty(b, r, a3, **f32)
         if want_samples:
             outs["density"] = torch.empty(b, r, s, 1, **f32)
@@ -542,6 +545,9 @@ class Model(nn.Module):
                            jacobian_precision=self.decoder.j_precision)
         if clip_depth:  # tensor-global clip of model.py:277
             outs["depth"] = self.depth_clip(outs["depth"], outs["step_minmax"])
+        if want_vis and not (dump_jacobian or dump_perception) and hasattr(self.decoder, "composited_features"):
+            outs["action_features"] = self.decoder.composited_features(
+                ray_bundle.samples_from_bins(bins).get_positions(), outs["weights"], enc)
         return outs, bins, weights_list, bins_list, ray_bundle
 
     def forward(self, camera_input: CameraInput, rendering_input: RenderingInput, robot_input: RobotInput,

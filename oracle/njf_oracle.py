@@ -384,8 +384,11 @@ def sh4_encoding(dirs01: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------
 # a7 / a8: ResnetFC and the density activation
 # --------------------------------------------------------------------------------------
-def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_layer: int = 3) -> Tensor:
-    """NJF/model_components/resnet_fc.py:130-154 (ResnetFC.forward) with ResnetBlockFC (:69-79), ReLU (beta=0)."""
+def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_layer: int = 3,
+              features: Optional[list] = None) -> Tensor:
+    """NJF/model_components/resnet_fc.py:130-154 (ResnetFC.forward) with ResnetBlockFC (:69-79), ReLU (beta=0).
+    ``features`` (a list): receives the residual stream after each block -- ``compute_features=True`` (:141-151; the caller
+    concatenates along the last dimension as :150-151 does)."""
     h = _affine(params, "lin_in", x)
     # operand-rounding model: the build folds fc_1's bias of blocks 0 and 1 into the hoisted map of the NEXT block's latent
     # (bilerp(G + b) = bilerp(G) + b), so it is part of what the map's fp16 rounding sees (csrc: njf_pack_resnetfc / njf_pack_linz)
@@ -397,6 +400,8 @@ def resnet_fc(params: Params, z: Tensor, x: Tensor, n_blocks: int = 5, combine_l
         net = _affine(params, f"blocks.{i}.fc_0", torch.relu(h))
         dx = _affine(params, f"blocks.{i}.fc_1", torch.relu(net), drop_bias=fold and i + 1 < combine_layer)
         h = h + dx
+        if features is not None:
+            features.append(h)
     return _affine(params, "lin_out", torch.relu(h))
 
 
@@ -486,6 +491,14 @@ def flow_mlp(params: Params, feats: Tensor, pe: Tensor, action: Tensor) -> Tenso
     return resnet_fc(_sub(params, "flow_head."), torch.cat([feats, action], dim=-1), pe)
 
 
+def flow_mlp_with_features(params: Params, feats: Tensor, pe: Tensor, action: Tensor) -> Tuple[Tensor, Tensor]:
+    """compute_flow as the reference calls it (action_decoder_flow.py:168-176: ``compute_features=True``): (flow [.., 3], the
+    head's hidden features [.., 5 * 128] = FlowHeadOutput.action_features)."""
+    blocks: list = []
+    flow = resnet_fc(_sub(params, "flow_head."), torch.cat([feats, action], dim=-1), pe, features=blocks)
+    return flow, torch.cat(blocks, dim=-1)
+
+
 def jacobian_transformer(params: Params, feats: Tensor, pe: Tensor, heads: int = 8, depth: int = 3) -> Tensor:
     """NJF/models/decoder/action_decoder_jacobian.py:418-446 + transformer.py:85-135."""
     x = _affine(params, "jacobian_query_mlp", torch.cat([pe, feats], dim=-1))
@@ -516,8 +529,9 @@ def decoder_forward(params: Params, xyz: Tensor, dirs: Tensor, enc: PixelEncodin
     action = enc.action[:, None, :].expand(b, r * s, action_dim)
     if kind == "flow_mlp":
         # NJF/models/decoder/action_decoder_flow.py:165-183 (compute_flow): the action is concatenated to the pixel-aligned
-        # features and the head outputs the scene flow directly; there is no Jacobian ("jac" = the head's raw output)
-        flow = jac = flow_mlp(params, feats, pe, action)
+        # features and the head outputs the scene flow directly; there is no Jacobian: "jac" = DecoderOutput.action_features is
+        # the head's 640 hidden features for this decoder (:168-176, :240-244)
+        flow, jac = flow_mlp_with_features(params, feats, pe, action)
     else:
         jac = jacobian_mlp(params, feats, pe) if kind == "jacobian_mlp" else jacobian_transformer(params, feats, pe)
         # :128-145 -- J viewed (action_dim, spatial_dim), contracted with the action

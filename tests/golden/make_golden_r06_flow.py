@@ -5,8 +5,9 @@
   model_flow_train.npz   ``ActionDecoderFlowMlp`` built with ``use_arm_model`` (``flow_head_arm``, action_decoder_flow.py:109-116),
                          arm_action_dim == action_dim (compute_flow concatenates the robot action itself, :168-172, so no other
                          arm width runs in the reference).  Per mode ("regular", "arm" = ``switch_mode``, :122-123, :163-166):
-                           * ``Model.forward`` end to end (rgb, depth, optical_flow) and the decoder on the fp32 run's final sample
-                             positions (density, colour, scene flow), in fp32 and in float64;
+                           * ``Model.forward`` end to end (rgb, depth, optical_flow, and with compute_vis_features the composited 640
+                             hidden features of the flow head) and the decoder on the fp32 run's final sample positions (density,
+                             colour, scene flow, the per-sample hidden features of the first 2 rays), in fp32 and in float64;
                            * the reference's ACTION-MODE training gradient: parameters frozen exactly as
                              ``ModelWrapper.freeze_parameters`` does (models/model_wrapper.py:75-85 ->
                              ``freeze_non_action_parameters``, action_decoder_flow.py:281-288: every decoder parameter whose name does
@@ -31,6 +32,7 @@ import make_golden as mg  # noqa: E402  (shims + helpers; also puts the repo roo
 
 save, rigid, randn, rand, k_norm, load_seeded = mg.save, mg.rigid, mg.randn, mg.rand, mg.k_norm, mg.load_seeded
 
+FEATURE_RAYS = 2
 RESNET_ORDER = (["lin_in.weight", "lin_in.bias"]
                 + [f"blocks.{b}.{fc}.{wb}" for b in range(5) for fc in ("fc_0", "fc_1") for wb in ("weight", "bias")]
                 + [f"lin_z.{i}.{wb}" for i in range(3) for wb in ("weight", "bias")] + ["lin_out.weight", "lin_out.bias"])
@@ -99,7 +101,7 @@ def main():
         out = {}
         with torch.no_grad():
             feats = m.encoder.forward(cam.input_image)
-            res = m.forward(cam, rin, rob, compute_vis_features=False)
+            res = m.forward(cam, rin, rob, compute_vis_features=True)
             penc = PixelEncoding(features=feats, extrinsics=cam.ctxt_extrinsics, intrinsics=cam.ctxt_intrinsics, action=rob.robot_action)
             rb = m.compute_ray_bundle(rin)
             samples, pos, dirs, wl, sl = m.compute_proposal(rb, penc)
@@ -109,6 +111,11 @@ def main():
             dec = m.decoder.forward(world_space_xyz=p_fin, world_space_dir=rin.directions[..., None, :].expand(p_fin.shape),
                                     pixel_encoding=penc)
             out.update(dec_density=dec.density, dec_color=dec.color, dec_flow=dec.flow)
+            # the flow head's 640 hidden features (action_decoder_flow.py:168-176 = ResnetFC.forward(compute_features=True)): per sample
+            # on FEATURE_RAYS rays of every batch element (the whole tensor is 1.2 MB per mode and precision), and composited along
+            # every ray by Model.forward (model.py:381-390)
+            out.update(dec_action_features=dec.action_features[:, :FEATURE_RAYS], vis_action_features=res.vis_output.action_features,
+                       vis_weights=res.vis_output.weights, vis_ray_positions_warped=res.vis_output.ray_positions_warped)
         # the action-mode training gradient (autograd through the whole reference model, frozen like the wrapper)
         freeze_like_the_wrapper(m)
         m.zero_grad(set_to_none=True)

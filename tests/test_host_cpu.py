@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 17
+    assert lib.njf_abi_version() == 18
 
 
 def test_hoisted_channel_order(built):
@@ -671,7 +671,7 @@ def test_header_is_plain_c(tmp_path, built):
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == len(names) and int(out[1]) == 17
+    assert int(out[0]) == len(names) and int(out[1]) == 18
 
 
 def test_static_isa_properties_of_the_fused_kernels():
@@ -710,7 +710,7 @@ def test_static_isa_properties_of_the_fused_kernels():
     # the plain-fp16 kernels (round 5): no spilled VGPR in any inference instantiation -- the shared tile state of the render kernel
     # (TileShareF16, 16-24 registers) is only instantiated where it fits -- and the weight stream is the LDS DMA here too
     for name in ("void render_kernel<1, 3, 0, false, 3>", "void render_kernel<1, 3, 0, true, 3>", "void render_kernel<2, 3, 0, false, 3>",
-                 "void render_kernel<2, 3, 0, true, 3>", "void proposal_kernel<3, false>", "void points_kernel<2, 3, 3>"):
+                 "void render_kernel<2, 3, 0, true, 3>", "void proposal_kernel<3, false>", "void points_kernel<2, 3, 3, false>"):
         r = row(name)
         assert r["spill"] == 0 and r["lds_dma"] > 0, (name, r)
 

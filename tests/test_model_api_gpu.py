@@ -474,7 +474,9 @@ def test_flow_mlp_decoder_at_reference_sample_locations(flow_model_and_golden, m
     margins(c, "flow", dec.flow, g["dec_flow"], g["dec_flow_f64"])
     margins(c, "color", dec.color, g["dec_color"], g["dec_color_f64"])
     margins(c, "density", dec.density, g["dec_density"], g["dec_density_f64"])
-    assert dec.action_features is None
+    # DecoderOutput.action_features: the flow head's 5 x 128 hidden features (action_decoder_flow.py:168-176); the values are pinned
+    # against the reference in tests/test_training_gpu.py::test_flow_mlp_arm_head_and_action_mode_training_vs_reference_golden
+    assert dec.action_features.shape == (*pos.shape[:3], 640) and torch.isfinite(dec.action_features).all()
     # the reference's flow_mlp.encode_image as it is (action_decoder_flow.py:246-279): a map object yielding the density alone
     only = list(model.decoder.encode_image(pos, enc))
     assert len(only) == 1 and only[0].shape == dec.density.shape and rel(only[0], dec.density) < 1e-6

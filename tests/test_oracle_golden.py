@@ -189,6 +189,11 @@ def test_flow_mlp_arm_head_and_action_mode_gradient(golden, mode):
         close(res.flow, g[mode + ".dec_flow"], tol=1e-6)
         close(res.rgb, g[mode + ".rgb"]); close(res.depth, g[mode + ".depth"])
         close(res.optical_flow, g[mode + ".optical_flow"], tol=1e-6)
+        # the flow head's 640 hidden features: per sample (the fixture keeps the first rays) and composited (model.py:381-390)
+        rays = g[mode + ".dec_action_features"].shape[1]
+        close(res.jacobian[:, :rays], g[mode + ".dec_action_features"], tol=1e-6)
+        close(res.action_features, g[mode + ".vis_action_features"], tol=1e-6)
+        close(res.weights, g[mode + ".vis_weights"]); close(res.ray_positions_warped, g[mode + ".vis_ray_positions_warped"], tol=1e-6)
     loss = orc.flow_loss(res.optical_flow, g["target"])
     close(loss.detach().reshape(1), g[mode + ".loss"], tol=1e-6)
     loss.backward()

@@ -686,8 +686,11 @@ def test_flow_mlp_arm_head_and_action_mode_training_vs_reference_golden(golden, 
     margins(c, "flow", dec.flow, g["dec_flow"], g["dec_flow_f64"])
     margins(c, "density", dec.density, g["dec_density"], g["dec_density_f64"])
     margins(c, "color", dec.color, g["dec_color"], g["dec_color_f64"])
-    assert dec.action_features is None
-    out = model.forward(cam, rin, rob)
+    # the flow head's 640 hidden features (ResnetFC.forward(compute_features=True)), stored by the point-query kernel (ABI v18)
+    rays = g["dec_action_features"].shape[1]
+    assert dec.action_features.shape == (*pos.shape[:3], 640)
+    margins(c, "action_features", dec.action_features[:, :rays], g["dec_action_features"], g["dec_action_features_f64"])
+    out = model.forward(cam, rin, rob, compute_vis_features=True)
     c = f"model_flow_train[{mode}].forward"
     so = out.standard_output
     # the fixture holds no self-noise figures; the oracle's movement under one-ulp rays supplies them (consulted only on failure)
@@ -716,13 +719,23 @@ def test_flow_mlp_arm_head_and_action_mode_training_vs_reference_golden(golden, 
                                 **{k: (cv(v) if torch.is_tensor(v) else v) for k, v in common.items()})
         loss = orc.flow_loss(ref.optical_flow, cv(g["target"]))
         loss.backward()
-        losses[fmode] = (loss.detach().reshape(1), ref.rgb.detach(), ref.depth.detach(), ref.optical_flow.detach())
+        losses[fmode] = (loss.detach().reshape(1), ref.rgb.detach(), ref.depth.detach(), ref.optical_flow.detach(),
+                         ref.action_features.detach(), ref.weights.detach(), ref.ray_positions_warped.detach())
         return {n: params["decoder.flow_head." + n].grad for n in JACOBIAN_PARAM_ORDER}
 
     _, floor, _ = gradient_floor(oracle_backward, JACOBIAN_PARAM_ORDER)
     ray_modes = [m for m in FLOOR_MODES if m.startswith("rays")]
     for i, (key, got) in enumerate((("rgb", so.rgb), ("depth", so.depth), ("optical_flow", so.optical_flow)), start=1):
         margins(c, key, got, g[key], g[key + "_f64"], self_noise=[rel(losses[m][i], losses[None][i]) for m in ray_modes])
+    # ModelVisOutput.action_features = sum_s w_s f_s over the 640 hidden features (model.py:381-390)
+    vis = out.vis_output
+    assert vis.action_features.shape == (*so.rgb.shape[:2], 640)
+    margins(c, "vis.action_features", vis.action_features, g["vis_action_features"], g["vis_action_features_f64"],
+            self_noise=[rel(losses[m][4], losses[None][4]) for m in ray_modes])
+    margins(c, "vis.weights", vis.weights, g["vis_weights"], g["vis_weights_f64"],
+            self_noise=[rel(losses[m][5], losses[None][5]) for m in ray_modes])
+    margins(c, "vis.ray_positions_warped", vis.ray_positions_warped, g["vis_ray_positions_warped"], g["vis_ray_positions_warped_f64"],
+            self_noise=[rel(losses[m][6], losses[None][6]) for m in ray_modes])
     # ---- the action-mode step ---------------------------------------------------------------------------------------------------
     model.requires_grad_(True)
     model.decoder.freeze_non_action_parameters()           # action_decoder_flow.py:281-288
