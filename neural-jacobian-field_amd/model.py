@@ -512,7 +512,8 @@ class Model(nn.Module):
             outs["pos_warped"] = outs.get("pos_warped", torch.empty(b, r, 3, **f32))
             if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:  # the transformer head is recomputed from pe + footprint
                 from . import training as _tr   # (fp16 under the opt-in 16-bit training storage, training.set_storage_precision)
-                outs["jac_act"] = torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(), device=dev)
+                outs["jac_forward_precision"] = self.decoder.j_precision    # (what training.py's "auto" settings follow)
+                outs["jac_act"] = torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(self.decoder.j_precision), device=dev)
                 outs["jac_mask"] = torch.empty(11, pts, 4, dtype=torch.int32, device=dev)   # ReLU masks: what the backward chain reads
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
@@ -524,7 +525,8 @@ class Model(nn.Module):
             outs["density"] = outs.get("density", torch.empty(b, r, s, 1, **f32))
             outs["color"] = torch.empty(b, r, s, 3, **f32)
             from . import training as _tr
-            outs["den_act"] = torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(), device=dev)
+            outs["den_forward_precision"] = self.decoder.precision
+            outs["den_act"] = torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(self.decoder.precision), device=dev)
             outs["den_mask"] = torch.empty(11, pts, 4, dtype=torch.int32, device=dev)
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)

@@ -261,12 +261,12 @@ class ProposalNetworkSampler(Sampler):
                 pts = b * r * s_in
                 sigma = torch.empty(b, r, s_in, dtype=torch.float32, device=dev)
                 from . import training as _tr   # (fp16 under the opt-in 16-bit training storage)
-                dump = {"act": torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(), device=dev),
+                dump = {"act": torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(net.precision), device=dev),
                         "pe": torch.empty(pts, 64, dtype=torch.float32, device=dev),
                         "foot_idx": torch.empty(pts, 4, dtype=torch.int32, device=dev),
                         "foot_w": torch.empty(pts, 4, dtype=torch.float32, device=dev),
                         "mask": torch.empty(11, pts, 4, dtype=torch.int32, device=dev)}   # ReLU masks for the backward chain (ABI v17)
-                dump_out.append({**dump, "density": sigma, "updated": updated})
+                dump_out.append({**dump, "density": sigma, "updated": updated, "forward_precision": net.precision})
             hip.proposal_forward(o, d, cams, fmap, goff, w, bias, bins.contiguous(), s_in, u, s_out, self._anneal, bins_out,
                                  w_out, sigma, precision=net.precision, dump=dump)
             if want_lists:

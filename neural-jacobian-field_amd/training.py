@@ -76,47 +76,64 @@ def _tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out.reshape(layers, groups, n, -1).sum(1)
 
 
-# Product form of the fused backward chain (njf_resnetfc_backward): "f32" = exact fp32 MFMA products (default; what every gradient
-# row of the test-suite is held to its fp64 floor with), "f16x2" = split fp16 products on power-of-two-scaled gradients (fp32-class,
-# 2^-22 per product where the reference's own training runs TF32 products, train.py:64-65; measured against the exact chain in
-# tests/test_training_gpu.py::test_backward_chain_f16x2_against_exact).  Process-wide, like the reference's
-# torch.set_float32_matmul_precision.
-_BACKWARD_PRECISION = os.environ.get("NJF_BACKWARD_PRECISION", "f32")
+# How the reference itself trains: ``torch.set_float32_matmul_precision("high")`` (train.py:64-65) -- every GEMM of its training step,
+# forward and backward, runs on TF32 products (10 mantissa bits per operand).  The same process-wide switch selects the TF32-class
+# forms of THIS backward pass: with "auto" (the default of both settings below) they are used exactly when the caller has relaxed
+# torch's matmul precision the way train.py does AND the network's forward pass runs in a split precision (i.e. inside fp16's
+# range: a network forced to exact fp32 products, by hand or by the range guard of Model._maybe_check_range, keeps the exact
+# backward).  With torch's own default ("highest") nothing changes: exact fp32 products, fp32 storage.
+def reference_allows_reduced_products() -> bool:
+    return torch.get_float32_matmul_precision() != "highest"
+
+
+def _auto(setting: str, reduced: str, forward_precision) -> str:
+    if setting != "auto":
+        return setting
+    return reduced if (reference_allows_reduced_products() and forward_precision != "f32") else "f32"
+
+
+# Product form of the fused backward chain (njf_resnetfc_backward): "f32" = exact fp32 MFMA products (what every gradient row of
+# the test-suite is held to its fp64 floor with), "f16x2" = split fp16 products on power-of-two-scaled gradients (fp32-class,
+# 2^-22 per product where the reference's own training runs TF32 products; measured against the exact chain in
+# tests/test_training_gpu.py::test_backward_chain_f16x2_against_exact), "auto" (default) = see above.  Process-wide, like the
+# reference's torch.set_float32_matmul_precision.
+_BACKWARD_PRECISION = os.environ.get("NJF_BACKWARD_PRECISION", "auto")
 
 
 def set_backward_precision(name: str) -> None:
     global _BACKWARD_PRECISION
-    if name not in hip.BACKWARD_PRECISIONS:
-        raise ValueError(f"backward precision must be one of {hip.BACKWARD_PRECISIONS} (got {name!r})")
+    if name != "auto" and name not in hip.BACKWARD_PRECISIONS:
+        raise ValueError(f"backward precision must be 'auto' or one of {hip.BACKWARD_PRECISIONS} (got {name!r})")
     _BACKWARD_PRECISION = name
 
 
-def backward_precision() -> str:
-    return _BACKWARD_PRECISION
+def backward_precision(forward_precision=None) -> str:
+    """The chain's product form for a network whose forward pass ran in ``forward_precision`` (None: unknown, taken as split)."""
+    return _auto(_BACKWARD_PRECISION, "f16x2", forward_precision)
 
 
 # Storage of what the weight-gradient GEMMs read (the K = points contractions deltas[l+1]^T act[l]: 2.95 GB per network and operand
-# on SURVEY's C4 shard).  "f32" (default): fp32 activations from the training forward, fp32 deltas from the chain, fp32 GEMMs.
-# "f16" (opt-in): the forward dumps the activations as fp16, the chain writes deltas x 2^k as fp16 (k from max|d_out|; its masks make
+# on SURVEY's C4 shard).  "f32": fp32 activations from the training forward, fp32 deltas from the chain, fp32 GEMMs.
+# "f16": the forward dumps the activations as fp16, the chain writes deltas x 2^k as fp16 (k from max|d_out|; its masks make
 # it independent of the activations' format), and the GEMMs run with fp16 operands and FP32 ACCUMULATION (torch.bmm(..., out_dtype=
 # float32)) -- 10 mantissa bits per operand, which is what the reference's own training arithmetic keeps (TF32: train.py:64-65).
-# Stated tolerance: tests/test_training_gpu.py::test_f16_training_storage_against_fp32_storage.
-_STORAGE_PRECISION = os.environ.get("NJF_TRAINING_STORAGE", "f32")
+# "auto" (default): see above.  Stated tolerance: tests/test_training_gpu.py::test_f16_training_storage_against_fp32_storage.
+_STORAGE_PRECISION = os.environ.get("NJF_TRAINING_STORAGE", "auto")
 
 
 def set_storage_precision(name: str) -> None:
     global _STORAGE_PRECISION
-    if name not in ("f32", "f16"):
-        raise ValueError(f"training storage must be 'f32' or 'f16' (got {name!r})")
+    if name not in ("auto", "f32", "f16"):
+        raise ValueError(f"training storage must be 'auto', 'f32' or 'f16' (got {name!r})")
     _STORAGE_PRECISION = name
 
 
-def storage_precision() -> str:
-    return _STORAGE_PRECISION
+def storage_precision(forward_precision=None) -> str:
+    return _auto(_STORAGE_PRECISION, "f16", forward_precision)
 
 
-def activation_dump_dtype() -> torch.dtype:
-    return torch.float16 if _STORAGE_PRECISION == "f16" else torch.float32
+def activation_dump_dtype(forward_precision=None) -> torch.dtype:
+    return torch.float16 if storage_precision(forward_precision) == "f16" else torch.float32
 
 
 def _tn_batched_f16(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
@@ -131,20 +148,21 @@ def _tn_batched_f16(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
 
 
 def resnetfc_backward_chain(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, want_colsum: bool = False,
-                            mask: torch.Tensor = None):
+                            mask: torch.Tensor = None, forward_precision=None):
     """The data-gradient chain of one ResnetFC as ONE fused launch (njf_resnetfc_backward): deltas [11,P,128], see
     include/njf_hip.h for the meaning of each slice (with ``want_colsum`` also their column sums [11,128], from the
     kernel's per-tile partial sums).  The transposed weights are packed per call (eleven small launches: the weights
     change with every optimiser step)."""
     w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
-    hip.pack_resnetfc_backward(p, "", w_t, precision=_BACKWARD_PRECISION)
-    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum, mask=mask, precision=_BACKWARD_PRECISION)
+    chain = backward_precision(forward_precision)
+    hip.pack_resnetfc_backward(p, "", w_t, precision=chain)
+    return hip.resnetfc_backward(d_out, act, w_t, want_colsum=want_colsum, mask=mask, precision=chain)
 
 
 def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torch.Tensor, pe: torch.Tensor,
                       foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
                       d_feats: torch.Tensor = None, samples_per_ray: int = 1, mask: torch.Tensor = None,
-                      latent_constants: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+                      latent_constants: torch.Tensor = None, forward_precision=None) -> Dict[str, torch.Tensor]:
     """Backward pass of one ResnetFC (resnet_fc.py:130-154) from the activations the HIP forward dumped.  ``mask`` [11,P,4] int32:
     the ReLU masks the same forward dumped -- the fused data-gradient chain then reads 16 instead of 512 bytes per point and layer
     (the weight-gradient GEMMs below are what still reads ``act``).
@@ -168,14 +186,16 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
         if mask is None:
             raise ValueError("the 16-bit training storage needs the forward's ReLU masks")
         w_t = torch.empty(hip.RESNET_BACKWARD_W_FLOATS, dtype=torch.float32, device=d_out.device)
-        hip.pack_resnetfc_backward(p, "", w_t, precision=_BACKWARD_PRECISION)
-        latent, deltas16, sums, unscale = hip.resnetfc_backward_f16_storage(d_out, w_t, mask, precision=_BACKWARD_PRECISION)
+        chain = backward_precision(forward_precision)
+        hip.pack_resnetfc_backward(p, "", w_t, precision=chain)
+        latent, deltas16, sums, unscale = hip.resnetfc_backward_f16_storage(d_out, w_t, mask, precision=chain)
         w_grads = _tn_batched_f16(deltas16[1:11], act[0:10]) * unscale
         deltas_latent = latent                                        # [3,P,128]: gradients w.r.t. the three hoisted latents
         delta0 = latent[0]
         grads["lin_out.weight"] = _tn(d_out, act[10].float())
     else:
-        deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True, mask=mask)   # sums [11,128]: deltas[l+1] <-> bias of layer l
+        deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True, mask=mask,
+                                               forward_precision=forward_precision)   # sums [11,128]: deltas[l+1] <-> bias of layer l
         w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
         deltas_latent = deltas[0:6:2]
         delta0 = deltas[0]
@@ -301,7 +321,8 @@ class ActionFlowFunction(torch.autograd.Function):
             p = {n[cut:]: t for n, t in zip(ctx.names, ctx.saved_tensors)}
             grads = resnetfc_backward(p, d_j, outs["jac_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"], feats_flat,
                                       samples_per_ray=s, mask=outs.get("jac_mask"),
-                                      latent_constants=action if ctx.kind == "flow_mlp" else None)
+                                      latent_constants=action if ctx.kind == "flow_mlp" else None,
+                                      forward_precision=outs.get("jac_forward_precision"))
             result = tuple(grads[n[cut:]] for n in ctx.names)
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
@@ -396,7 +417,8 @@ class FieldFunction(torch.autograd.Function):
             if g_sigma is not None:
                 d_out[:, 15] = g_sigma.reshape(pts) * clamp_exp(outs["density"].reshape(pts))
             grads = resnetfc_backward(den, d_out, outs["den_act"], outs["jac_pe"], outs["foot_idx"], outs["foot_w"],
-                                      feats_flat, d_feats, samples_per_ray=outs["weights"].shape[-1], mask=outs.get("den_mask"))
+                                      feats_flat, d_feats, samples_per_ray=outs["weights"].shape[-1], mask=outs.get("den_mask"),
+                                      forward_precision=outs.get("den_forward_precision"))
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[i] = grads[k]
         for lvl in range(ctx.n_prop):
@@ -407,7 +429,8 @@ class FieldFunction(torch.autograd.Function):
             net = dict(zip(JACOBIAN_PARAM_ORDER, params[n + 6 + lvl * n:n + 6 + (lvl + 1) * n]))
             d_out = (g.reshape(-1) * clamp_exp(d["density"].reshape(-1)))[:, None]
             grads = resnetfc_backward(net, d_out, d["act"], d["pe"], d["foot_idx"], d["foot_w"], feats_flat, d_feats,
-                                      samples_per_ray=d["density"].shape[-1], mask=d.get("mask"))
+                                      samples_per_ray=d["density"].shape[-1], mask=d.get("mask"),
+                                      forward_precision=d.get("forward_precision"))
             for i, k in enumerate(JACOBIAN_PARAM_ORDER):
                 out_grads[n + 6 + lvl * n + i] = grads[k]
         ctx.outs = None

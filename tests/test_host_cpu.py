@@ -503,6 +503,31 @@ def test_arm_head_registration_and_mode_switch():
         Model(fcfg(use_arm_model=True, arm_action_dim=3)).decoder.switch_mode("arm")
 
 
+def test_training_precision_follows_the_reference_matmul_switch():
+    """training.py's "auto" settings: the TF32-class backward forms are selected by torch.set_float32_matmul_precision("high") --
+    what the reference's train.py sets (train.py:64-65) -- for networks whose forward runs in a split precision, and only then."""
+    from neural_jacobian_field_amd import training
+    assert torch.get_float32_matmul_precision() == "highest"
+    try:
+        for fwd in (None, "f16f6", "f16x2", "f32"):
+            assert (training.backward_precision(fwd), training.storage_precision(fwd), training.activation_dump_dtype(fwd)) == \
+                ("f32", "f32", torch.float32)
+        torch.set_float32_matmul_precision("high")
+        for fwd in (None, "f16f6", "f16x2"):
+            assert (training.backward_precision(fwd), training.storage_precision(fwd), training.activation_dump_dtype(fwd)) == \
+                ("f16x2", "f16", torch.float16)
+        assert (training.backward_precision("f32"), training.storage_precision("f32")) == ("f32", "f32")
+        training.set_backward_precision("f32"); training.set_storage_precision("f32")     # explicit settings win
+        assert (training.backward_precision("f16f6"), training.storage_precision("f16f6")) == ("f32", "f32")
+        with pytest.raises(ValueError):
+            training.set_backward_precision("bf16")
+        with pytest.raises(ValueError):
+            training.set_storage_precision("f8")
+    finally:
+        torch.set_float32_matmul_precision("highest")
+        training.set_backward_precision("auto"); training.set_storage_precision("auto")
+
+
 def test_resnetfc_backward_latent_constant_columns_are_exact_algebra():
     """What flow_mlp's training relies on (training.resnetfc_backward, ``latent_constants``): with z = cat[f, a] and a constant per
     batch element, d lin_z.weight[:, C:] = sum_b a[b] (x) sum_{p in b} delta[p] -- checked against autograd of the plain formula."""

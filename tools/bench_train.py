@@ -41,12 +41,16 @@ def main():
     ap.add_argument("--seed", type=int, default=1234, help="torch seed of every rank (stratified jitter): the same step twice gives the same loss")
     ap.add_argument("--start-step", type=int, default=0,
                     help="global step of the first iteration (20000: steady state -- anneal exponent 1, proposal nets updated every sixth step)")
-    ap.add_argument("--backward-precision", choices=["f32", "f16x2"], default="f32",
-                    help="product form of the fused backward chain (training.set_backward_precision): exact fp32 (default) or split fp16 "
-                         "on scaled gradients (fp32-class; the reference trains on TF32 products)")
-    ap.add_argument("--storage", choices=["f32", "f16"], default="f32",
-                    help="what the weight-gradient GEMMs read (training.set_storage_precision): fp32 activations / deltas (default) or fp16 "
-                         "ones with fp32 accumulation (the reference trains on TF32 products)")
+    ap.add_argument("--matmul-precision", choices=["highest", "high"], default="highest",
+                    help="torch.set_float32_matmul_precision of the run.  'high' is what the reference's train.py sets (train.py:64-65: "
+                         "TF32 GEMMs in every training step); with the 'auto' settings below it selects the TF32-class forms of this "
+                         "backward pass (f16x2 chain + 16-bit storage) for the networks whose forward runs in a split precision")
+    ap.add_argument("--backward-precision", choices=["auto", "f32", "f16x2"], default="auto",
+                    help="product form of the fused backward chain (training.set_backward_precision): auto (follows --matmul-precision), "
+                         "exact fp32, or split fp16 on scaled gradients (fp32-class; the reference trains on TF32 products)")
+    ap.add_argument("--storage", choices=["auto", "f32", "f16"], default="auto",
+                    help="what the weight-gradient GEMMs read (training.set_storage_precision): auto (follows --matmul-precision), fp32 "
+                         "activations / deltas, or fp16 ones with fp32 accumulation (the reference trains on TF32 products)")
     args = ap.parse_args()
     mode = args.mode or args.mode_pos or "action"
     launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -65,8 +69,10 @@ def main():
         dist.barrier()
 
     from neural_jacobian_field_amd import model_wrapper as mw, synthetic, training
+    torch.set_float32_matmul_precision(args.matmul_precision)
     training.set_backward_precision(args.backward_precision)
     training.set_storage_precision(args.storage)
+    chain_form, storage_form = training.backward_precision("f16f6"), training.storage_precision("f16f6")   # what a split-precision net gets
     from neural_jacobian_field_amd.config import model_cfg_from_dict
     from neural_jacobian_field_amd.model import CameraInput, Model, ModelTarget, RenderingInput, RobotInput
     from neural_jacobian_field_amd.parallel import data_parallel_step
@@ -154,9 +160,13 @@ def main():
                 "mode": {"action": "action (Jacobian head only), encoder fwd included",
                          "perception": "perception (all parameters), encoder fwd+bwd included"}[mode],
                 "dtype": "forward: package default precision; backward chain: "
-                         + ("exact fp32 MFMA" if args.backward_precision == "f32" else "f16x2 (split fp16 products on power-of-two-scaled gradients)")
-                         + ("; weight-gradient GEMMs: fp32 operands" if args.storage == "f32" else
+                         + ("exact fp32 MFMA" if chain_form == "f32" else "f16x2 (split fp16 products on power-of-two-scaled gradients)")
+                         + ("; weight-gradient GEMMs: fp32 operands" if storage_form == "f32" else
                             "; weight-gradient GEMMs: fp16 activations x fp16 scaled deltas, fp32 accumulation (16-bit training storage)"),
+                "matmul_precision": {"torch.get_float32_matmul_precision": torch.get_float32_matmul_precision(),
+                                     "backward_precision": f"{args.backward_precision} -> {chain_form}",
+                                     "storage": f"{args.storage} -> {storage_form}",
+                                     "note": "the reference's train.py sets 'high' (TF32 GEMMs, train.py:64-65)"},
                 "data": "synthetic",
                 "config": {"workload": "C4: Allegro training step, ray-batch DP, one flattened gradient all-reduce per step",
                            "parallelism": f"dp{world}"},
