@@ -201,6 +201,16 @@ class Model(nn.Module):
             return   # a check synchronises with the host; it runs on the first eager forward instead
         self._range_pending, self._range_forwards, self._range_checked = False, 0, sig
         self.calibrate_precision(camera_input, rendering_input, robot_input)
+        # the same periodic check looks after the TF32-class backward forms (training.py: fp16 has a range, TF32 does not)
+        from . import training
+        if training.reduced_backward_overflowed(rendering_input.origins.device):
+            import warnings
+            warnings.warn("njf: a reduced-precision backward pass (f16x2 chain / 16-bit training storage) produced non-finite "
+                          "gradients since the last check -- its fp16 range was exceeded; switching the backward pass to exact fp32 "
+                          "(training.set_backward_precision('f32'), set_storage_precision('f32')).  Gradients of the steps in "
+                          "between were non-finite: reload the last checkpoint.", RuntimeWarning)
+            training.set_backward_precision("f32")
+            training.set_storage_precision("f32")
 
     def _inverse(self, name: str, m: torch.Tensor) -> torch.Tensor:
         """hip.inverse(m), kept while ``m`` is the same tensor object at the same version (a camera rig that does not move

@@ -136,6 +136,39 @@ def activation_dump_dtype(forward_precision=None) -> torch.dtype:
     return torch.float16 if storage_precision(forward_precision) == "f16" else torch.float32
 
 
+# Safety net of the TF32-class forms (fp16 has a range, TF32 does not): the chain runs on gradients scaled so that max|d_out| = 64
+# (2^9 of head room) and the 16-bit storage holds deltas x 2^k as halves -- a network whose transposed weights amplify a gradient
+# by more than that overflows to inf / NaN where the exact backward would not.  Every reduced backward call folds "were its results
+# finite?" into ONE device scalar (no host synchronisation); Model._maybe_check_range reads it at its periodic check (which
+# synchronises anyway), warns, and switches both settings to exact fp32 for the rest of the process.
+_reduced_flags: Dict[tuple, torch.Tensor] = {}
+
+
+def _note_reduced_results(*tensors: torch.Tensor) -> None:
+    dev = tensors[0].device
+    key = hip.device_key(dev)
+    flag = _reduced_flags.get(key)
+    if flag is None:
+        flag = _reduced_flags[key] = torch.zeros((), dtype=torch.float32, device=dev)
+    total = tensors[0].sum()
+    for t in tensors[1:]:
+        total = total + t.sum()
+    flag.add_(total * 0.0)          # inf * 0 = NaN * 0 = NaN: the flag turns NaN once and stays
+
+
+def reduced_backward_overflowed(device=None, reset: bool = True) -> bool:
+    """Did any TF32-class backward call since the last query produce a non-finite gradient?  (One host synchronisation.)"""
+    hit = False
+    for key, flag in list(_reduced_flags.items()):
+        if device is not None and key != hip.device_key(torch.device(device)):
+            continue
+        if bool(torch.isnan(flag).item()):
+            hit = True
+            if reset:
+                flag.zero_()
+    return hit
+
+
 def _tn_batched_f16(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
     """a[l]^T b[l] for fp16 operands [L,K,128] with fp32 accumulation and fp32 results (K split into groups as in _tn_batched)."""
     layers, k, n = a16.shape
@@ -193,10 +226,13 @@ def resnetfc_backward(p: Dict[str, torch.Tensor], d_out: torch.Tensor, act: torc
         deltas_latent = latent                                        # [3,P,128]: gradients w.r.t. the three hoisted latents
         delta0 = latent[0]
         grads["lin_out.weight"] = _tn(d_out, act[10].float())
+        _note_reduced_results(w_grads, sums)
     else:
         deltas, sums = resnetfc_backward_chain(p, d_out, act, want_colsum=True, mask=mask,
                                                forward_precision=forward_precision)   # sums [11,128]: deltas[l+1] <-> bias of layer l
         w_grads = _tn_batched(deltas[1:11], act[0:10])                   # [10,128,128]
+        if backward_precision(forward_precision) != "f32":
+            _note_reduced_results(sums)
         deltas_latent = deltas[0:6:2]
         delta0 = deltas[0]
         grads["lin_out.weight"] = _tn(d_out, act[10])

@@ -844,3 +844,50 @@ def test_reference_matmul_precision_selects_the_tf32_class_backward():
         # (exact HIP chain behind an exact-fp32 FORWARD: against the default-precision forward's gradient this is the 1e-3-class
         # difference of the two forward precisions -- ReLU-mask flips, sample placement -- plus torch's GEMMs as switched: sanity only)
         assert forced <= 5e-3 and torch.isfinite(forced_exact[n]).all(), (n, forced)
+
+
+def test_reduced_backward_reports_an_exceeded_fp16_range():
+    """The safety net of the TF32-class backward forms (training._note_reduced_results / reduced_backward_overflowed): a network whose
+    transposed weights amplify the gradient beyond the scaled chain's head room (max|d_out| = 64 of fp16's 65504) yields non-finite
+    gradients where the exact backward does not; every reduced call folds that into one device scalar, read (and reset) by the
+    model's periodic range check.  Ordinary weights leave it clear."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import __graft_entry__ as g
+    g.build()
+    from neural_jacobian_field_amd import training
+    from neural_jacobian_field_amd.training import JACOBIAN_PARAM_ORDER
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    P, T = 512, 64
+    shapes = {"lin_in.weight": (128, 63), "lin_in.bias": (128,), "lin_out.weight": (8, 128), "lin_out.bias": (8,)}
+    for b in range(5):
+        for fc in ("fc_0", "fc_1"):
+            shapes[f"blocks.{b}.{fc}.weight"], shapes[f"blocks.{b}.{fc}.bias"] = (128, 128), (128,)
+    for i in range(3):
+        shapes[f"lin_z.{i}.weight"], shapes[f"lin_z.{i}.bias"] = (128, 512), (128,)
+    assert set(shapes) == set(JACOBIAN_PARAM_ORDER)
+    act = torch.rand(11, P, 128, generator=gen).half().to(dev)
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (11, P, 4), generator=gen, dtype=torch.int64).to(torch.int32).to(dev)
+    pe = torch.randn(P, 64, generator=gen).to(dev)
+    foot_idx = torch.randint(0, T, (P, 4), generator=gen, dtype=torch.int64).to(torch.int32).to(dev)
+    foot_w = torch.rand(P, 4, generator=gen).to(dev)
+    feats = torch.randn(T, 512, generator=gen).to(dev)
+    d_out = torch.randn(P, 8, generator=gen).to(dev)
+
+    def run(weight_scale):
+        p = {k: (torch.randn(*v, generator=gen) * (weight_scale if k.endswith("weight") else 0.0)).to(dev) for k, v in shapes.items()}
+        return training.resnetfc_backward(p, d_out, act, pe, foot_idx, foot_w, feats, mask=mask)
+
+    training.reduced_backward_overflowed(dev)                      # (clear whatever earlier tests left)
+    try:
+        training.set_backward_precision("f16x2")
+        grads = run(0.08)                                          # kaiming-sized weights: gain ~1 per layer
+        assert all(torch.isfinite(v).all() for v in grads.values())
+        assert not training.reduced_backward_overflowed(dev)
+        grads = run(8.0)                                           # gain ~1e2 per layer: far beyond 2^9 over eleven layers
+        assert not all(torch.isfinite(v).all() for v in grads.values())
+        assert training.reduced_backward_overflowed(dev)           # reported ...
+        assert not training.reduced_backward_overflowed(dev)       # ... and reset by the query
+    finally:
+        training.set_backward_precision("auto")
