@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank")
     ap.add_argument("--scenes", type=int, default=7, help="scenes per rank (reference: 7, configurations/config.yaml:18-20)")
     ap.add_argument("--rays", type=int, default=256, help="rays per scene (reference: 256)")
+    ap.add_argument("--decoder", choices=["jacobian_mlp", "jacobian_transformer", "flow_mlp"], default="jacobian_mlp",
+                    help="action decoder (configurations/model/model_allegro.yaml:26 ships jacobian_transformer)")
+    ap.add_argument("--samples", type=int, default=64, help="proposal = final samples per ray (model_allegro.yaml: 256)")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--seed", type=int, default=1234, help="torch seed of every rank (stratified jitter): the same step twice gives the same loss")
@@ -79,11 +82,11 @@ def main():
 
     if os.environ.get("NJF_MIOPEN_FIND"):
         torch.backends.cudnn.benchmark = True
-    B, H, W, R, S, A = args.scenes, args.height, args.width, args.rays, 64, 8
+    B, H, W, R, S, A = args.scenes, args.height, args.width, args.rays, args.samples, 8
     torch.manual_seed(args.seed)
     model = Model(model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [S], "num_nerf_samples": S},
-                                       "action_decoder": {"name": "jacobian_mlp"}}))
-    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_mlp", A), seed=0))   # replicated weights
+                                       "action_decoder": {"name": args.decoder}}))
+    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes(args.decoder, A), seed=0))   # replicated weights
     model.to(dev).train()
     if os.environ.get("NJF_CHANNELS_LAST"):
         model.encoder.to(memory_format=torch.channels_last)
@@ -157,6 +160,7 @@ def main():
                 "ms_per_step": round(1e3 * dt, 3), "training_step_ms": round(1e3 * dt, 2), "higher_is_better": True, "scaling": "weak",
                 "rays_per_step": world * B * R, "samples": f"{S}+{S}", "train_rays_per_s": round(world * B * R / dt, 1),
                 "final_loss": float(loss), "gradient_bucket_bytes": bucket, "start_step": args.start_step,
+                "decoder": args.decoder,
                 "mode": {"action": "action (Jacobian head only), encoder fwd included",
                          "perception": "perception (all parameters), encoder fwd+bwd included"}[mode],
                 "dtype": "forward: package default precision; backward chain: "
