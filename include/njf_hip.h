@@ -267,9 +267,9 @@ typedef struct NjfRenderOutputs {
   /* training forward, all NULL for inference (P = B*R*S; layouts as in NjfActivationDump).  jac_pe / foot_idx /
    * foot_w select a training forward and are shared by both modes: with den_act + col_* it is the perception mode
    * (backward of the density net and the colour head), otherwise the action mode (backward of the Jacobian head:
-   * jac_act is required for NJF_JACOBIAN_MLP and must be NULL for NJF_JACOBIAN_TRANSFORMER, whose backward pass
-   * recomputes the head from the encoding and the footprint). */
-  float* jac_act;         /* [11, P, 128] activations of the Jacobian ResnetFC */
+   * jac_act is required for NJF_JACOBIAN_MLP; for NJF_JACOBIAN_TRANSFORMER it is optional and has another shape -- the head's
+   * residual stream [4, P, 64] that njf_transformer_backward reads). */
+  float* jac_act;         /* [11, P, 128] activations of the Jacobian ResnetFC; transformer head: [4, P, 64] residual stream */
   float* jac_pe;          /* [P, 64] positional encoding (the density and Jacobian nets see the same one) */
   int* foot_idx;          /* [P, 4] */
   float* foot_w;          /* [P, 4] */
@@ -394,6 +394,26 @@ int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* w_out, int 
 int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activations, const float* w_backward, int points,
                           float* deltas, float* colsum_partial, const unsigned* masks, int precision,
                           const float* d_out_absmax, void* deltas16, void* stream);
+
+/* The data-gradient chain of the folded Jacobian transformer head (ActionDecoderJacobianTransformer.compute_jacobian,
+ * action_decoder_jacobian.py:418-446 with model_components/transformer.py:38-135, as njf_render_forward evaluates it: decoder.py
+ * folds keys / values / LayerNorm affines into 64 x 64 matrices) in one launch, exact fp32 MFMA -- what autograd runs for the
+ * reference's parameterisation of the head.  Per layer l: n = norm(x), a = softmax_8(Mqk n + bqk), xm = x + Nov a + bo,
+ * n2 = norm(xm), u = W1' n2 + b1', h = gelu(u), x_next = xm + W2 h + b2.
+ * x [4,P,64]: the residual stream in front of layers 0, 1, 2 and behind layer 2 -- NjfRenderOutputs.jac_act of an action-mode
+ * training forward with NJF_JACOBIAN_TRANSFORMER (slice 3 is not read here: the caller contracts it with d_out for the output
+ * Linear's gradient).  d_out [P,d_out_dim]: gradient w.r.t. the head's 3A outputs.  keys = A (valid key slots per head).
+ * Outputs: wg_x, wg_dy [12,P,64] -- per layer l the pairs the weight gradients contract over the points, at 4l + (0, 1, 2, 3) for
+ * (Mqk, Nov, W1', W2): X = (n, a, n2, h), dY = (d dots, d xm, d u, d x_next); dW = dY^T X (K = points: library GEMM on the host),
+ * bias gradients = column sums of dY.  dx0 [P,64]: gradient w.r.t. the head's input (the query MLP's output): its weight gradient
+ * contracts with the positional encoding, its hoisted feature part goes through njf_scatter_footprint.
+ * njf_pack_transformer_backward: mats [3,4,64,64] = (Mqk, Nov, W1', W2) per layer, row-major [out][in]; biases [3,3,64] = (bqk, bo,
+ * b1'); head_w [d_out,64]; -> w_out (NJF_TRANSFORMER_BACKWARD_CHUNKS chunks), b_out [3,192]. */
+#define NJF_TRANSFORMER_BACKWARD_CHUNKS 13
+int njf_pack_transformer_backward(const float* mats, const float* biases, const float* head_w, int d_out, float* w_out,
+                                  float* b_out, void* stream);
+int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points, const float* w_backward,
+                             const float* b_backward, float* wg_x, float* wg_dy, float* dx0, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

@@ -1386,10 +1386,38 @@ __device__ __forceinline__ void norm64(const f32x16 (&x)[2], f32x16 (&n)[2]) {
     for (int r = 0; r < 16; ++r) n[m][r] = fmaf(x[m][r], rstd, shift);   // (x - mean) * rstd as one fma
 }
 
+// this lane's 32 values of a 64-wide tile (logical features 32*hh + 16*m + r) <-> dst / src = row + 32*hh
+__device__ __forceinline__ void store_vec64(float* __restrict__ dst, const f32x16 (&v)[2]) {
+  if (dst == nullptr) return;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[m][4 * q + e];
+      *(f32x4*)(dst + 16 * m + 4 * q) = o;
+    }
+}
+__device__ __forceinline__ void load_vec64(const float* __restrict__ src, bool ok, f32x16 (&v)[2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (ok) o = *(const f32x4*)(src + 16 * m + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[m][4 * q + e] = o[e];
+    }
+}
+
+// `xdump` (training forward, action mode: the head's backward pass, njf_transformer_backward): this lane's slot of slice 0 of
+// [4][P][64] -- the residual stream IN FRONT of each of the three layers and behind the last one; `xstride` = P * 64; nullptr = no dump
 template <int PREC, class ST>
 __device__ __forceinline__ void transformer_tile(ST& st, const float* __restrict__ bias,
                                                  const float* __restrict__ gq, const PointGeom& g,
-                                                 const f32x16 (&pe)[2], int keys, int wave, int lane, f32x16 (&out)[1]) {
+                                                 const f32x16 (&pe)[2], int keys, int wave, int lane, f32x16 (&out)[1],
+                                                 float* __restrict__ xdump = nullptr, size_t xstride = 0) {
   const int hh = lane >> 5;
   f32x16 x[2], n[2], t[2];
   x[0] = (f32x16)(0.f);
@@ -1399,6 +1427,7 @@ __device__ __forceinline__ void transformer_tile(ST& st, const float* __restrict
   add_hoisted_latent<2, PREC>(gq, g, lane, x);    // query MLP, feature part (hoisted)
   for (int l = 0; l < 3; ++l) {
     const float* bl = bias + 256 * l;
+    if (xdump != nullptr) store_vec64(xdump + (size_t)l * xstride, x);
     norm64(x, n);
     bias_init<2, true, PREC>(bl, hh, t);
     mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, n, t);  // dots[head*8 + key]
@@ -1443,8 +1472,57 @@ __device__ __forceinline__ void transformer_tile(ST& st, const float* __restrict
     bias_init<2, false, PREC>(bl + 192, hh, x);
     mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, t, x);  // x += FF
   }
+  if (xdump != nullptr) store_vec64(xdump + 3 * xstride, x);
   bias_init<1, true, PREC>(bias + 768, hh, out);
   mma_chunk<PREC, 1, 2, 0, false, 2>(st, wl + 4096, lane, x, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward pieces of the folded transformer head on a 32-point x 64-channel tile (njf_transformer_backward)
+// ------------------------------------------------------------------------------------------
+// norm64 that also returns 1 / sqrt(var + eps): what the backward of the (affine-free) normalisation needs next to n itself
+__device__ __forceinline__ float norm64_rstd(const f32x16 (&x)[2], f32x16 (&n)[2]) {
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += x[m][r];
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / 64.0f;
+  float v = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = x[m][r] - mean;
+      v = fmaf(d, d, v);
+    }
+  v += __shfl_xor(v, 32, 64);
+  const float rstd = __builtin_amdgcn_rsqf(v / 64.0f + 1e-5f);
+  const float shift = -mean * rstd;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) n[m][r] = fmaf(x[m][r], rstd, shift);
+  return rstd;
+}
+// n = (x - mean) * rstd over 64 channels  =>  dx = rstd * (dn - mean(dn) - n * mean(dn * n));  acc += dx
+__device__ __forceinline__ void norm64_backward(const f32x16 (&dn)[2], const f32x16 (&n)[2], float rstd, f32x16 (&acc)[2]) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0 += dn[m][r];
+      s1 = fmaf(dn[m][r], n[m][r], s1);
+    }
+  s0 += __shfl_xor(s0, 32, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  const float m0 = s0 / 64.0f, m1 = s1 / 64.0f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = fmaf(rstd, dn[m][r] - m0 - n[m][r] * m1, acc[m][r]);
 }
 
 // ------------------------------------------------------------------------------------------

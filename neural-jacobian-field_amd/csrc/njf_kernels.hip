@@ -1428,7 +1428,8 @@ __device__ __forceinline__ void jacobian_stage(ST& st, const float* __restrict__
           *(f32x4*)(dump.pe + 16 * kb + 4 * q) = o;
         }
     }
-    transformer_tile<PREC>(st, bias, gz_j, g, pe, action_dim, wave, lane, jac);
+    // (training forward: dump.act addresses the head's residual-stream dump [4][P][64], render_kernel)
+    transformer_tile<PREC>(st, bias, gz_j, g, pe, action_dim, wave, lane, jac, DUMP == 1 ? dump.act : nullptr, dump.stride);
   }
   }
   // flow_s = sum_a J[3a+s] * action[a]  (action_decoder_jacobian.py:128-145); this lane holds
@@ -1554,6 +1555,14 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) render_kernel(RenderArgs a) {
       const NjfActivationDump d{DUMP == 1 ? a.out.jac_act : a.out.den_act, a.out.jac_pe, a.out.foot_idx, a.out.foot_w,
                                 DUMP == 1 ? a.out.jac_mask : a.out.den_mask, a.out.dump_f16};
       dump = point_dump(d, si, points, hh, g, b * a.rc.gmap.height * a.rc.gmap.width, a.rc.gmap.stride);
+      if constexpr (JKIND == 2 && DUMP == 1) {
+        // the transformer head's backward pass (njf_transformer_backward) recomputes each layer from the residual stream in front
+        // of it: jac_act is [4][P][64] here -- x before layers 0, 1, 2 and behind layer 2 -- written by transformer_tile
+        dump.act = a.out.jac_act ? a.out.jac_act + si * 64 + 32 * hh : nullptr;
+        dump.stride = points * 64;
+        dump.mask = nullptr;
+        dump.half = false;
+      }
       if (DUMP == 2) cdump = ColorDump{a.out.col_in + si * 32 + 16 * hh, a.out.col_act + si * 64 + 32 * hh, points * 64};
     }
     // ---- density net -> sample weight; everything that only needs the weight is composited right away
@@ -2476,6 +2485,149 @@ extern "C" int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* 
 }
 
 // =============================================================================================
+// Backward of the folded Jacobian transformer head (transformer_tile): the data-gradient chain of its three layers in ONE launch,
+// in exact fp32 MFMA.  Per layer l (x = residual stream in front of it, dumped by the training forward; dx = gradient behind it):
+//   forward again:  n = norm(x);  a = softmax_8(Mqk n + bqk);  xm = x + Nov a + bo;  n2 = norm(xm);  u = W1' n2 + b1';  h = gelu(u)
+//   backward:       du  = (W2^T dx) * gelu'(u)                      dxm = dx + norm'(W1'^T du ; n2)
+//                   ds  = softmax'(a ; Nov^T dxm)                   dx  = dxm + norm'(Mqk^T ds ; n)     (= gradient in front of l)
+// and, like njf_resnetfc_backward, it EMITS per layer the pairs a weight gradient contracts over the points (K = points: one
+// batched library GEMM on the host): X = (n, a, n2, h) and dY = (ds, dxm, du, dx) for (Mqk, Nov, W1', W2).  What autograd runs for
+// the reference's parameterisation of the same head (transformer.py:38-135 recomputed in library ops: 54 ms of a 62 ms action
+// step on SURVEY's C4 shard) -- the gradients of the FOLDED matrices go back to the reference's parameters through the fold's
+// own autograd graph on the host (64 x 64 matrices).
+// Weight blob (13 chunks, two 64 x 64 matrices each): [Wj^T | -] then for l = 2, 1, 0: [Mqk | Nov] [W1' | W2^T] [W1'^T | Nov^T]
+// [Mqk^T | -];  bias blob [3][192] = (bqk | bo | b1') per layer.
+// =============================================================================================
+
+struct TransformerBwdArgs {
+  const float* x;        // [4, P, 64] residual stream (NjfRenderOutputs.jac_act of a transformer-head training forward)
+  const float* d_out;    // [P, d_out_dim]
+  int d_out_dim, keys, points;
+  const float* w_pack;   // NJF_TRANSFORMER_BACKWARD_CHUNKS chunks
+  const float* b_pack;   // [3][192]
+  float* wg_x;           // [12, P, 64]  X of (Mqk, Nov, W1', W2) of layer l at 4l + (0, 1, 2, 3)
+  float* wg_dy;          // [12, P, 64]  dY, same order
+  float* dx0;            // [P, 64] gradient w.r.t. the head's input (query MLP output)
+};
+
+__global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(TransformerBwdArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int tile = blockIdx.x * NJF_WAVES + wave;
+  const int p = tile * 32 + j;
+  const bool ok = p < a.points;
+  const size_t pc = (size_t)min(p, a.points - 1);
+  const size_t slice = (size_t)a.points * 64;
+  const size_t row = pc * 64 + 32 * hh;
+  load_bias_block(a.b_pack, 3 * 192, 0);
+  WeightStream st;
+  stream_begin(st, a.w_pack, NJF_TRANSFORMER_BACKWARD_CHUNKS, 1, wave, lane);
+  const float* bias = njf_lds + LDS_BIAS;
+  float* const wx = ok ? a.wg_x + row : nullptr;
+  float* const wy = ok ? a.wg_dy + row : nullptr;
+  auto slot = [&](float* base, int k) -> float* { return base ? base + (size_t)k * slice : nullptr; };
+
+  f32x16 din[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = 16 * hh + r;
+    din[0][r] = (ok && d < a.d_out_dim) ? a.d_out[pc * a.d_out_dim + d] : 0.f;
+  }
+  f32x16 dx[2], xin[2], n[2], t[2], n2[2], u[2];
+  dx[0] = (f32x16)(0.f);
+  dx[1] = (f32x16)(0.f);
+  const float* wl = stream_step(st, wave, lane);
+  mma_chunk<PREC_F32, 2, 1, 0, false, 1>(st, wl, lane, din, dx);   // Wj^T: gradient behind layer 2
+  for (int l = 2; l >= 0; --l) {
+    const float* bl = bias + 192 * l;
+    load_vec64(a.x + (size_t)l * slice + row, true, xin);
+    // ---- the layer again -----------------------------------------------------------------------------------------
+    const float rstd1 = norm64_rstd(xin, n);
+    store_vec64(slot(wx, 4 * l + 0), n);
+    bias_init<2, true, PREC_F32>(bl, hh, t);
+    wl = stream_step(st, wave, lane);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, n, t);            // dots[head * 8 + key]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h8 = 0; h8 < 2; ++h8) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < a.keys) mx = fmaxf(mx, t[m][8 * h8 + k]);
+        float e[8], sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          e[k] = (k < a.keys) ? __builtin_amdgcn_exp2f((t[m][8 * h8 + k] - mx) * 1.4426950408889634f) : 0.f;
+          sum += e[k];
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] = e[k] * inv;       // a
+      }
+    store_vec64(slot(wx, 4 * l + 1), t);
+    bias_init<2, false, PREC_F32>(bl + 64, hh, xin);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, t, xin);    // xm = x + Nov a + bo
+    const float rstd2 = norm64_rstd(xin, n2);
+    store_vec64(slot(wx, 4 * l + 2), n2);
+    bias_init<2, true, PREC_F32>(bl + 128, hh, u);
+    wl = stream_step(st, wave, lane);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, n2, u);           // u = W1' n2 + b1'
+    {
+      f32x16 hval[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = u[m][r];
+          const float cdf = 0.5f * (1.0f + erf_branchless(v * 0.70710678118654752440f));
+          hval[m][r] = v * cdf;                                             // gelu(u)
+          // gelu'(u) = Phi(u) + u phi(u),  phi(u) = exp(-u^2 / 2) / sqrt(2 pi)
+          u[m][r] = fmaf(v * 0.3989422804014327f, __builtin_amdgcn_exp2f(v * v * -0.7213475204444817f), cdf);
+        }
+      store_vec64(slot(wx, 4 * l + 3), hval);
+    }
+    // ---- and backwards ---------------------------------------------------------------------------------------------
+    store_vec64(slot(wy, 4 * l + 3), dx);                                    // W2:  dY = dx
+    xin[0] = (f32x16)(0.f);
+    xin[1] = (f32x16)(0.f);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // W2^T dx
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[m][r] *= xin[m][r];                     // du
+    store_vec64(slot(wy, 4 * l + 2), u);                                     // W1': dY = du
+    xin[0] = (f32x16)(0.f);
+    xin[1] = (f32x16)(0.f);
+    wl = stream_step(st, wave, lane);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, u, xin);           // W1'^T du = dn2
+    norm64_backward(xin, n2, rstd2, dx);                                     // dxm = dx + norm'(dn2)
+    store_vec64(slot(wy, 4 * l + 1), dx);                                    // Nov: dY = dxm
+    xin[0] = (f32x16)(0.f);
+    xin[1] = (f32x16)(0.f);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // Nov^T dxm = da
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h8 = 0; h8 < 2; ++h8) {
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dot = fmaf(t[m][8 * h8 + k], xin[m][8 * h8 + k], dot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] *= xin[m][8 * h8 + k] - dot;   // ds = a (da - <a, da>)
+      }
+    store_vec64(slot(wy, 4 * l + 0), t);                                     // Mqk: dY = ds
+    xin[0] = (f32x16)(0.f);
+    xin[1] = (f32x16)(0.f);
+    wl = stream_step(st, wave, lane);
+    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, t, xin);           // Mqk^T ds = dn
+    norm64_backward(xin, n, rstd1, dx);                                      // gradient in front of layer l
+  }
+  if (ok) store_vec64(a.dx0 + row, dx);
+}
+
+// =============================================================================================
 // stand-alone sampler ops
 // =============================================================================================
 __global__ void __launch_bounds__(256) alpha_weights_kernel(const float* __restrict__ deltas,
@@ -2878,7 +3030,8 @@ extern "C" int njf_render_forward(const float* origins, const float* directions,
       if (!out->jac_act) return NJF_E_NULL;
       return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<1, NJF_P, 1, TRAIN_AF, NJF_PJ>, a, n, s); });
     }
-    if (out->jac_act) return NJF_E_MODE;
+    // (transformer head: jac_act is optional and has another shape, [4, P, 64]: the residual stream njf_transformer_backward reads)
+    if (out->dump_f16 || out->jac_mask) return NJF_E_MODE;
     return with_precisions<true>(precision, [&](auto P, auto PJ) { return launch_fused(render_kernel<2, NJF_P, 1, TRAIN_AF, NJF_PJ>, a, n, s); });
   }
   if (out->den_act != nullptr) {  // perception-mode training forward: dump the density net and the colour head
@@ -2972,3 +3125,40 @@ extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const fl
   if (precision != NJF_PRECISION_F32) return NJF_E_MODE;
   return launch_fused(resnetfc_backward_kernel<PREC_F32>, a, (points + 31) / 32, (hipStream_t)stream);
 }
+
+extern "C" int njf_pack_transformer_backward(const float* mats, const float* biases, const float* head_w, int d_out,
+                                             float* w_out, float* b_out, void* stream) {
+  // mats [3][4][64][64] row-major [out][in] = (Mqk, Nov, W1', W2) per layer; biases [3][3][64] = (bqk, bo, b1') per layer;
+  // head_w [d_out][64] = the output Linear.  w_out: NJF_TRANSFORMER_BACKWARD_CHUNKS chunks, b_out [3][192]
+  if (!mats || !biases || !head_w || !w_out || !b_out) return NJF_E_NULL;
+  if (d_out < 1 || d_out > 32) return NJF_E_DOUT;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = NJF_PRECISION_F32;
+  fill_kernel<<<64, 256, 0, s>>>(w_out, NJF_TRANSFORMER_BACKWARD_CHUNKS * NJF_CHUNK_FLOATS, 0.f);
+  launch_pack(head_w, nullptr, 64, d_out, 2, 1, 3, P, w_out, nullptr, s);                      // Wj^T: 64 rows, K = d_out (<= 32)
+  for (int l = 2, c = 1; l >= 0; --l, c += 4) {
+    const float* m = mats + (size_t)l * 4 * 4096;
+    const float* b = biases + (size_t)l * 192;
+    float* base = w_out + (size_t)c * NJF_CHUNK_FLOATS;
+    launch_pack(m, b, 64, 64, 2, 2, 0, P, base, b_out + 192 * l, s);                           // Mqk (+ bqk)
+    launch_pack(m + 4096, b + 64, 64, 64, 2, 2, 0, P, base + 4096, b_out + 192 * l + 64, s);   // Nov (+ bo)
+    launch_pack(m + 2 * 4096, b + 128, 64, 64, 2, 2, 0, P, base + NJF_CHUNK_FLOATS, b_out + 192 * l + 128, s);   // W1' (+ b1')
+    launch_pack(m + 3 * 4096, nullptr, 64, 64, 2, 2, 3, P, base + NJF_CHUNK_FLOATS + 4096, nullptr, s);          // W2^T
+    launch_pack(m + 2 * 4096, nullptr, 64, 64, 2, 2, 3, P, base + 2 * NJF_CHUNK_FLOATS, nullptr, s);             // W1'^T
+    launch_pack(m + 4096, nullptr, 64, 64, 2, 2, 3, P, base + 2 * NJF_CHUNK_FLOATS + 4096, nullptr, s);          // Nov^T
+    launch_pack(m, nullptr, 64, 64, 2, 2, 3, P, base + 3 * NJF_CHUNK_FLOATS, nullptr, s);                        // Mqk^T
+  }
+  return launch_status();
+}
+
+extern "C" int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points,
+                                        const float* w_backward, const float* b_backward, float* wg_x, float* wg_dy,
+                                        float* dx0, void* stream) {
+  if (!x || !d_out || !w_backward || !b_backward || !wg_x || !wg_dy || !dx0) return NJF_E_NULL;
+  if (points < 1 || (long long)points * 12 * 64 > 0x7fffffffffLL) return NJF_E_SHAPE;
+  if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
+  if (keys < 1 || keys > 8) return NJF_E_ACTION_DIM;
+  TransformerBwdArgs a{x, d_out, d_out_dim, keys, points, w_backward, b_backward, wg_x, wg_dy, dx0};
+  return launch_fused(transformer_backward_kernel, a, (points + 31) / 32, (hipStream_t)stream);
+}
+

@@ -520,11 +520,15 @@ class Model(nn.Module):
             pts = b * r * s
             outs["weights"] = outs.get("weights", torch.empty(b, r, s, **f32))
             outs["pos_warped"] = outs.get("pos_warped", torch.empty(b, r, 3, **f32))
-            if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:  # the transformer head is recomputed from pe + footprint
+            if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:
                 from . import training as _tr   # (fp16 under the opt-in 16-bit training storage, training.set_storage_precision)
                 outs["jac_forward_precision"] = self.decoder.j_precision    # (what training.py's "auto" settings follow)
                 outs["jac_act"] = torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(self.decoder.j_precision), device=dev)
                 outs["jac_mask"] = torch.empty(11, pts, 4, dtype=torch.int32, device=dev)   # ReLU masks: what the backward chain reads
+            elif self.decoder.JACOBIAN_KIND == hip.JACOBIAN_TRANSFORMER:
+                # the transformer head's residual stream in front of its three layers and behind the last one: what its fused
+                # backward chain (njf_transformer_backward, training.transformer_head_backward) recomputes each layer from
+                outs["jac_act"] = torch.empty(4, pts, 64, **f32)
             outs["jac_pe"] = torch.empty(pts, 64, **f32)
             outs["foot_idx"] = torch.empty(pts, 4, dtype=torch.int32, device=dev)
             outs["foot_w"] = torch.empty(pts, 4, **f32)

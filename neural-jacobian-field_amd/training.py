@@ -313,6 +313,84 @@ def transformer_head(p: Dict[str, torch.Tensor], xyz_features: torch.Tensor, pix
     return torch.nn.functional.linear(x, p["jacobian_head.weight"], p["jacobian_head.bias"])
 
 
+def folded_transformer(p: Dict[str, torch.Tensor], heads: int = 8) -> Dict[str, torch.Tensor]:
+    """The FOLDED form of the transformer head that the fused kernels evaluate (decoder.ActionDecoderJacobianTransformer.
+    _pack_regular_jacobian restated as differentiable torch ops on the reference's parameters, names relative to the decoder):
+    ``mats`` [3,4,64,64] = (Mqk, Nov, W1', W2) per layer, ``biases`` [3,4,64] = (bqk, bo, b1', b2).  Keys / values depend only on
+    the learned index embedding, so to_q . K^T / sqrt(d) and V . to_out are 64 x 64 matrices (rows of Mqk / columns of Nov ordered
+    head * 8 + key, unused key slots zero); the LayerNorm affines are folded into Mqk / W1'.  The fold's own autograd graph is what
+    carries the gradients of the folded matrices (njf_transformer_backward) back to the reference's parameters."""
+    z = p["jacobian_index_embedding"][0]                                  # [A, 64]
+    a = z.shape[0]
+    mats, biases = [], []
+    layer = 0
+    while f"jacobian_attn_decoder.layers.{layer}.0.norm.weight" in p:
+        pre = f"jacobian_attn_decoder.layers.{layer}."
+        g1, be1 = p[pre + "0.norm.weight"], p[pre + "0.norm.bias"]
+        kv = z @ p[pre + "0.fn.to_kv.weight"].t()                         # [A, 2 * H * dh]
+        inner = kv.shape[1] // 2
+        dh = inner // heads
+        k = kv[:, :inner].reshape(a, heads, dh).permute(1, 0, 2)          # [H, A, dh]
+        v = kv[:, inner:].reshape(a, heads, dh).permute(1, 0, 2)
+        wq = p[pre + "0.fn.to_q.weight"].reshape(heads, dh, -1)           # [H, dh, 64]
+        c = wq.shape[-1]
+        mqk = torch.zeros(heads, 8, c, dtype=z.dtype, device=z.device)
+        mqk[:, :a] = (dh ** -0.5) * torch.einsum("had,hdc->hac", k, wq)
+        mqk = mqk.reshape(heads * 8, c)
+        wo = p[pre + "0.fn.to_out.0.weight"].reshape(-1, heads, dh)       # [64, H, dh]
+        nov = torch.zeros(wo.shape[0], heads, 8, dtype=z.dtype, device=z.device)
+        nov[:, :, :a] = torch.einsum("chd,had->cha", wo, v)
+        nov = nov.reshape(wo.shape[0], heads * 8)
+        g2, be2 = p[pre + "1.norm.weight"], p[pre + "1.norm.bias"]
+        w1, b1 = p[pre + "1.fn.net.0.weight"], p[pre + "1.fn.net.0.bias"]
+        mats.append(torch.stack([mqk * g1[None, :], nov, w1 * g2[None, :], p[pre + "1.fn.net.3.weight"]]))
+        biases.append(torch.stack([mqk @ be1, p[pre + "0.fn.to_out.0.bias"], w1 @ be2 + b1, p[pre + "1.fn.net.3.bias"]]))
+        layer += 1
+    return {"mats": torch.stack(mats), "biases": torch.stack(biases)}
+
+
+def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tensor], d_j: torch.Tensor, x: torch.Tensor,
+                              pe: torch.Tensor, foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
+                              samples_per_ray: int = 1):
+    """Gradients of the transformer Jacobian head's parameters (names relative to the decoder, any order) from d_j [P,3A], the
+    residual stream x [4,P,64] the training forward dumped, the dumped encoding pe [P,64] (slot order) and footprint.
+    ONE fused launch for the data-gradient chain (njf_transformer_backward, exact fp32 MFMA on the folded head), one batched
+    library GEMM for the K = points weight gradients of the twelve folded matrices, the footprint scatter for the hoisted query
+    features, and the fold's autograd graph (64 x 64 matrices) back to the reference's parameterisation."""
+    leaves = [t.detach().double().requires_grad_(True) for t in params]
+    p64 = dict(zip(names, leaves))
+    with torch.enable_grad():
+        folded = folded_transformer(p64)
+    mats32, biases32 = folded["mats"].detach().float(), folded["biases"].detach().float()
+    head_w = p64["jacobian_head.weight"].detach().float()
+    dev = d_j.device
+    w_t = torch.empty(hip.TRANSFORMER_BACKWARD_W_FLOATS, dtype=torch.float32, device=dev)
+    b_t = torch.empty(hip.TRANSFORMER_BACKWARD_B_FLOATS, dtype=torch.float32, device=dev)
+    hip.pack_transformer_backward(mats32, biases32[:, :3].contiguous(), head_w, w_t, b_t)
+    keys = p64["jacobian_index_embedding"].shape[1]
+    wg_x, wg_dy, dx0 = hip.transformer_backward(x, d_j, keys, w_t, b_t)
+    g_mats = _tn_batched(wg_dy, wg_x).reshape(3, 4, 64, 64)                 # dY^T X per folded matrix: [out, in]
+    g_biases = wg_dy.sum(1).reshape(3, 4, 64)                               # (bqk, bo, b1', b2): column sums of the dY
+    grads: Dict[str, torch.Tensor] = {}
+    with torch.enable_grad():
+        through_fold = torch.autograd.grad([folded["mats"], folded["biases"]], leaves, [g_mats.double(), g_biases.double()],
+                                           allow_unused=True)
+    for n, g in zip(names, through_fold):
+        if g is not None:
+            grads[n] = g
+    # output Linear: J = Wj x3 + bj
+    grads["jacobian_head.weight"] = _tn(d_j, x[3]).double()
+    grads["jacobian_head.bias"] = d_j.sum(0).double()
+    # query MLP: x0 = Wq [pe | bilinear(features)] + bq  (action_decoder_jacobian.py:421-427)
+    d_q = _tn(dx0, pe)                                                       # [64, 64 slots]; slot 63 is the bias
+    d_pe = d_q.new_zeros(64, 63).index_copy_(1, _slot_to_channel(dev), d_q[:, :63])
+    d_g = torch.zeros(feats_flat.shape[0], 64, dtype=torch.float32, device=dev)
+    hip.scatter_footprint(dx0, foot_idx, foot_w, d_g, run_length=samples_per_ray)
+    grads["jacobian_query_mlp.weight"] = torch.cat([d_pe, _tn(d_g, feats_flat)], dim=1).double()
+    grads["jacobian_query_mlp.bias"] = d_q[:, 63].double()
+    return tuple(grads[n].to(t.dtype).reshape(t.shape) if n in grads else torch.zeros_like(t) for n, t in zip(names, params))
+
+
 class ActionFlowFunction(torch.autograd.Function):
     """optical_flow = f(Jacobian-head parameters); every other input is a constant captured by ``run``.
     ``names``: the parameters' names relative to the decoder, ``kind``: ``jacobian_mlp`` | ``jacobian_transformer`` | ``flow_mlp``
@@ -360,6 +438,11 @@ class ActionFlowFunction(torch.autograd.Function):
                                       latent_constants=action if ctx.kind == "flow_mlp" else None,
                                       forward_precision=outs.get("jac_forward_precision"))
             result = tuple(grads[n[cut:]] for n in ctx.names)
+        elif outs.get("jac_act") is not None and os.environ.get("NJF_TRANSFORMER_BACKWARD", "hip") != "torch":
+            # jacobian_transformer: the fused chain on the residual stream the forward dumped (round 6; the recomputation in
+            # library ops below was 54 ms of a 62 ms action step on SURVEY's C4 shard and stays as the comparator of the tests)
+            result = transformer_head_backward(ctx.names, ctx.saved_tensors, d_j, outs["jac_act"], outs["jac_pe"],
+                                               outs["foot_idx"], outs["foot_w"], feats_flat, samples_per_ray=s)
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
             xyz_features = pe.new_empty(pe.shape[0], 63)
