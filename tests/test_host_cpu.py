@@ -528,6 +528,43 @@ def test_training_precision_follows_the_reference_matmul_switch():
         training.set_backward_precision("auto"); training.set_storage_precision("auto")
 
 
+def test_folded_transformer_head_is_exact_algebra_and_differentiable():
+    """training.folded_transformer: the folded form the fused kernels evaluate (and whose gradients njf_transformer_backward produces)
+    equals the head in the reference's parameterisation (training.transformer_head = action_decoder_jacobian.py:418-446 with
+    transformer.py:38-135) to float64 rounding, for A = 6 (two unused key slots per head) and A = 8 -- and gradients pushed through
+    the fold's autograd graph equal autograd through the original head."""
+    from neural_jacobian_field_amd import synthetic, training
+    for a_dim in (6, 8):
+        shapes = synthetic.decoder_shapes("jacobian_transformer", a_dim)
+        p = {k[len("decoder."):]: v.double() for k, v in synthetic.seeded_state_dict(shapes, seed=3).items()
+             if k.startswith("decoder.jacobian")}
+        for v in p.values():
+            v.requires_grad_(True)
+        g = torch.Generator().manual_seed(a_dim)
+        pts = 40
+        xyz = torch.randn(pts, 63, generator=g, dtype=torch.float64)
+        feats = torch.randn(pts, 512, generator=g, dtype=torch.float64)
+        upstream = torch.randn(pts, 3 * a_dim, generator=g, dtype=torch.float64)
+        ref = training.transformer_head(p, xyz, feats)
+        ref_grads = torch.autograd.grad(ref, list(p.values()), upstream)
+        folded = training.folded_transformer(p)
+        norm = lambda t: (t - t.mean(-1, keepdim=True)) / torch.sqrt(t.var(-1, unbiased=False, keepdim=True) + 1e-5)
+        x = torch.nn.functional.linear(torch.cat([xyz, feats], -1), p["jacobian_query_mlp.weight"], p["jacobian_query_mlp.bias"])
+        valid = torch.arange(8) < a_dim
+        for l in range(3):
+            m, b = folded["mats"][l], folded["biases"][l]
+            dots = (norm(x) @ m[0].t() + b[0]).reshape(pts, 8, 8).masked_fill(~valid, float("-inf"))
+            x = x + torch.softmax(dots, -1).reshape(pts, 64) @ m[1].t() + b[1]
+            x = x + torch.nn.functional.gelu(norm(x) @ m[2].t() + b[2]) @ m[3].t() + b[3]
+        out = torch.nn.functional.linear(x, p["jacobian_head.weight"], p["jacobian_head.bias"])
+        assert (out - ref).abs().max() <= 1e-12 * ref.abs().max()
+        got = torch.autograd.grad(out, list(p.values()), upstream)
+        for name, g_ref, g_got in zip(p, ref_grads, got):
+            assert (g_got - g_ref).abs().max() <= 1e-9 * (g_ref.abs().max() + 1e-30), name
+        # rows / columns of the unused key slots are structurally zero
+        assert a_dim == 8 or float(folded["mats"].detach()[:, 0].reshape(3, 8, 8, 64)[:, :, a_dim:].abs().max()) == 0.0
+
+
 def test_resnetfc_backward_latent_constant_columns_are_exact_algebra():
     """What flow_mlp's training relies on (training.resnetfc_backward, ``latent_constants``): with z = cat[f, a] and a constant per
     batch element, d lin_z.weight[:, C:] = sum_b a[b] (x) sum_{p in b} delta[p] -- checked against autograd of the plain formula."""
