@@ -2325,6 +2325,27 @@ __device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __res
     }
 }
 
+// the same for a 64-wide tile (two accumulator blocks; dst = the layer's 64 sums + 32 * hh)
+__device__ __forceinline__ void tile_colsum64(const f32x16 (&acc)[2], float* __restrict__ dst, int lane) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[m][4 * q + e];
+        v = dpp_add<0x128, 0xf>(v);  // row_ror:8
+        v = dpp_add<0x124, 0xf>(v);  // row_ror:4
+        v = dpp_add<0x122, 0xf>(v);  // row_ror:2
+        v = dpp_add<0x121, 0xf>(v);  // row_ror:1
+        v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+        o[e] = v;
+      }
+      if ((lane & 31) == 16 + 4 * m + q) *(f32x4*)(dst + 16 * m + 4 * q) = o;
+    }
+}
+
 // acc = [act > 0] * acc (+ base), written to `dst`; act / dst address this lane's 64 features of its point.  `mask` (this lane's
 // two words of the forward pass's ReLU-mask dump, dump_vec128) replaces the 16 loads of the activations by one 8-byte load: the
 // chain needs the SIGN of an activation only, and reading the fp32 values back was 1.05 of the kernel's 2.81 ms on the C4 shard
@@ -2508,6 +2529,7 @@ struct TransformerBwdArgs {
   float* wg_x;           // [12, P, 64]  X of (Mqk, Nov, W1', W2) of layer l at 4l + (0, 1, 2, 3)
   float* wg_dy;          // [12, P, 64]  dY, same order
   float* dx0;            // [P, 64] gradient w.r.t. the head's input (query MLP output)
+  float* colsum;         // [tiles, 12, 64] per-tile column sums of the dY (the bias gradients), or nullptr
 };
 
 __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(TransformerBwdArgs a) {
@@ -2527,6 +2549,8 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
   float* const wx = ok ? a.wg_x + row : nullptr;
   float* const wy = ok ? a.wg_dy + row : nullptr;
   auto slot = [&](float* base, int k) -> float* { return base ? base + (size_t)k * slice : nullptr; };
+  // (rows of padding lanes contribute nothing: their d_out is zero and the chain is linear in it)
+  float* const sums = (a.colsum && tile * 32 < a.points) ? a.colsum + (size_t)tile * (12 * 64) + 32 * hh : nullptr;
 
   f32x16 din[1];
 #pragma unroll
@@ -2590,6 +2614,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
     }
     // ---- and backwards ---------------------------------------------------------------------------------------------
     store_vec64(slot(wy, 4 * l + 3), dx);                                    // W2:  dY = dx
+    if (sums) tile_colsum64(dx, sums + (4 * l + 3) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // W2^T dx
@@ -2598,12 +2623,14 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[m][r] *= xin[m][r];                     // du
     store_vec64(slot(wy, 4 * l + 2), u);                                     // W1': dY = du
+    if (sums) tile_colsum64(u, sums + (4 * l + 2) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     wl = stream_step(st, wave, lane);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, u, xin);           // W1'^T du = dn2
     norm64_backward(xin, n2, rstd2, dx);                                     // dxm = dx + norm'(dn2)
     store_vec64(slot(wy, 4 * l + 1), dx);                                    // Nov: dY = dxm
+    if (sums) tile_colsum64(dx, sums + (4 * l + 1) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // Nov^T dxm = da
@@ -2618,6 +2645,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
         for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] *= xin[m][8 * h8 + k] - dot;   // ds = a (da - <a, da>)
       }
     store_vec64(slot(wy, 4 * l + 0), t);                                     // Mqk: dY = ds
+    if (sums) tile_colsum64(t, sums + (4 * l + 0) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     wl = stream_step(st, wave, lane);
@@ -3153,12 +3181,12 @@ extern "C" int njf_pack_transformer_backward(const float* mats, const float* bia
 
 extern "C" int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points,
                                         const float* w_backward, const float* b_backward, float* wg_x, float* wg_dy,
-                                        float* dx0, void* stream) {
+                                        float* dx0, float* colsum_partial, void* stream) {
   if (!x || !d_out || !w_backward || !b_backward || !wg_x || !wg_dy || !dx0) return NJF_E_NULL;
   if (points < 1 || (long long)points * 12 * 64 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
   if (keys < 1 || keys > 8) return NJF_E_ACTION_DIM;
-  TransformerBwdArgs a{x, d_out, d_out_dim, keys, points, w_backward, b_backward, wg_x, wg_dy, dx0};
+  TransformerBwdArgs a{x, d_out, d_out_dim, keys, points, w_backward, b_backward, wg_x, wg_dy, dx0, colsum_partial};
   return launch_fused(transformer_backward_kernel, a, (points + 31) / 32, (hipStream_t)stream);
 }
 

@@ -368,9 +368,9 @@ def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tenso
     b_t = torch.empty(hip.TRANSFORMER_BACKWARD_B_FLOATS, dtype=torch.float32, device=dev)
     hip.pack_transformer_backward(mats32, biases32[:, :3].contiguous(), head_w, w_t, b_t)
     keys = p64["jacobian_index_embedding"].shape[1]
-    wg_x, wg_dy, dx0 = hip.transformer_backward(x, d_j, keys, w_t, b_t)
+    wg_x, wg_dy, dx0, dy_sums = hip.transformer_backward(x, d_j, keys, w_t, b_t)
     g_mats = _tn_batched(wg_dy, wg_x).reshape(3, 4, 64, 64)                 # dY^T X per folded matrix: [out, in]
-    g_biases = wg_dy.sum(1).reshape(3, 4, 64)                               # (bqk, bo, b1', b2): column sums of the dY
+    g_biases = dy_sums.reshape(3, 4, 64)                                    # (bqk, bo, b1', b2): column sums of the dY (per-tile partials)
     grads: Dict[str, torch.Tensor] = {}
     with torch.enable_grad():
         through_fold = torch.autograd.grad([folded["mats"], folded["biases"]], leaves, [g_mats.double(), g_biases.double()],
