@@ -406,7 +406,8 @@ int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activa
  * Outputs: wg_x, wg_dy [12,P,64] -- per layer l the pairs the weight gradients contract over the points, at 4l + (0, 1, 2, 3) for
  * (Mqk, Nov, W1', W2): X = (n, a, n2, h), dY = (d dots, d xm, d u, d x_next); dW = dY^T X (K = points: library GEMM on the host),
  * bias gradients = column sums of dY (colsum_partial, may be NULL: [ceil(P / 32), 12, 64] per-tile sums, to be added over the
- * tiles).  dx0 [P,64]: gradient w.r.t. the head's input (the query MLP's output): its weight gradient
+ * tiles).  half_storage != 0 (16-bit training storage, as `deltas16` of njf_resnetfc_backward): wg_x / wg_dy address [12,P,64]
+ * HALVES, the dY stored x 2^k with k = 6 - exponent(*d_out_absmax) (device scalar max|d_out|, required then).  dx0 [P,64]: gradient w.r.t. the head's input (the query MLP's output): its weight gradient
  * contracts with the positional encoding, its hoisted feature part goes through njf_scatter_footprint.
  * njf_pack_transformer_backward: mats [3,4,64,64] = (Mqk, Nov, W1', W2) per layer, row-major [out][in]; biases [3,3,64] = (bqk, bo,
  * b1'); head_w [d_out,64]; -> w_out (NJF_TRANSFORMER_BACKWARD_CHUNKS chunks), b_out [3,192]. */
@@ -414,7 +415,8 @@ int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activa
 int njf_pack_transformer_backward(const float* mats, const float* biases, const float* head_w, int d_out, float* w_out,
                                   float* b_out, void* stream);
 int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points, const float* w_backward,
-                             const float* b_backward, float* wg_x, float* wg_dy, float* dx0, float* colsum_partial, void* stream);
+                             const float* b_backward, float* wg_x, float* wg_dy, float* dx0, float* colsum_partial,
+                             int half_storage, const float* d_out_absmax, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

@@ -2530,7 +2530,25 @@ struct TransformerBwdArgs {
   float* wg_dy;          // [12, P, 64]  dY, same order
   float* dx0;            // [P, 64] gradient w.r.t. the head's input (query MLP output)
   float* colsum;         // [tiles, 12, 64] per-tile column sums of the dY (the bias gradients), or nullptr
+  // 16-bit training storage (training.py: what the weight-gradient GEMMs read): wg_x / wg_dy address HALVES, the dY are stored
+  // x 2^k with k = 6 - exponent(max|d_out|) as in njf_resnetfc_backward (the caller divides the GEMM's result by 2^k)
+  int half;
+  const float* absmax;   // device scalar max|d_out| (half storage only)
 };
+
+// this lane's 32 values as halves (x scale): 4 stores of 16 bytes at row + 32 * hh (in halves)
+__device__ __forceinline__ void store_vec64_f16(_Float16* __restrict__ dst, const f32x16 (&v)[2], float scale) {
+  if (dst == nullptr) return;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_pair_f16<false>(v[m][8 * q + 2 * e] * scale, v[m][8 * q + 2 * e + 1] * scale);
+      *(u32x4*)(dst + 16 * m + 8 * q) = o;
+    }
+}
 
 __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(TransformerBwdArgs a) {
   const int tid = threadIdx.x;
@@ -2546,9 +2564,24 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
   WeightStream st;
   stream_begin(st, a.w_pack, NJF_TRANSFORMER_BACKWARD_CHUNKS, 1, wave, lane);
   const float* bias = njf_lds + LDS_BIAS;
-  float* const wx = ok ? a.wg_x + row : nullptr;
-  float* const wy = ok ? a.wg_dy + row : nullptr;
-  auto slot = [&](float* base, int k) -> float* { return base ? base + (size_t)k * slice : nullptr; };
+  float* const wx = !ok ? nullptr : (a.half ? (float*)((_Float16*)a.wg_x + row) : a.wg_x + row);
+  float* const wy = !ok ? nullptr : (a.half ? (float*)((_Float16*)a.wg_dy + row) : a.wg_dy + row);
+  float pow2 = 1.0f;   // 2^k of the fp16 dY (wave-uniform)
+  if (a.half) {
+    const float mx = a.absmax ? *a.absmax : 0.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+      int e;
+      frexpf(mx, &e);
+      pow2 = ldexpf(1.0f, max(min(6 - e, 120), -120));
+    }
+  }
+  const bool half = a.half != 0;
+  // the (X, dY) pair slots: fp32, or halves under the 16-bit training storage (X as it is, dY x 2^k)
+  auto put = [&](float* base, int k, const f32x16 (&v)[2], float scale) {
+    if (base == nullptr) return;
+    if (half) store_vec64_f16((_Float16*)base + (size_t)k * slice, v, scale);
+    else store_vec64(base + (size_t)k * slice, v);
+  };
   // (rows of padding lanes contribute nothing: their d_out is zero and the chain is linear in it)
   float* const sums = (a.colsum && tile * 32 < a.points) ? a.colsum + (size_t)tile * (12 * 64) + 32 * hh : nullptr;
 
@@ -2568,7 +2601,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
     load_vec64(a.x + (size_t)l * slice + row, true, xin);
     // ---- the layer again -----------------------------------------------------------------------------------------
     const float rstd1 = norm64_rstd(xin, n);
-    store_vec64(slot(wx, 4 * l + 0), n);
+    put(wx, 4 * l + 0, n, 1.0f);
     bias_init<2, true, PREC_F32>(bl, hh, t);
     wl = stream_step(st, wave, lane);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, n, t);            // dots[head * 8 + key]
@@ -2590,11 +2623,11 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] = e[k] * inv;       // a
       }
-    store_vec64(slot(wx, 4 * l + 1), t);
+    put(wx, 4 * l + 1, t, 1.0f);
     bias_init<2, false, PREC_F32>(bl + 64, hh, xin);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, t, xin);    // xm = x + Nov a + bo
     const float rstd2 = norm64_rstd(xin, n2);
-    store_vec64(slot(wx, 4 * l + 2), n2);
+    put(wx, 4 * l + 2, n2, 1.0f);
     bias_init<2, true, PREC_F32>(bl + 128, hh, u);
     wl = stream_step(st, wave, lane);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, n2, u);           // u = W1' n2 + b1'
@@ -2610,10 +2643,10 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
           // gelu'(u) = Phi(u) + u phi(u),  phi(u) = exp(-u^2 / 2) / sqrt(2 pi)
           u[m][r] = fmaf(v * 0.3989422804014327f, __builtin_amdgcn_exp2f(v * v * -0.7213475204444817f), cdf);
         }
-      store_vec64(slot(wx, 4 * l + 3), hval);
+      put(wx, 4 * l + 3, hval, 1.0f);
     }
     // ---- and backwards ---------------------------------------------------------------------------------------------
-    store_vec64(slot(wy, 4 * l + 3), dx);                                    // W2:  dY = dx
+    put(wy, 4 * l + 3, dx, pow2);                                    // W2:  dY = dx
     if (sums) tile_colsum64(dx, sums + (4 * l + 3) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
@@ -2622,14 +2655,14 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[m][r] *= xin[m][r];                     // du
-    store_vec64(slot(wy, 4 * l + 2), u);                                     // W1': dY = du
+    put(wy, 4 * l + 2, u, pow2);                                     // W1': dY = du
     if (sums) tile_colsum64(u, sums + (4 * l + 2) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     wl = stream_step(st, wave, lane);
     mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, u, xin);           // W1'^T du = dn2
     norm64_backward(xin, n2, rstd2, dx);                                     // dxm = dx + norm'(dn2)
-    store_vec64(slot(wy, 4 * l + 1), dx);                                    // Nov: dY = dxm
+    put(wy, 4 * l + 1, dx, pow2);                                    // Nov: dY = dxm
     if (sums) tile_colsum64(dx, sums + (4 * l + 1) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
@@ -2644,7 +2677,7 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] *= xin[m][8 * h8 + k] - dot;   // ds = a (da - <a, da>)
       }
-    store_vec64(slot(wy, 4 * l + 0), t);                                     // Mqk: dY = ds
+    put(wy, 4 * l + 0, t, pow2);                                     // Mqk: dY = ds
     if (sums) tile_colsum64(t, sums + (4 * l + 0) * 64, lane);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
@@ -3181,12 +3214,15 @@ extern "C" int njf_pack_transformer_backward(const float* mats, const float* bia
 
 extern "C" int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points,
                                         const float* w_backward, const float* b_backward, float* wg_x, float* wg_dy,
-                                        float* dx0, float* colsum_partial, void* stream) {
+                                        float* dx0, float* colsum_partial, int half_storage, const float* d_out_absmax,
+                                        void* stream) {
   if (!x || !d_out || !w_backward || !b_backward || !wg_x || !wg_dy || !dx0) return NJF_E_NULL;
   if (points < 1 || (long long)points * 12 * 64 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
   if (keys < 1 || keys > 8) return NJF_E_ACTION_DIM;
-  TransformerBwdArgs a{x, d_out, d_out_dim, keys, points, w_backward, b_backward, wg_x, wg_dy, dx0, colsum_partial};
+  if (half_storage && !d_out_absmax) return NJF_E_NULL;
+  TransformerBwdArgs a{x, d_out, d_out_dim, keys, points, w_backward, b_backward, wg_x, wg_dy, dx0, colsum_partial,
+                       half_storage != 0, d_out_absmax};
   return launch_fused(transformer_backward_kernel, a, (points + 31) / 32, (hipStream_t)stream);
 }
 

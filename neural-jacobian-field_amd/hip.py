@@ -139,7 +139,7 @@ _SIGNATURES = {
     "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, C.c_int, _vp], C.c_int),
     "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_pack_transformer_backward": ([_vp, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
-    "njf_transformer_backward": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "njf_transformer_backward": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
@@ -625,23 +625,29 @@ def pack_transformer_backward(mats: torch.Tensor, biases: torch.Tensor, head_w: 
             _ptr(b_out, "b_out"))
 
 
-def transformer_backward(x: torch.Tensor, d_out: torch.Tensor, keys: int, w_backward: torch.Tensor, b_backward: torch.Tensor):
+def transformer_backward(x: torch.Tensor, d_out: torch.Tensor, keys: int, w_backward: torch.Tensor, b_backward: torch.Tensor,
+                         half_storage: bool = False):
     """The folded transformer head's data-gradient chain (include/njf_hip.h: njf_transformer_backward): x [4,P,64] (the residual
-    stream the training forward dumped), d_out [P,3A] -> (wg_x [12,P,64], wg_dy [12,P,64], dx0 [P,64], column sums of wg_dy [12,64])."""
+    stream the training forward dumped), d_out [P,3A] -> (wg_x [12,P,64], wg_dy [12,P,64], dx0 [P,64], column sums of the dY
+    [12,64], unscale).  ``half_storage``: the pairs are fp16, the dY scaled by 2^k; ``unscale`` = 2^-k as a device scalar (else 1)."""
     points = d_out.shape[0]
     if tuple(x.shape) != (4, points, 64) or w_backward.numel() != TRANSFORMER_BACKWARD_W_FLOATS \
             or b_backward.numel() != TRANSFORMER_BACKWARD_B_FLOATS:
         raise ValueError("njf_hip: transformer_backward shape mismatch")
     dev = d_out.device
-    wg_x = torch.empty(12, points, 64, dtype=torch.float32, device=dev)
-    wg_dy = torch.empty(12, points, 64, dtype=torch.float32, device=dev)
+    pair_dtype = torch.float16 if half_storage else torch.float32
+    wg_x = torch.empty(12, points, 64, dtype=pair_dtype, device=dev)
+    wg_dy = torch.empty(12, points, 64, dtype=pair_dtype, device=dev)
     dx0 = torch.empty(points, 64, dtype=torch.float32, device=dev)
     partial = torch.empty((points + 31) // 32, 12, 64, dtype=torch.float32, device=dev)
     d_out = d_out.contiguous()
+    absmax = d_out.abs().amax().reshape(1) if half_storage else None
     _launch("njf_transformer_backward", load_library().njf_transformer_backward, _ptr(x, "x"), _ptr(d_out, "d_out"), d_out.shape[1],
-            int(keys), points, _ptr(w_backward, "w_backward"), _ptr(b_backward, "b_backward"), _ptr(wg_x, "wg_x"),
-            _ptr(wg_dy, "wg_dy"), _ptr(dx0, "dx0"), _ptr(partial, "colsum_partial"))
-    return wg_x, wg_dy, dx0, partial.sum(0)
+            int(keys), points, _ptr(w_backward, "w_backward"), _ptr(b_backward, "b_backward"), _ptr(wg_x, "wg_x", pair_dtype),
+            _ptr(wg_dy, "wg_dy", pair_dtype), _ptr(dx0, "dx0"), _ptr(partial, "colsum_partial"), int(half_storage),
+            _ptr(absmax, "d_out_absmax"))
+    unscale = power_of_two_unscale(absmax) if half_storage else None
+    return wg_x, wg_dy, dx0, partial.sum(0), unscale
 
 
 BACKWARD_PRECISIONS = ("f32", "f16x2")

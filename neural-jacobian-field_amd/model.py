@@ -520,9 +520,9 @@ class Model(nn.Module):
             pts = b * r * s
             outs["weights"] = outs.get("weights", torch.empty(b, r, s, **f32))
             outs["pos_warped"] = outs.get("pos_warped", torch.empty(b, r, 3, **f32))
+            outs["jac_forward_precision"] = self.decoder.j_precision    # (what training.py's "auto" settings follow)
             if self.decoder.JACOBIAN_KIND == hip.JACOBIAN_MLP:
                 from . import training as _tr   # (fp16 under the opt-in 16-bit training storage, training.set_storage_precision)
-                outs["jac_forward_precision"] = self.decoder.j_precision    # (what training.py's "auto" settings follow)
                 outs["jac_act"] = torch.empty(11, pts, 128, dtype=_tr.activation_dump_dtype(self.decoder.j_precision), device=dev)
                 outs["jac_mask"] = torch.empty(11, pts, 4, dtype=torch.int32, device=dev)   # ReLU masks: what the backward chain reads
             elif self.decoder.JACOBIAN_KIND == hip.JACOBIAN_TRANSFORMER:

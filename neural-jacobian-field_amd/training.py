@@ -351,12 +351,14 @@ def folded_transformer(p: Dict[str, torch.Tensor], heads: int = 8) -> Dict[str, 
 
 def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tensor], d_j: torch.Tensor, x: torch.Tensor,
                               pe: torch.Tensor, foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
-                              samples_per_ray: int = 1):
+                              samples_per_ray: int = 1, forward_precision=None):
     """Gradients of the transformer Jacobian head's parameters (names relative to the decoder, any order) from d_j [P,3A], the
     residual stream x [4,P,64] the training forward dumped, the dumped encoding pe [P,64] (slot order) and footprint.
     ONE fused launch for the data-gradient chain (njf_transformer_backward, exact fp32 MFMA on the folded head), one batched
     library GEMM for the K = points weight gradients of the twelve folded matrices, the footprint scatter for the hoisted query
-    features, and the fold's autograd graph (64 x 64 matrices) back to the reference's parameterisation."""
+    features, and the fold's autograd graph (64 x 64 matrices) back to the reference's parameterisation.  The chain itself is
+    always exact fp32; under the 16-bit training storage (``storage_precision``: "f16", or "auto" with the reference's matmul
+    precision "high") the (X, dY) pairs are written as halves and contracted with fp32 accumulation."""
     leaves = [t.detach().double().requires_grad_(True) for t in params]
     p64 = dict(zip(names, leaves))
     with torch.enable_grad():
@@ -368,8 +370,13 @@ def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tenso
     b_t = torch.empty(hip.TRANSFORMER_BACKWARD_B_FLOATS, dtype=torch.float32, device=dev)
     hip.pack_transformer_backward(mats32, biases32[:, :3].contiguous(), head_w, w_t, b_t)
     keys = p64["jacobian_index_embedding"].shape[1]
-    wg_x, wg_dy, dx0, dy_sums = hip.transformer_backward(x, d_j, keys, w_t, b_t)
-    g_mats = _tn_batched(wg_dy, wg_x).reshape(3, 4, 64, 64)                 # dY^T X per folded matrix: [out, in]
+    half = storage_precision(forward_precision) == "f16"     # 16-bit training storage of what the weight-gradient GEMM reads
+    wg_x, wg_dy, dx0, dy_sums, unscale = hip.transformer_backward(x, d_j, keys, w_t, b_t, half_storage=half)
+    if half:
+        g_mats = (_tn_batched_f16(wg_dy, wg_x) * unscale).reshape(3, 4, 64, 64)
+        _note_reduced_results(g_mats)
+    else:
+        g_mats = _tn_batched(wg_dy, wg_x).reshape(3, 4, 64, 64)             # dY^T X per folded matrix: [out, in]
     g_biases = dy_sums.reshape(3, 4, 64)                                    # (bqk, bo, b1', b2): column sums of the dY (per-tile partials)
     grads: Dict[str, torch.Tensor] = {}
     with torch.enable_grad():
@@ -442,7 +449,8 @@ class ActionFlowFunction(torch.autograd.Function):
             # jacobian_transformer: the fused chain on the residual stream the forward dumped (round 6; the recomputation in
             # library ops below was 54 ms of a 62 ms action step on SURVEY's C4 shard and stays as the comparator of the tests)
             result = transformer_head_backward(ctx.names, ctx.saved_tensors, d_j, outs["jac_act"], outs["jac_pe"],
-                                               outs["foot_idx"], outs["foot_w"], feats_flat, samples_per_ray=s)
+                                               outs["foot_idx"], outs["foot_w"], feats_flat, samples_per_ray=s,
+                                               forward_precision=outs.get("jac_forward_precision"))
         else:  # jacobian_transformer: recompute the head on the dumped inputs, autograd to the original parameters
             pe = outs["jac_pe"]
             xyz_features = pe.new_empty(pe.shape[0], 63)

@@ -932,3 +932,17 @@ def test_transformer_backward_chain_equals_the_library_recomputation(setup):
         bad = {n: v for n, v in worst.items() if not v <= 2e-4}
         assert not bad, (A, bad)
         print(f"[transformer backward, A = {A}] worst rel vs the library recomputation: {max(worst.values()):.2e} over {len(worst)} tensors")
+        # the 16-bit training storage of the (X, dY) pairs (fp16 operands, fp32 accumulation: the 11 bits per operand TF32 keeps)
+        from neural_jacobian_field_amd import training
+        try:
+            training.set_storage_precision("f16")
+            model.zero_grad(set_to_none=True)
+            out = model.forward(s["cam"], s["rin"], RobotInput(action.to(dev)))
+            (0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))).backward()
+        finally:
+            training.set_storage_precision("auto")
+        half = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        worst16 = {n: rel(half[n], g) for n, g in grads["hip"].items()}
+        assert max(worst16.values()) <= 2e-3 and all(torch.isfinite(v).all() for v in half.values()), worst16
+        assert not training.reduced_backward_overflowed(dev)
+        print(f"[transformer backward, A = {A}] 16-bit storage vs fp32 storage: {max(worst16.values()):.2e}")
