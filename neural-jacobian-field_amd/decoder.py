@@ -692,7 +692,7 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
     @torch.no_grad()
     def _pack_regular_jacobian(self, params, w_j, b_j, wz, bz):
         t = self.cfg.transformer
-        heads, dh, a = t.num_attn_heads, t.attn_head_dim, self.action_dim
+        heads = t.num_attn_heads
         f32 = lambda x: x.to(torch.float32).contiguous()
         half = lambda i: w_j[4096 * i: 4096 * (i + 1)]
         qw = self.jacobian_query_mlp.weight  # [64, 63 + 512], input = cat[xyz_features, pixel_aligned_features] (:421-427)
@@ -701,27 +701,18 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
         pos = hip.hoisted_channel_order(64, qw.device, self.j_precision)
         wz[:, hip.ZDIM + pos] = qw[:, 63:].t()
         bz[hip.ZDIM:] = 0.0
-        z = self.jacobian_index_embedding[0].double()  # [A, 64]
-        for l, (attn, ff) in enumerate(self.jacobian_attn_decoder.layers):
-            g1, be1 = attn.norm.weight.double(), attn.norm.bias.double()
-            kv = z @ attn.fn.to_kv.weight.double().t()  # [A, 2*H*dh]
-            k = kv[:, : heads * dh].reshape(a, heads, dh).permute(1, 0, 2)  # [H, A, dh]
-            v = kv[:, heads * dh:].reshape(a, heads, dh).permute(1, 0, 2)
-            wq = attn.fn.to_q.weight.double().reshape(heads, dh, -1)  # [H, dh, 64]
-            mqk = torch.zeros(heads, 8, wq.shape[-1], dtype=torch.float64, device=z.device)
-            mqk[:, :a] = (dh ** -0.5) * torch.einsum("had,hdc->hac", k, wq)
-            mqk = mqk.reshape(heads * 8, -1)
-            wo = attn.fn.to_out[0].weight.double().reshape(-1, heads, dh)  # [64, H, dh]
-            nov = torch.zeros(wo.shape[0], heads, 8, dtype=torch.float64, device=z.device)
-            nov[:, :, :a] = torch.einsum("chd,had->cha", wo, v)
-            nov = nov.reshape(wo.shape[0], heads * 8)
-            g2, be2 = ff.norm.weight.double(), ff.norm.bias.double()
-            w1, b1 = ff.fn.net[0].weight.double(), ff.fn.net[0].bias.double()
+        # the fold itself (keys / values / LayerNorm affines -> two 64 x 64 matrices per attention layer, the affine of the second
+        # LayerNorm into W1): training.folded_transformer -- ONE set of batched float64 ops for the three layers, the same graph the
+        # head's backward pass differentiates (an action-mode run re-packs after every optimiser step; fp32 results bit-identical
+        # to a loop over the layers)
+        from . import training
+        folded = training.folded_transformer({n: v.detach().double() for n, v in params.items()
+                                              if n.startswith("jacobian") and not n.startswith("jacobian_head_arm.")}, heads)
+        mats, biases = f32(folded["mats"]), f32(folded["biases"])     # [3,4,64,64] = (Mqk', Nov, W1', W2), [3,4,64] = (bqk', bo, b1', b2)
+        for l in range(mats.shape[0]):
             bl = b_j[256 * l: 256 * (l + 1)]
-            hip.pack_linear(f32(mqk * g1[None, :]), f32(mqk @ be1), 0, half(1 + 4 * l), bl[0:64], precision=self.j_precision)
-            hip.pack_linear(f32(nov), attn.fn.to_out[0].bias, 0, half(2 + 4 * l), bl[64:128], precision=self.j_precision)
-            hip.pack_linear(f32(w1 * g2[None, :]), f32(w1 @ be2 + b1), 0, half(3 + 4 * l), bl[128:192], precision=self.j_precision)
-            hip.pack_linear(ff.fn.net[3].weight, ff.fn.net[3].bias, 0, half(4 + 4 * l), bl[192:256], precision=self.j_precision)
+            for i in range(4):
+                hip.pack_linear(mats[l, i], biases[l, i], 0, half(1 + 4 * l + i), bl[64 * i:64 * (i + 1)], precision=self.j_precision)
         hip.pack_linear(self.jacobian_head.weight, self.jacobian_head.bias, 0, half(13)[:2048], b_j[768:800], precision=self.j_precision)
 
 
