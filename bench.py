@@ -491,12 +491,12 @@ def main():
                 "kernel_ms": kernel_ms(launches, steps), "launches_per_step": len(launches) / max(steps, 1), "graphed": graphed,
                 "timing_note": timing_note, "digest": digest_hex}
 
-    # headline first; the package's default precision with the SAME steps / warm-up / barriers; any remaining mode briefly
+    # headline first; the package's default precision with the SAME steps / warm-up / barriers; every other mode likewise
     runs = {precision: measure(precision, args.steps, args.warmup)}
     for prec in models:
         if prec not in runs:
-            full = prec == default_precision
-            runs[prec] = measure(prec, args.steps if full else max(2, args.steps // 4), args.warmup if full else 1)
+            # every mode with the SAME --steps / --warmup as the headline (a 60-step run of the slowest extra mode is 0.7 s)
+            runs[prec] = measure(prec, args.steps, args.warmup)
     head = runs[precision]
     evidence = launch.rank_evidence(dist, device, head["local_ms"], graph=head["graphed"], kernel_ms=head["kernel_ms"])
     # One more UNTIMED step of the headline mode on every rank: the digest of what it produced (assembled frame + the six clip /
