@@ -946,3 +946,53 @@ def test_transformer_backward_chain_equals_the_library_recomputation(setup):
         assert max(worst16.values()) <= 2e-3 and all(torch.isfinite(v).all() for v in half.values()), worst16
         assert not training.reduced_backward_overflowed(dev)
         print(f"[transformer backward, A = {A}] 16-bit storage vs fp32 storage: {max(worst16.values()):.2e}")
+
+
+def test_wrapper_action_steps_with_the_shipped_allegro_head(setup):
+    """ModelWrapper("action").training_step with the decoder the reference ships for Allegro (jacobian_transformer, model_allegro.yaml:26)
+    in TRAINING mode (jittered samplers, annealed proposal weights): every "jacobian*" parameter and nothing else receives a finite
+    gradient through the fused chain (njf_transformer_backward), and a few Adam steps on one batch lower the flow loss -- the head is
+    re-folded and re-packed after every optimiser step."""
+    from neural_jacobian_field_amd import synthetic
+    from neural_jacobian_field_amd.config import model_cfg_from_dict
+    from neural_jacobian_field_amd.geometry import get_pixel_coordinates
+    from neural_jacobian_field_amd.model import Model
+    from neural_jacobian_field_amd.model_wrapper import ModelWrapper
+    s = setup
+    dev, case, A = s["dev"], s["case"], 8
+    model = Model(model_cfg_from_dict({"action_dim": A, "rendering": {"num_proposal_samples": [s["S"]], "num_nerf_samples": s["S"]},
+                                       "action_decoder": {"name": "jacobian_transformer"}}))
+    model.load_state_dict(synthetic.seeded_state_dict(synthetic.model_shapes("jacobian_transformer", A), seed=6), strict=True)
+    model.to(dev)
+    B, H, W = 2, 16, 16
+    c = case["cams"]
+    g2 = torch.Generator().manual_seed(33)
+    coords, _ = get_pixel_coordinates(H, W, dev)
+    action = (torch.randn(B, A, generator=g2) * 0.3).to(dev)
+    t_rgb, t_depth = torch.rand(B, 3, H, W, generator=g2).to(dev), (torch.rand(B, 1, H, W, generator=g2) + 0.5).to(dev)
+    t_flow = torch.randn(B, 2, H, W, generator=g2).to(dev)
+
+    def batch():   # (a fresh dict per step, as a data loader hands it over: the wrapper reshapes target entries)
+        return {"context": {"rgb": s["image"].to(dev), "extrinsics": c["ctxt_c2w"].to(dev), "intrinsics": c["ctxt_k_norm"].to(dev),
+                            "robot_action": action},
+                "target": {"rgb": t_rgb.clone(), "depth": t_depth.clone(), "flow": t_flow.clone(), "extrinsics": c["trgt_c2w"].to(dev),
+                           "intrinsics": c["ctxt_k_norm"].to(dev)},
+                "scene": {"near": c["z_near"].to(dev), "far": c["z_far"].to(dev), "coordinates": coords[None].expand(B, -1, -1, -1)}}
+
+    wrapper = ModelWrapper("action", 64, model).train()
+    trainable = [p for p in wrapper.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(trainable, lr=1e-3)
+    losses = []
+    for it in range(6):
+        torch.manual_seed(100)                       # the same ray subset and jitter every step: the loss is comparable across steps
+        opt.zero_grad(set_to_none=True)
+        loss = wrapper.training_step(batch())
+        loss.backward()
+        if it == 0:
+            for n, p in wrapper.named_parameters():
+                has = p.grad is not None
+                assert has == (".jacobian" in n), n
+                assert not has or torch.isfinite(p.grad).all(), n
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
