@@ -706,9 +706,9 @@ class ActionDecoderJacobianTransformer(ActionDecoderJacobian):
         # head's backward pass differentiates (an action-mode run re-packs after every optimiser step; fp32 results bit-identical
         # to a loop over the layers)
         from . import training
-        folded = training.folded_transformer({n: v.detach().double() for n, v in params.items()
-                                              if n.startswith("jacobian") and not n.startswith("jacobian_head_arm.")}, heads)
-        mats, biases = f32(folded["mats"]), f32(folded["biases"])     # [3,4,64,64] = (Mqk', Nov, W1', W2), [3,4,64] = (bqk', bo, b1', b2)
+        names = [n for n in params if n.startswith("jacobian") and not n.startswith("jacobian_head_arm.")]
+        _, folded = training.transformer_fold(names, [params[n] for n in names], heads=heads)   # (kept for this step's backward pass)
+        mats, biases = f32(folded["mats"].detach()), f32(folded["biases"].detach())     # [3,4,64,64] = (Mqk', Nov, W1', W2), [3,4,64] = (bqk', bo, b1', b2)
         for l in range(mats.shape[0]):
             bl = b_j[256 * l: 256 * (l + 1)]
             for i in range(4):

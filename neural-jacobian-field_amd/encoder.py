@@ -10,6 +10,8 @@ reference checkpoints load with ``strict=True`` even though the forward never us
 
 from __future__ import annotations
 
+import os
+import weakref
 from abc import ABC, abstractmethod
 from typing import Callable, Optional
 
@@ -131,11 +133,67 @@ class EncoderResnet(Encoder):
                 pyramid.append(x)
         return pyramid
 
+    # ---- the frozen trunk as ONE HIP graph ------------------------------------------------------------------------------
+    # A frozen encoder in eval mode (inference; the reference's action mode, model_wrapper.py:75-85) is a fixed sequence of ~120
+    # library launches (29 convolutions, their batch norms, ReLUs and residual adds) on an input of fixed shape: ~1 ms of device
+    # time behind ~1.5 ms of host launches -- a step of action-mode training with the shipped head is bound by exactly those
+    # (profiles/r06_training_allegro_head.json).  The second call with the same input shape and the same parameter versions
+    # captures the trunk on a side stream (after two warm-up runs: MIOpen's solver search must not happen inside a capture) and
+    # every later call is: copy the image into the graph's input, replay, clone the four latents out of the graph's pool (the
+    # caller owns what it gets; a later call must not change it).  Same kernels, same order: the latents are what the eager trunk
+    # gives.  NJF_ENCODER_GRAPH=0 switches it off; a capture that fails switches it off for the process with a warning.
+    # (per instance, kept outside the module so that deepcopy / pickling of a model never meets a graph object):
+    # (graph, static input, static outputs, key) | ("seen", key)
+    _graph_states = weakref.WeakKeyDictionary()
+    _graph_disabled = os.environ.get("NJF_ENCODER_GRAPH", "1") == "0"
+
+    def _graph_key(self, rgb: torch.Tensor):
+        return ((tuple(rgb.shape), rgb.dtype, rgb.device, rgb.stride(), self.num_layers, self.use_first_pool)
+                + tuple((t.data_ptr(), t._version) for t in self.model.parameters())
+                + tuple((t.data_ptr(), t._version) for t in self.model.buffers()))
+
+    def _graphed_latents(self, rgb: torch.Tensor):
+        """The latents through the captured trunk, or None when this call has to run eagerly."""
+        if (EncoderResnet._graph_disabled or self.training or torch.is_grad_enabled() or not rgb.is_cuda
+                or torch.cuda.is_current_stream_capturing()):
+            return None
+        key = self._graph_key(rgb)
+        states = EncoderResnet._graph_states
+        st = states.get(self)
+        if st is None or st[-1] != key:           # first call with this shape / these weights: eager, remember it
+            states[self] = ("seen", key)
+            return None
+        if st[0] == "seen":
+            try:
+                static_in = rgb.clone()
+                side = torch.cuda.Stream(device=rgb.device)
+                side.wait_stream(torch.cuda.current_stream(rgb.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._latents(static_in)
+                torch.cuda.current_stream(rgb.device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._latents(static_in)
+            except Exception as exc:   # noqa: BLE001 -- whatever the libraries refuse inside a capture: fall back for good
+                import warnings
+                warnings.warn(f"EncoderResnet: HIP-graph capture of the frozen trunk failed ({exc!r}); running it eagerly")
+                EncoderResnet._graph_disabled = True
+                states.pop(self, None)
+                return None
+            st = states[self] = (graph, static_in, static_out, key)
+        graph, static_in, static_out, _ = st
+        static_in.copy_(rgb)
+        graph.replay()
+        return [t.clone() for t in static_out]
+
     def forward_pyramid(self, rgb: torch.Tensor):
         """Inference path of the fused renderer: the latents without the up-sampling + concatenation of
         encoder_resnet.py:78-86 (a FeaturePyramid), or the plain feature tensor when the configuration is not the
         bilinear 512-channel one the pyramid producer implements."""
-        pyramid = self._latents(rgb)
+        pyramid = self._graphed_latents(rgb)
+        if pyramid is None:
+            pyramid = self._latents(rgb)
         if self.upsample_interp != "bilinear" or sum(p.shape[1] for p in pyramid) != 512:
             return self.forward(rgb)
         return FeaturePyramid(pyramid)

@@ -346,6 +346,48 @@ def folded_transformer(p: Dict[str, torch.Tensor], heads: int = 8) -> Dict[str, 
     return {"mats": mats, "biases": biases}
 
 
+def flat_double(tensors: Sequence[torch.Tensor], requires_grad: bool = False):
+    """(flat, views): ONE float64 copy of a list of small tensors -- a cat of the flattened tensors, one conversion, and per-tensor
+    views of the result (three launches instead of one conversion per tensor: the transformer head has 41 parameter tensors and a
+    step with it is bound by its host launches).  With ``requires_grad`` the FLAT tensor is the autograd leaf."""
+    flat = torch.cat([t.detach().reshape(-1) for t in tensors]).double()
+    if requires_grad:
+        flat.requires_grad_(True)
+    with torch.set_grad_enabled(requires_grad):     # (callers run under no_grad: the views must be recorded all the same)
+        views = [v.reshape(t.shape) for v, t in zip(flat.split([t.numel() for t in tensors]), tensors)]
+    return flat, views
+
+
+# The fold of the CURRENT parameter values with its autograd graph, built by whoever needs it first: the forward pass's pack
+# (decoder.ActionDecoderJacobianTransformer._pack_regular_jacobian, after every optimiser step) or the backward pass.  One entry,
+# keyed by the parameters' (storage, version) pairs; the backward pass consumes it (its graph is freed by the differentiation).
+_fold_cache: Dict[str, object] = {}
+
+
+def _fold_key(names: Sequence[str], params: Sequence[torch.Tensor]):
+    return tuple(names), tuple((t.data_ptr(), t._version) for t in params)
+
+
+def transformer_fold(names: Sequence[str], params: Sequence[torch.Tensor], consume: bool = False, heads: int = 8):
+    """(flat float64 leaf, folded) for the transformer head's parameters (names relative to the decoder).  ``folded`` carries the
+    autograd graph back to ``flat`` when any parameter trains.  ``consume``: the caller differentiates the graph (it is dropped
+    from the cache); otherwise the result is kept for the backward pass of the same step."""
+    key = _fold_key(names, params)
+    hit = _fold_cache.get("entry")
+    if hit is not None and hit[0] == key:
+        if consume:
+            _fold_cache.clear()
+        return hit[1], hit[2]
+    want_graph = any(t.requires_grad for t in params)
+    flat, views = flat_double(params, requires_grad=want_graph)
+    with torch.set_grad_enabled(want_graph):
+        folded = folded_transformer(dict(zip(names, views)), heads)
+    _fold_cache.clear()
+    if want_graph and not consume:
+        _fold_cache["entry"] = (key, flat, folded)
+    return flat, folded
+
+
 def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tensor], d_j: torch.Tensor, x: torch.Tensor,
                               pe: torch.Tensor, foot_idx: torch.Tensor, foot_w: torch.Tensor, feats_flat: torch.Tensor,
                               samples_per_ray: int = 1, forward_precision=None):
@@ -356,17 +398,17 @@ def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tenso
     features, and the fold's autograd graph (64 x 64 matrices) back to the reference's parameterisation.  The chain itself is
     always exact fp32; under the 16-bit training storage (``storage_precision``: "f16", or "auto" with the reference's matmul
     precision "high") the (X, dY) pairs are written as halves and contracted with fp32 accumulation."""
-    leaves = [t.detach().double().requires_grad_(True) for t in params]
-    p64 = dict(zip(names, leaves))
-    with torch.enable_grad():
-        folded = folded_transformer(p64)
+    sizes = [t.numel() for t in params]
+    flat, folded = transformer_fold(names, params, consume=True)      # (the forward pass's pack has usually built it already)
+    if not flat.requires_grad:                                        # every parameter frozen: nothing to differentiate
+        return tuple(torch.zeros_like(t) for t in params)
     mats32, biases32 = folded["mats"].detach().float(), folded["biases"].detach().float()
-    head_w = p64["jacobian_head.weight"].detach().float()
+    head_w = params[list(names).index("jacobian_head.weight")].detach().float()
     dev = d_j.device
     w_t = torch.empty(hip.TRANSFORMER_BACKWARD_W_FLOATS, dtype=torch.float32, device=dev)
     b_t = torch.empty(hip.TRANSFORMER_BACKWARD_B_FLOATS, dtype=torch.float32, device=dev)
     hip.pack_transformer_backward(mats32, biases32[:, :3].contiguous(), head_w, w_t, b_t)
-    keys = p64["jacobian_index_embedding"].shape[1]
+    keys = params[list(names).index("jacobian_index_embedding")].shape[1]
     half = storage_precision(forward_precision) == "f16"     # 16-bit training storage of what the weight-gradient GEMM reads
     wg_x, wg_dy, dx0, dy_sums, unscale = hip.transformer_backward(x, d_j, keys, w_t, b_t, half_storage=half)
     if half:
@@ -375,24 +417,23 @@ def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tenso
     else:
         g_mats = _tn_batched(wg_dy, wg_x).reshape(3, 4, 64, 64)             # dY^T X per folded matrix: [out, in]
     g_biases = dy_sums.reshape(3, 4, 64)                                    # (bqk, bo, b1', b2): column sums of the dY (per-tile partials)
-    grads: Dict[str, torch.Tensor] = {}
     with torch.enable_grad():
-        through_fold = torch.autograd.grad([folded["mats"], folded["biases"]], leaves, [g_mats.double(), g_biases.double()],
-                                           allow_unused=True)
-    for n, g in zip(names, through_fold):
-        if g is not None:
-            grads[n] = g
+        (g_flat,) = torch.autograd.grad([folded["mats"], folded["biases"]], [flat], [g_mats.double(), g_biases.double()])
+    # one conversion for all parameters; the gradients returned are views of this buffer
+    g32 = g_flat.float()
+    out = dict(zip(names, g32.split(sizes)))
     # output Linear: J = Wj x3 + bj
-    grads["jacobian_head.weight"] = _tn(d_j, x[3]).double()
-    grads["jacobian_head.bias"] = d_j.sum(0).double()
+    out["jacobian_head.weight"].copy_(_tn(d_j, x[3]).reshape(-1))
+    torch.sum(d_j, 0, out=out["jacobian_head.bias"])
     # query MLP: x0 = Wq [pe | bilinear(features)] + bq  (action_decoder_jacobian.py:421-427)
     d_q = _tn(dx0, pe)                                                       # [64, 64 slots]; slot 63 is the bias
-    d_pe = d_q.new_zeros(64, 63).index_copy_(1, _slot_to_channel(dev), d_q[:, :63])
     d_g = torch.zeros(feats_flat.shape[0], 64, dtype=torch.float32, device=dev)
     hip.scatter_footprint(dx0, foot_idx, foot_w, d_g, run_length=samples_per_ray)
-    grads["jacobian_query_mlp.weight"] = torch.cat([d_pe, _tn(d_g, feats_flat)], dim=1).double()
-    grads["jacobian_query_mlp.bias"] = d_q[:, 63].double()
-    return tuple(grads[n].to(t.dtype).reshape(t.shape) if n in grads else torch.zeros_like(t) for n, t in zip(names, params))
+    gq = out["jacobian_query_mlp.weight"].reshape(64, -1)
+    gq[:, :63].index_copy_(1, _slot_to_channel(dev), d_q[:, :63])            # (every encoding channel has a slot)
+    gq[:, 63:] = _tn(d_g, feats_flat)
+    out["jacobian_query_mlp.bias"].copy_(d_q[:, 63])
+    return tuple(out[n].to(t.dtype).reshape(t.shape) for n, t in zip(names, params))
 
 
 class ActionFlowFunction(torch.autograd.Function):

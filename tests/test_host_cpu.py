@@ -565,6 +565,45 @@ def test_folded_transformer_head_is_exact_algebra_and_differentiable():
         assert a_dim == 8 or float(folded["mats"].detach()[:, 0].reshape(3, 8, 8, 64)[:, :, a_dim:].abs().max()) == 0.0
 
 
+def test_transformer_fold_on_one_flat_leaf_equals_the_per_tensor_fold_and_is_shared_within_a_step():
+    """training.transformer_fold: the fold on ONE flat float64 copy of the 41 parameter tensors (three launches instead of 41
+    conversions) gives the same folded matrices and -- through the flat leaf -- the same gradients as the fold on per-tensor
+    float64 leaves; the entry the forward pass's pack leaves behind is the one the backward pass of the same step consumes, and a
+    parameter update (version bump) invalidates it."""
+    from neural_jacobian_field_amd import synthetic, training
+    shapes = synthetic.decoder_shapes("jacobian_transformer", 6)
+    p = {k[len("decoder."):]: v.clone().requires_grad_(True) for k, v in synthetic.seeded_state_dict(shapes, seed=5).items()
+         if k.startswith("decoder.jacobian")}
+    names, params = list(p), list(p.values())
+    leaves = [t.detach().double().requires_grad_(True) for t in params]
+    ref = training.folded_transformer(dict(zip(names, leaves)))
+    g = torch.Generator().manual_seed(1)
+    up_m = torch.randn(ref["mats"].shape, generator=g, dtype=torch.float64)
+    up_b = torch.randn(ref["biases"].shape, generator=g, dtype=torch.float64)
+    ref_grads = torch.autograd.grad([ref["mats"], ref["biases"]], leaves, [up_m, up_b], allow_unused=True)
+    training._fold_cache.clear()
+    with torch.no_grad():                                       # the pack runs under no_grad; the graph is built all the same
+        flat, folded = training.transformer_fold(names, params)
+    assert flat.requires_grad and folded["mats"].requires_grad
+    assert torch.equal(folded["mats"].detach(), ref["mats"].detach()) and torch.equal(folded["biases"].detach(), ref["biases"].detach())
+    flat2, folded2 = training.transformer_fold(names, params, consume=True)       # the backward pass of the same step
+    assert flat2 is flat and folded2 is folded and not training._fold_cache
+    (g_flat,) = torch.autograd.grad([folded["mats"], folded["biases"]], [flat], [up_m, up_b])
+    for name, t, g_ref, g_got in zip(names, params, ref_grads, g_flat.split([t.numel() for t in params])):
+        if g_ref is None:
+            assert float(g_got.abs().max()) == 0.0, name
+        else:
+            assert torch.equal(g_got.reshape(t.shape), g_ref), name
+    with torch.no_grad():
+        training.transformer_fold(names, params)
+        params[0].add_(1.0)                                      # an optimiser step
+    flat3, _ = training.transformer_fold(names, params, consume=True)
+    assert flat3 is not flat and not training._fold_cache
+    frozen = [t.detach() for t in params]
+    flat4, folded4 = training.transformer_fold(names, frozen)
+    assert not flat4.requires_grad and not folded4["mats"].requires_grad and not training._fold_cache
+
+
 def test_resnetfc_backward_latent_constant_columns_are_exact_algebra():
     """What flow_mlp's training relies on (training.resnetfc_backward, ``latent_constants``): with z = cat[f, a] and a constant per
     batch element, d lin_z.weight[:, C:] = sum_b a[b] (x) sum_{p in b} delta[p] -- checked against autograd of the plain formula."""

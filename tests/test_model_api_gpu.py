@@ -48,6 +48,51 @@ def test_encoder_matches_reference(model_and_golden, margins):
     margins("model_mlp.encoder", "features", model.encoder(g["image"]), g["features"], g["features_f64"], tol=1e-5)  # MIOpen vs CPU
 
 
+def test_frozen_encoder_trunk_as_hip_graph_equals_the_eager_trunk(model_and_golden, margins):
+    """EncoderResnet.forward_pyramid of a frozen encoder in eval mode: the first call with a shape runs eagerly, the second captures
+    the trunk as one HIP graph, later calls replay it on a copy of the image.  The latents must be what the eager trunk gives for
+    EVERY image (same kernels in the same order: held to 1e-6, MIOpen's own run-to-run spread), the caller owns them (a later call
+    does not change an earlier result), a weight change re-captures, and grad-enabled / train-mode calls stay eager."""
+    from neural_jacobian_field_amd.encoder import EncoderResnet
+    model, g = model_and_golden
+    enc = model.encoder
+    if EncoderResnet._graph_disabled:
+        pytest.skip("NJF_ENCODER_GRAPH=0")
+    EncoderResnet._graph_states.pop(enc, None)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    images = [g["image"]] + [torch.rand(g["image"].shape, generator=gen).to(g["image"].device) for _ in range(3)]
+    with torch.no_grad():
+        eager = [[lv.clone() for lv in enc._latents(im)] for im in images]
+        got, kept = [], None
+        for i, im in enumerate(images + images):
+            out = enc.forward_pyramid(im).levels
+            state = EncoderResnet._graph_states.get(enc)
+            assert state is not None and (state[0] == "seen") == (i == 0), (i, state[0])     # captured on the second call
+            if i == 1:
+                kept = (out, [lv.clone() for lv in out])
+            got.append(out)
+        for i, out in enumerate(got):
+            for lv, ref in zip(out, eager[i % len(images)]):
+                assert lv.shape == ref.shape and rel(lv, ref) <= 1e-6, (i, rel(lv, ref))
+        assert all(torch.equal(a, b) for a, b in zip(*kept))                                  # replays did not touch a returned result
+        graph = EncoderResnet._graph_states[enc][0]
+        enc.model.conv1.weight.mul_(1.0)                                                      # version bump: the capture is stale
+        enc.forward_pyramid(images[0])
+        assert EncoderResnet._graph_states[enc][0] == "seen"
+        out = enc.forward_pyramid(images[1]).levels
+        assert EncoderResnet._graph_states[enc][0] is not graph and rel(out[-1], eager[1][-1]) <= 1e-6
+    before = EncoderResnet._graph_states[enc]
+    enc.forward_pyramid(images[0])                       # grad mode: eager, state untouched
+    assert EncoderResnet._graph_states[enc] is before
+    # and the whole forward pass through the captured trunk is the golden one
+    # (two runs of the MIOpen trunk differ by ~5e-7, which the renderer's flow amplifies to ~1e-4: held to the golden's own floors)
+    cam, rin, rob = _inputs(g)
+    with torch.no_grad():
+        out = model.forward(cam, rin, rob, compute_vis_features=True)
+    assert EncoderResnet._graph_states[enc] is before and before[0] != "seen"               # (it was a replay)
+    _check_forward(margins, "model_mlp.forward[through the graphed encoder]", out, g)
+
+
 def _noise(g, key, encoder):
     """The reference's own fp32 movement of output `key` under a one-ulp ray perturbation (+ a 1e-5 feature perturbation when
     the comparison runs through the MIOpen encoder); scalars stored next to the float64 golden."""
