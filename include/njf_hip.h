@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 18
+#define NJF_ABI_VERSION 19
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -410,13 +410,17 @@ int njf_resnetfc_backward(const float* d_out, int d_out_dim, const float* activa
  * HALVES, the dY stored x 2^k with k = 6 - exponent(*d_out_absmax) (device scalar max|d_out|, required then).  dx0 [P,64]: gradient w.r.t. the head's input (the query MLP's output): its weight gradient
  * contracts with the positional encoding, its hoisted feature part goes through njf_scatter_footprint.
  * njf_pack_transformer_backward: mats [3,4,64,64] = (Mqk, Nov, W1', W2) per layer, row-major [out][in]; biases [3,3,64] = (bqk, bo,
- * b1'); head_w [d_out,64]; -> w_out (NJF_TRANSFORMER_BACKWARD_CHUNKS chunks), b_out [3,192]. */
+ * b1'); head_w [d_out,64]; -> w_out (NJF_TRANSFORMER_BACKWARD_CHUNKS chunks), b_out [3,192].
+ * precision (ABI v19, both entry points, the same value): NJF_PRECISION_F32 -- exact fp32 MFMA -- or NJF_PRECISION_F16X2: split fp16
+ * products (hi*hi + hi*lo + lo*hi, fp32-class inside fp16's range) for the layer's re-evaluation and for the chain, which then runs on
+ * d_out x 2^k (d_out_absmax required) and scales its fp32 results back; the opt-in TF32-class form of njf_resnetfc_backward, for
+ * callers whose reference trains on TF32 products (train.py:64-65). */
 #define NJF_TRANSFORMER_BACKWARD_CHUNKS 13
 int njf_pack_transformer_backward(const float* mats, const float* biases, const float* head_w, int d_out, float* w_out,
-                                  float* b_out, void* stream);
+                                  float* b_out, int precision, void* stream);
 int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points, const float* w_backward,
                              const float* b_backward, float* wg_x, float* wg_dy, float* dx0, float* colsum_partial,
-                             int half_storage, const float* d_out_absmax, void* stream);
+                             int half_storage, const float* d_out_absmax, int precision, void* stream);
 
 /* One layer step of the ResnetFC backward chain (model_components/resnet_fc.py:69-79,130-154 differentiated; what
  * autograd runs as compare + multiply + add + sum kernels):  out [P,C] = residual + upstream * [act > 0], with act the

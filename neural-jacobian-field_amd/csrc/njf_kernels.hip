@@ -2326,7 +2326,7 @@ __device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4], float* __res
 }
 
 // the same for a 64-wide tile (two accumulator blocks; dst = the layer's 64 sums + 32 * hh)
-__device__ __forceinline__ void tile_colsum64(const f32x16 (&acc)[2], float* __restrict__ dst, int lane) {
+__device__ __forceinline__ void tile_colsum64(const f32x16 (&acc)[2], float* __restrict__ dst, int lane, float scale = 1.0f) {
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -2340,7 +2340,7 @@ __device__ __forceinline__ void tile_colsum64(const f32x16 (&acc)[2], float* __r
         v = dpp_add<0x122, 0xf>(v);  // row_ror:2
         v = dpp_add<0x121, 0xf>(v);  // row_ror:1
         v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-        o[e] = v;
+        o[e] = v * scale;
       }
       if ((lane & 31) == 16 + 4 * m + q) *(f32x4*)(dst + 16 * m + 4 * q) = o;
     }
@@ -2550,6 +2550,11 @@ __device__ __forceinline__ void store_vec64_f16(_Float16* __restrict__ dst, cons
     }
 }
 
+// PREC_F16X2 (opt-in like resnetfc_backward_kernel<PREC_F16X2>; training.py: backward_precision): every product -- the layer's
+// re-evaluation and the chain -- is hi*hi + hi*lo + lo*hi of fp16 halves.  The re-evaluated activations are O(1) (the forward pass
+// runs the same products in the same form); the chain is linear in d_out and runs on d_out * 2^k, k = 6 - exponent(max|d_out|), the
+// dY / dx0 / column sums are scaled back on the way out (fp16 pairs keep the 2^k, as in the exact form).
+template <int PREC>
 __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(TransformerBwdArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2566,21 +2571,30 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
   const float* bias = njf_lds + LDS_BIAS;
   float* const wx = !ok ? nullptr : (a.half ? (float*)((_Float16*)a.wg_x + row) : a.wg_x + row);
   float* const wy = !ok ? nullptr : (a.half ? (float*)((_Float16*)a.wg_dy + row) : a.wg_dy + row);
-  float pow2 = 1.0f;   // 2^k of the fp16 dY (wave-uniform)
-  if (a.half) {
+  constexpr bool SCALED = PREC != PREC_F32;
+  float pow2 = 1.0f, unpow2 = 1.0f;   // 2^k of max|d_out| and its inverse (wave-uniform)
+  if (SCALED || a.half) {
     const float mx = a.absmax ? *a.absmax : 0.f;
     if (mx > 0.f && mx < 3.0e38f) {
       int e;
       frexpf(mx, &e);
-      pow2 = ldexpf(1.0f, max(min(6 - e, 120), -120));
+      const int k = max(min(6 - e, 120), -120);
+      pow2 = ldexpf(1.0f, k);
+      unpow2 = ldexpf(1.0f, -k);
     }
   }
   const bool half = a.half != 0;
+  const float scale = SCALED ? pow2 : 1.0f;                                     // of the chain's own arithmetic
+  const float unscale = SCALED ? unpow2 : 1.0f;                                 // what leaves the chain in fp32
+  const float dy_scale = half ? (SCALED ? 1.0f : pow2) : unscale;               // of a stored dY
   // the (X, dY) pair slots: fp32, or halves under the 16-bit training storage (X as it is, dY x 2^k)
   auto put = [&](float* base, int k, const f32x16 (&v)[2], float scale) {
     if (base == nullptr) return;
     if (half) store_vec64_f16((_Float16*)base + (size_t)k * slice, v, scale);
-    else store_vec64(base + (size_t)k * slice, v);
+    else if (SCALED && scale != 1.0f) {
+      f32x16 w[2] = {v[0] * scale, v[1] * scale};
+      store_vec64(base + (size_t)k * slice, w);
+    } else store_vec64(base + (size_t)k * slice, v);
   };
   // (rows of padding lanes contribute nothing: their d_out is zero and the chain is linear in it)
   float* const sums = (a.colsum && tile * 32 < a.points) ? a.colsum + (size_t)tile * (12 * 64) + 32 * hh : nullptr;
@@ -2589,22 +2603,22 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int d = 16 * hh + r;
-    din[0][r] = (ok && d < a.d_out_dim) ? a.d_out[pc * a.d_out_dim + d] : 0.f;
+    din[0][r] = (ok && d < a.d_out_dim) ? a.d_out[pc * a.d_out_dim + d] * scale : 0.f;
   }
   f32x16 dx[2], xin[2], n[2], t[2], n2[2], u[2];
   dx[0] = (f32x16)(0.f);
   dx[1] = (f32x16)(0.f);
   const float* wl = stream_step(st, wave, lane);
-  mma_chunk<PREC_F32, 2, 1, 0, false, 1>(st, wl, lane, din, dx);   // Wj^T: gradient behind layer 2
+  mma_chunk<PREC, 2, 1, 0, false, 1>(st, wl, lane, din, dx);   // Wj^T: gradient behind layer 2
   for (int l = 2; l >= 0; --l) {
     const float* bl = bias + 192 * l;
     load_vec64(a.x + (size_t)l * slice + row, true, xin);
     // ---- the layer again -----------------------------------------------------------------------------------------
     const float rstd1 = norm64_rstd(xin, n);
     put(wx, 4 * l + 0, n, 1.0f);
-    bias_init<2, true, PREC_F32>(bl, hh, t);
+    bias_init<2, true, PREC>(bl, hh, t);
     wl = stream_step(st, wave, lane);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, n, t);            // dots[head * 8 + key]
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, n, t);            // dots[head * 8 + key]
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -2624,13 +2638,13 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
         for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] = e[k] * inv;       // a
       }
     put(wx, 4 * l + 1, t, 1.0f);
-    bias_init<2, false, PREC_F32>(bl + 64, hh, xin);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, t, xin);    // xm = x + Nov a + bo
+    bias_init<2, false, PREC>(bl + 64, hh, xin);
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, t, xin);    // xm = x + Nov a + bo
     const float rstd2 = norm64_rstd(xin, n2);
     put(wx, 4 * l + 2, n2, 1.0f);
-    bias_init<2, true, PREC_F32>(bl + 128, hh, u);
+    bias_init<2, true, PREC>(bl + 128, hh, u);
     wl = stream_step(st, wave, lane);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, n2, u);           // u = W1' n2 + b1'
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, n2, u);           // u = W1' n2 + b1'
     {
       f32x16 hval[2];
 #pragma unroll
@@ -2646,27 +2660,27 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
       put(wx, 4 * l + 3, hval, 1.0f);
     }
     // ---- and backwards ---------------------------------------------------------------------------------------------
-    put(wy, 4 * l + 3, dx, pow2);                                    // W2:  dY = dx
-    if (sums) tile_colsum64(dx, sums + (4 * l + 3) * 64, lane);
+    put(wy, 4 * l + 3, dx, dy_scale);                                    // W2:  dY = dx
+    if (sums) tile_colsum64(dx, sums + (4 * l + 3) * 64, lane, unscale);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // W2^T dx
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // W2^T dx
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[m][r] *= xin[m][r];                     // du
-    put(wy, 4 * l + 2, u, pow2);                                     // W1': dY = du
-    if (sums) tile_colsum64(u, sums + (4 * l + 2) * 64, lane);
+    put(wy, 4 * l + 2, u, dy_scale);                                     // W1': dY = du
+    if (sums) tile_colsum64(u, sums + (4 * l + 2) * 64, lane, unscale);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     wl = stream_step(st, wave, lane);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, u, xin);           // W1'^T du = dn2
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, u, xin);           // W1'^T du = dn2
     norm64_backward(xin, n2, rstd2, dx);                                     // dxm = dx + norm'(dn2)
-    put(wy, 4 * l + 1, dx, pow2);                                    // Nov: dY = dxm
-    if (sums) tile_colsum64(dx, sums + (4 * l + 1) * 64, lane);
+    put(wy, 4 * l + 1, dx, dy_scale);                                    // Nov: dY = dxm
+    if (sums) tile_colsum64(dx, sums + (4 * l + 1) * 64, lane, unscale);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // Nov^T dxm = da
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl + 4096, lane, dx, xin);   // Nov^T dxm = da
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -2677,15 +2691,21 @@ __global__ void __launch_bounds__(NJF_THREADS, 2) transformer_backward_kernel(Tr
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[m][8 * h8 + k] *= xin[m][8 * h8 + k] - dot;   // ds = a (da - <a, da>)
       }
-    put(wy, 4 * l + 0, t, pow2);                                     // Mqk: dY = ds
-    if (sums) tile_colsum64(t, sums + (4 * l + 0) * 64, lane);
+    put(wy, 4 * l + 0, t, dy_scale);                                     // Mqk: dY = ds
+    if (sums) tile_colsum64(t, sums + (4 * l + 0) * 64, lane, unscale);
     xin[0] = (f32x16)(0.f);
     xin[1] = (f32x16)(0.f);
     wl = stream_step(st, wave, lane);
-    mma_chunk<PREC_F32, 2, 2, 0, false, 2>(st, wl, lane, t, xin);           // Mqk^T ds = dn
+    mma_chunk<PREC, 2, 2, 0, false, 2>(st, wl, lane, t, xin);           // Mqk^T ds = dn
     norm64_backward(xin, n, rstd1, dx);                                      // gradient in front of layer l
   }
-  if (ok) store_vec64(a.dx0 + row, dx);
+  if (ok) {
+    if (SCALED) {
+      dx[0] *= unscale;
+      dx[1] *= unscale;
+    }
+    store_vec64(a.dx0 + row, dx);
+  }
 }
 
 // =============================================================================================
@@ -3188,13 +3208,14 @@ extern "C" int njf_resnetfc_backward(const float* d_out, int d_out_dim, const fl
 }
 
 extern "C" int njf_pack_transformer_backward(const float* mats, const float* biases, const float* head_w, int d_out,
-                                             float* w_out, float* b_out, void* stream) {
+                                             float* w_out, float* b_out, int precision, void* stream) {
   // mats [3][4][64][64] row-major [out][in] = (Mqk, Nov, W1', W2) per layer; biases [3][3][64] = (bqk, bo, b1') per layer;
   // head_w [d_out][64] = the output Linear.  w_out: NJF_TRANSFORMER_BACKWARD_CHUNKS chunks, b_out [3][192]
   if (!mats || !biases || !head_w || !w_out || !b_out) return NJF_E_NULL;
   if (d_out < 1 || d_out > 32) return NJF_E_DOUT;
+  if (precision != NJF_PRECISION_F32 && precision != NJF_PRECISION_F16X2) return NJF_E_MODE;
   hipStream_t s = (hipStream_t)stream;
-  const int P = NJF_PRECISION_F32;
+  const int P = precision;
   fill_kernel<<<64, 256, 0, s>>>(w_out, NJF_TRANSFORMER_BACKWARD_CHUNKS * NJF_CHUNK_FLOATS, 0.f);
   launch_pack(head_w, nullptr, 64, d_out, 2, 1, 3, P, w_out, nullptr, s);                      // Wj^T: 64 rows, K = d_out (<= 32)
   for (int l = 2, c = 1; l >= 0; --l, c += 4) {
@@ -3215,7 +3236,7 @@ extern "C" int njf_pack_transformer_backward(const float* mats, const float* bia
 extern "C" int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, int keys, int points,
                                         const float* w_backward, const float* b_backward, float* wg_x, float* wg_dy,
                                         float* dx0, float* colsum_partial, int half_storage, const float* d_out_absmax,
-                                        void* stream) {
+                                        int precision, void* stream) {
   if (!x || !d_out || !w_backward || !b_backward || !wg_x || !wg_dy || !dx0) return NJF_E_NULL;
   if (points < 1 || (long long)points * 12 * 64 > 0x7fffffffffLL) return NJF_E_SHAPE;
   if (d_out_dim < 1 || d_out_dim > 32) return NJF_E_DOUT;
@@ -3223,6 +3244,11 @@ extern "C" int njf_transformer_backward(const float* x, const float* d_out, int 
   if (half_storage && !d_out_absmax) return NJF_E_NULL;
   TransformerBwdArgs a{x, d_out, d_out_dim, keys, points, w_backward, b_backward, wg_x, wg_dy, dx0, colsum_partial,
                        half_storage != 0, d_out_absmax};
-  return launch_fused(transformer_backward_kernel, a, (points + 31) / 32, (hipStream_t)stream);
+  if (precision == NJF_PRECISION_F16X2) {
+    if (!d_out_absmax) return NJF_E_NULL;
+    return launch_fused(transformer_backward_kernel<PREC_F16X2>, a, (points + 31) / 32, (hipStream_t)stream);
+  }
+  if (precision != NJF_PRECISION_F32) return NJF_E_MODE;
+  return launch_fused(transformer_backward_kernel<PREC_F32>, a, (points + 31) / 32, (hipStream_t)stream);
 }
 

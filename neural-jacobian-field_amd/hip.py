@@ -138,8 +138,8 @@ _SIGNATURES = {
                             C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_pack_resnetfc_backward": ([C.POINTER(ResnetFcWeights), _vp, C.c_int, _vp], C.c_int),
     "njf_resnetfc_backward": ([_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
-    "njf_pack_transformer_backward": ([_vp, _vp, _vp, C.c_int, _vp, _vp, _vp], C.c_int),
-    "njf_transformer_backward": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
+    "njf_pack_transformer_backward": ([_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp], C.c_int),
+    "njf_transformer_backward": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
@@ -613,23 +613,29 @@ TRANSFORMER_BACKWARD_B_FLOATS = 3 * 192
 
 
 def pack_transformer_backward(mats: torch.Tensor, biases: torch.Tensor, head_w: torch.Tensor, w_out: torch.Tensor,
-                              b_out: torch.Tensor) -> None:
+                              b_out: torch.Tensor, precision: str = "f32") -> None:
     """Weights of njf_transformer_backward from the FOLDED head: mats [3,4,64,64] = (Mqk, Nov, W1', W2) per layer ([out, in]),
-    biases [3,3,64] = (bqk, bo, b1'), head_w [3A,64] (include/njf_hip.h)."""
+    biases [3,3,64] = (bqk, bo, b1'), head_w [3A,64] (include/njf_hip.h), packed for the chain's product form (``precision``:
+    "f32" exact, or "f16x2")."""
+    if precision not in BACKWARD_PRECISIONS:
+        raise ValueError(f"njf_hip: backward precision must be one of {BACKWARD_PRECISIONS} (got {precision!r})")
     if tuple(mats.shape) != (3, 4, 64, 64) or tuple(biases.shape) != (3, 3, 64) or head_w.dim() != 2 or head_w.shape[1] != 64:
         raise ValueError("njf_hip: pack_transformer_backward shape mismatch")
     if w_out.numel() != TRANSFORMER_BACKWARD_W_FLOATS or b_out.numel() != TRANSFORMER_BACKWARD_B_FLOATS:
         raise ValueError("njf_hip: pack_transformer_backward output size mismatch")
     _launch("njf_pack_transformer_backward", load_library().njf_pack_transformer_backward, _ptr(mats.contiguous(), "mats"),
             _ptr(biases.contiguous(), "biases"), _ptr(head_w.contiguous(), "head_w"), head_w.shape[0], _ptr(w_out, "w_out"),
-            _ptr(b_out, "b_out"))
+            _ptr(b_out, "b_out"), PRECISIONS[precision])
 
 
 def transformer_backward(x: torch.Tensor, d_out: torch.Tensor, keys: int, w_backward: torch.Tensor, b_backward: torch.Tensor,
-                         half_storage: bool = False):
+                         half_storage: bool = False, precision: str = "f32"):
     """The folded transformer head's data-gradient chain (include/njf_hip.h: njf_transformer_backward): x [4,P,64] (the residual
     stream the training forward dumped), d_out [P,3A] -> (wg_x [12,P,64], wg_dy [12,P,64], dx0 [P,64], column sums of the dY
-    [12,64], unscale).  ``half_storage``: the pairs are fp16, the dY scaled by 2^k; ``unscale`` = 2^-k as a device scalar (else 1)."""
+    [12,64], unscale).  ``half_storage``: the pairs are fp16, the dY scaled by 2^k; ``unscale`` = 2^-k as a device scalar (else 1).
+    ``precision``: the product form the weights were packed for ("f32" exact, "f16x2" split fp16 on d_out x 2^k)."""
+    if precision not in BACKWARD_PRECISIONS:
+        raise ValueError(f"njf_hip: backward precision must be one of {BACKWARD_PRECISIONS} (got {precision!r})")
     points = d_out.shape[0]
     if tuple(x.shape) != (4, points, 64) or w_backward.numel() != TRANSFORMER_BACKWARD_W_FLOATS \
             or b_backward.numel() != TRANSFORMER_BACKWARD_B_FLOATS:
@@ -641,11 +647,11 @@ def transformer_backward(x: torch.Tensor, d_out: torch.Tensor, keys: int, w_back
     dx0 = torch.empty(points, 64, dtype=torch.float32, device=dev)
     partial = torch.empty((points + 31) // 32, 12, 64, dtype=torch.float32, device=dev)
     d_out = d_out.contiguous()
-    absmax = d_out.abs().amax().reshape(1) if half_storage else None
+    absmax = d_out.abs().amax().reshape(1) if (half_storage or precision != "f32") else None
     _launch("njf_transformer_backward", load_library().njf_transformer_backward, _ptr(x, "x"), _ptr(d_out, "d_out"), d_out.shape[1],
             int(keys), points, _ptr(w_backward, "w_backward"), _ptr(b_backward, "b_backward"), _ptr(wg_x, "wg_x", pair_dtype),
             _ptr(wg_dy, "wg_dy", pair_dtype), _ptr(dx0, "dx0"), _ptr(partial, "colsum_partial"), int(half_storage),
-            _ptr(absmax, "d_out_absmax"))
+            _ptr(absmax, "d_out_absmax"), PRECISIONS[precision])
     unscale = power_of_two_unscale(absmax) if half_storage else None
     return wg_x, wg_dy, dx0, partial.sum(0), unscale
 

@@ -395,8 +395,8 @@ def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tenso
     residual stream x [4,P,64] the training forward dumped, the dumped encoding pe [P,64] (slot order) and footprint.
     ONE fused launch for the data-gradient chain (njf_transformer_backward, exact fp32 MFMA on the folded head), one batched
     library GEMM for the K = points weight gradients of the twelve folded matrices, the footprint scatter for the hoisted query
-    features, and the fold's autograd graph (64 x 64 matrices) back to the reference's parameterisation.  The chain itself is
-    always exact fp32; under the 16-bit training storage (``storage_precision``: "f16", or "auto" with the reference's matmul
+    features, and the fold's autograd graph (64 x 64 matrices) back to the reference's parameterisation.  The chain is exact fp32
+    unless ``backward_precision`` selects the split-fp16 form (as for the ResnetFC chain); under the 16-bit training storage (``storage_precision``: "f16", or "auto" with the reference's matmul
     precision "high") the (X, dY) pairs are written as halves and contracted with fp32 accumulation."""
     sizes = [t.numel() for t in params]
     flat, folded = transformer_fold(names, params, consume=True)      # (the forward pass's pack has usually built it already)
@@ -407,10 +407,13 @@ def transformer_head_backward(names: Sequence[str], params: Sequence[torch.Tenso
     dev = d_j.device
     w_t = torch.empty(hip.TRANSFORMER_BACKWARD_W_FLOATS, dtype=torch.float32, device=dev)
     b_t = torch.empty(hip.TRANSFORMER_BACKWARD_B_FLOATS, dtype=torch.float32, device=dev)
-    hip.pack_transformer_backward(mats32, biases32[:, :3].contiguous(), head_w, w_t, b_t)
+    chain = backward_precision(forward_precision)            # exact fp32, or (TF32-class, opt-in / "auto" under matmul precision "high") f16x2
+    hip.pack_transformer_backward(mats32, biases32[:, :3].contiguous(), head_w, w_t, b_t, precision=chain)
     keys = params[list(names).index("jacobian_index_embedding")].shape[1]
     half = storage_precision(forward_precision) == "f16"     # 16-bit training storage of what the weight-gradient GEMM reads
-    wg_x, wg_dy, dx0, dy_sums, unscale = hip.transformer_backward(x, d_j, keys, w_t, b_t, half_storage=half)
+    wg_x, wg_dy, dx0, dy_sums, unscale = hip.transformer_backward(x, d_j, keys, w_t, b_t, half_storage=half, precision=chain)
+    if chain != "f32":
+        _note_reduced_results(dx0, dy_sums)
     if half:
         g_mats = (_tn_batched_f16(wg_dy, wg_x) * unscale).reshape(3, 4, 64, 64)
         _note_reduced_results(g_mats)

@@ -946,6 +946,24 @@ def test_transformer_backward_chain_equals_the_library_recomputation(setup):
         assert max(worst16.values()) <= 2e-3 and all(torch.isfinite(v).all() for v in half.values()), worst16
         assert not training.reduced_backward_overflowed(dev)
         print(f"[transformer backward, A = {A}] 16-bit storage vs fp32 storage: {max(worst16.values()):.2e}")
+        # the chain itself on split fp16 products (njf_transformer_backward with NJF_PRECISION_F16X2, ABI v19: the layer's re-evaluation
+        # and the chain on d_out x 2^k; fp32-class, the TF32-class opt-in of the ResnetFC chain) against the exact chain, fp32 pairs;
+        # then both opt-ins together -- what matmul precision "high" selects
+        for storage, limit in (("f32", 1e-4), ("f16", 2e-3)):
+            try:
+                training.set_backward_precision("f16x2")
+                training.set_storage_precision(storage)
+                model.zero_grad(set_to_none=True)
+                out = model.forward(s["cam"], s["rin"], RobotInput(action.to(dev)))
+                (0.01 * torch.nn.functional.mse_loss(out.standard_output.optical_flow, s["target"].to(dev))).backward()
+            finally:
+                training.set_backward_precision("auto")
+                training.set_storage_precision("auto")
+            split = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            worst_split = {n: rel(split[n], g) for n, g in grads["hip"].items()}
+            assert max(worst_split.values()) <= limit and all(torch.isfinite(v).all() for v in split.values()), (storage, worst_split)
+            assert not training.reduced_backward_overflowed(dev)
+            print(f"[transformer backward, A = {A}] f16x2 chain ({storage} pairs) vs the exact chain: {max(worst_split.values()):.2e}")
 
 
 def test_wrapper_action_steps_with_the_shipped_allegro_head(setup):
