@@ -173,7 +173,9 @@ class EncoderResnet(Encoder):
                         self._latents(static_in)
                 torch.cuda.current_stream(rgb.device).wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # (thread-local error mode: a training process has other threads -- RCCL's watchdog, a loader's pinning thread --
+                #  whose event queries must not invalidate this thread's capture)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     static_out = self._latents(static_in)
             except Exception as exc:   # noqa: BLE001 -- whatever the libraries refuse inside a capture: fall back for good
                 import warnings
