@@ -155,7 +155,7 @@ def main():
     bucket = sum(p.numel() for p in trainable) * 4
     if rank == 0:
         dt = elapsed / args.steps
-        line = {"metric": f"training rays/s (config 4: {B} scene(s) x {R} rays per rank, 64+64 samples, fwd + bwd + gradient all-reduce + Adam)",
+        line = {"metric": f"training rays/s (config 4: {B} scene(s) x {R} rays per rank, {S}+{S} samples, fwd + bwd + gradient all-reduce + Adam)",
                 "value": round(world * B * R / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * dt, 3), "training_step_ms": round(1e3 * dt, 2), "higher_is_better": True, "scaling": "weak",
                 "rays_per_step": world * B * R, "samples": f"{S}+{S}", "train_rays_per_s": round(world * B * R / dt, 1),
