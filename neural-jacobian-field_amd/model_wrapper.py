@@ -134,7 +134,29 @@ def interlevel_loss(weights_list, ray_samples_list) -> torch.Tensor:
 
 def distortion_loss(weights_list, ray_samples_list) -> torch.Tensor:
     """nerfstudio.model_components.losses.distortion_loss (mip-NeRF 360 eq. 15) on the final level, in the spacing
-    domain: sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 (t_i+1 - t_i), averaged over rays."""
+    domain: sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 (t_i+1 - t_i), averaged over rays.
+
+    The pairwise term is evaluated in O(S) per ray instead of the O(S^2) outer difference nerfstudio forms: the bin mid-points of
+    a ray are non-decreasing (ray_samplers: bins are sorted by construction), so
+        sum_ij w_i w_j |m_i - m_j| = 2 sum_i w_i (m_i W_i - M_i),   W_i = sum_{j<i} w_j,  M_i = sum_{j<i} w_j m_j
+    -- two exclusive prefix sums.  At the shipped sampling (256 final samples, 1,792 rays) the outer form is four passes over a
+    470 MB [R,S,S] tensor forwards and as many backwards: 0.9 ms of a 16 ms perception step.  The prefix sums run in float64 (the
+    difference m_i W_i - M_i cancels when the weights concentrate at a surface; [R,S] doubles cost nothing), so the value and its
+    gradient d/dw_k = 2 sum_j w_j |m_k - m_j| are closer to the exact ones than the fp32 outer form's."""
+    t = _sdist(ray_samples_list[-1])
+    w = weights_list[-1][..., 0]
+    mid = ((t[..., 1:] + t[..., :-1]) / 2).double()
+    w64 = w.double()
+    wm = w64 * mid
+    below_w = torch.cumsum(w64, dim=-1) - w64          # exclusive prefix sums
+    below_wm = torch.cumsum(wm, dim=-1) - wm
+    inter = (2.0 * torch.sum(w64 * (mid * below_w - below_wm), dim=-1)).to(w.dtype)
+    intra = torch.sum(w ** 2 * (t[..., 1:] - t[..., :-1]), dim=-1) / 3
+    return torch.mean(inter + intra)
+
+
+def distortion_loss_outer(weights_list, ray_samples_list) -> torch.Tensor:
+    """The same loss in nerfstudio's literal O(S^2) form (the comparator of tests/test_host_cpu.py; not used by the training path)."""
     t = _sdist(ray_samples_list[-1])
     w = weights_list[-1][..., 0]
     mid = (t[..., 1:] + t[..., :-1]) / 2

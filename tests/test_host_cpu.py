@@ -685,6 +685,41 @@ def test_proposal_losses_match_the_loop_oracle():
     assert torch.allclose(g_i, r_i, rtol=1e-4, atol=1e-8) and torch.allclose(g_d, r_d, rtol=1e-4, atol=1e-8)
 
 
+def test_distortion_loss_prefix_form_equals_the_outer_form():
+    """model_wrapper.distortion_loss evaluates nerfstudio's pairwise term sum_ij w_i w_j |m_i - m_j| with two prefix sums (O(S) per
+    ray, float64) instead of the [R,S,S] outer difference.  Against the literal outer form evaluated in FLOAT64 (the truth of both):
+    value and gradient, uniform weights and weights concentrated on a surface (where m_i W_i - M_i cancels), equal mid-points
+    (zero-width bins) included; the fp32 outer form must not be closer to that truth than the prefix form is."""
+    from neural_jacobian_field_amd.model_wrapper import distortion_loss, distortion_loss_outer
+    from neural_jacobian_field_amd.ray_samplers import RaySamples
+    gen = torch.Generator().manual_seed(11)
+    n, s = 6, 48
+    edges = torch.sort(torch.rand(n, s + 1, generator=gen), dim=-1).values
+    edges[:, 0], edges[:, -1] = 0.0, 1.0
+    edges[0, 10:14] = edges[0, 10]                                          # zero-width bins: equal mid-points
+    spread = torch.rand(n, s, generator=gen)
+    peak = torch.exp(-0.5 * ((torch.arange(s)[None] - 30.0) / 0.6) ** 2) + 1e-6      # a surface: almost all weight in two bins
+    for raw in (spread, peak.expand(n, s) * (1 + 0.1 * spread)):
+        w0 = (raw / raw.sum(-1, keepdim=True) * 0.95)
+
+        def run(fn, dtype):
+            w = w0.to(dtype).clone().requires_grad_(True)
+            e = edges.to(dtype)
+            smp = RaySamples(None, None, e[:, :-1, None], e[:, 1:, None], None, e[:, :-1, None], e[:, 1:, None])
+            loss = fn([w[..., None]], [smp])
+            g, = torch.autograd.grad(loss, w)
+            return loss.detach().double(), g.detach().double()
+
+        truth, g_truth = run(distortion_loss_outer, torch.float64)
+        got, g_got = run(distortion_loss, torch.float32)
+        outer32, g_outer32 = run(distortion_loss_outer, torch.float32)
+        assert abs(got - truth) <= 1e-6 * abs(truth) + 1e-12, (got, truth)       # (fp32 mid-points, fp32 intra term and mean)
+        scale = g_truth.abs().max()
+        assert (g_got - g_truth).abs().max() <= 1e-6 * scale, ((g_got - g_truth).abs().max(), scale)
+        assert (g_got - g_truth).abs().max() <= (g_outer32 - g_truth).abs().max() + 2e-7 * scale
+        assert abs(got - truth) <= abs(outer32 - truth) + 5e-7 * abs(truth)
+
+
 def test_ctypes_structs_match_the_header():
     """Field names and order of every struct in include/njf_hip.h against the ctypes mirrors (hip.py) and the
     reference-side stub printed in INTEGRATION.md -- a missing trailing field would make the library read past the
