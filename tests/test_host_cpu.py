@@ -699,13 +699,17 @@ def test_distortion_loss_prefix_form_equals_the_outer_form():
     edges[0, 10:14] = edges[0, 10]                                          # zero-width bins: equal mid-points
     spread = torch.rand(n, s, generator=gen)
     peak = torch.exp(-0.5 * ((torch.arange(s)[None] - 30.0) / 0.6) ** 2) + 1e-6      # a surface: almost all weight in two bins
-    for raw in (spread, peak.expand(n, s) * (1 + 0.1 * spread)):
+    perm = torch.stack([torch.randperm(s, generator=gen) for _ in range(n)])            # samples of a ray in arbitrary order
+    for raw, shuffled in ((spread, False), (peak.expand(n, s) * (1 + 0.1 * spread), False), (spread, True)):
         w0 = (raw / raw.sum(-1, keepdim=True) * 0.95)
 
         def run(fn, dtype):
             w = w0.to(dtype).clone().requires_grad_(True)
             e = edges.to(dtype)
-            smp = RaySamples(None, None, e[:, :-1, None], e[:, 1:, None], None, e[:, :-1, None], e[:, 1:, None])
+            lo, hi = e[:, :-1], e[:, 1:]
+            if shuffled:
+                lo, hi = torch.gather(lo, -1, perm), torch.gather(hi, -1, perm)
+            smp = RaySamples(None, None, lo[..., None], hi[..., None], None, lo[..., None], hi[..., None])
             loss = fn([w[..., None]], [smp])
             g, = torch.autograd.grad(loss, w)
             return loss.detach().double(), g.detach().double()
