@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NJF_ABI_VERSION 19
+#define NJF_ABI_VERSION 20
 #define NJF_MAX_ACTION_DIM 10   /* 3*A <= 32 outputs of the Jacobian head */
 #define NJF_HIDDEN 128          /* MlpCfg.d_hidden (model_components/resnet_fc.py:12-18) */
 #define NJF_LATENT 512          /* encoder feature channels (models/encoder/encoder_resnet.py:88) */
@@ -429,6 +429,13 @@ int njf_transformer_backward(const float* x, const float* d_out, int d_out_dim, 
  * workgroup (the caller adds the rows; NULL = no sums).  C % 4 == 0 and C/4 must divide 256 (C = 64, 128, ...). */
 int njf_relu_backward(const float* upstream, const float* act, const float* residual, int points, int channels,
                       int rows_per_block, float* out, float* partial_colsum, void* stream);
+
+/* Epilogue of a convolution of the frozen encoder trunk in eval mode (models/encoder/encoder_resnet.py:24-89: the torchvision
+ * BasicBlock's  relu(bn(conv(x)))  and  relu(bn(conv(y)) + skip)  with batch norm on its running statistics; ABI v20):
+ * out = [relu]( (x - running_mean[c]) / sqrt(running_var[c] + eps) * gamma[c] + beta[c] [+ skip] ), x / skip / out [batch, channels,
+ * hw] fp32 NCHW (out may alias x; skip may be NULL), one launch instead of the library's batch-norm + add + ReLU kernels. */
+int njf_bn_act(const float* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               float eps, const float* skip, int relu, int batch, int channels, int hw, float* out, void* stream);
 
 /* ---- inverse dynamics on the composited Jacobian field ---------------------------------------- */
 /* The control loop of notebooks/real_world/2_inverse_dynamics.ipynb (cells 26-29: 100 Adam steps through

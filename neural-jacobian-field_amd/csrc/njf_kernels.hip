@@ -2266,6 +2266,75 @@ extern "C" int njf_relu_backward(const float* upstream, const float* act, const 
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue of a convolution of the FROZEN encoder trunk (encoder_resnet.py:24-89: torchvision BasicBlocks in eval mode):
+// out = [relu]( batch_norm_eval(x) [+ skip] ) on NCHW fp32 tensors, in ONE pass -- what the library runs as a batch-norm
+// inference kernel, an add and a ReLU (2-3 launches of ~4 us each: a single-image trunk is ~115 launches whose device time is
+// the launch floor, not the bytes).  batch_norm_eval(x)[c] = (x - mean[c]) / sqrt(var[c] + eps) * gamma[c] + beta[c], evaluated
+// in that order (the library's).  One thread = 4 consecutive floats of one (image, channel) plane (hw % 4 == 0), or one float.
+// ---------------------------------------------------------------------------------------------
+struct BnActArgs {
+  const float* x;
+  const float *gamma, *beta, *mean, *var;
+  float eps;
+  const float* skip;
+  int relu, channels, hw;
+  long long total;   // elements
+  float* out;
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) bn_act_kernel(BnActArgs a) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (i >= a.total) return;
+  const int c = (int)((i / a.hw) % a.channels);
+  const float mean = a.mean[c], invstd = 1.0f / sqrtf(a.var[c] + a.eps), g = a.gamma[c], bta = a.beta[c];
+  float v[V], sk[V];
+  if constexpr (V == 4) {
+    const f32x4 x4 = *(const f32x4*)(a.x + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x4[e];
+    if (a.skip) {
+      const f32x4 s4 = *(const f32x4*)(a.skip + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sk[e] = s4[e];
+    }
+  } else {
+    v[0] = a.x[i];
+    if (a.skip) sk[0] = a.skip[i];
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float y = (v[e] - mean) * invstd * g + bta;
+    if (a.skip) y += sk[e];
+    v[e] = a.relu ? fmaxf(y, 0.f) : y;
+  }
+  if constexpr (V == 4) {
+    const f32x4 o = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)(a.out + i) = o;
+  } else {
+    a.out[i] = v[0];
+  }
+}
+
+extern "C" int njf_bn_act(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, const float* skip, int relu, int batch, int channels, int hw,
+                          float* out, void* stream) {
+  if (!x || !gamma || !beta || !running_mean || !running_var || !out) return NJF_E_NULL;
+  if (batch < 1 || channels < 1 || hw < 1 || !(eps >= 0.f)) return NJF_E_SHAPE;
+  BnActArgs a{x, gamma, beta, running_mean, running_var, eps, skip, relu != 0, channels, hw, (long long)batch * channels * hw, out};
+  hipStream_t s = (hipStream_t)stream;
+  if ((hw & 3) == 0) {
+    const long long threads = a.total >> 2;
+    if ((threads + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
+    bn_act_kernel<4><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+  } else {
+    if ((a.total + 255) / 256 > 0x7fffffffLL) return NJF_E_SHAPE;
+    bn_act_kernel<1><<<(unsigned)((a.total + 255) / 256), 256, 0, s>>>(a);
+  }
+  return launch_status();
+}
+
 // =============================================================================================
 // backward data-gradient chain of one ResnetFC (training)
 // =============================================================================================

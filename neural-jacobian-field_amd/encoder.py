@@ -35,6 +35,16 @@ def _norm_factory(norm_type: str) -> Optional[Callable[[int], nn.Module]]:
     raise NotImplementedError(f"normalization layer [{norm_type}] is not found")
 
 
+def _fused_epilogue(x: torch.Tensor, bn: nn.Module) -> bool:
+    """May  [relu](bn(x) [+ skip])  of a frozen trunk run as ONE njf_bn_act launch?  Inference only: batch norm on its running
+    statistics (eval mode), no autograd graph, a contiguous fp32 NCHW tensor on the GPU.  NJF_ENCODER_FUSED=0 switches it off."""
+    return (_FUSED_EPILOGUES and not bn.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and x.is_contiguous() and isinstance(bn, nn.BatchNorm2d) and bn.affine and bn.running_mean is not None)
+
+
+_FUSED_EPILOGUES = os.environ.get("NJF_ENCODER_FUSED", "1") != "0"
+
+
 class _Block(nn.Module):
     def __init__(self, c_in: int, c_out: int, stride: int, norm):
         super().__init__()
@@ -47,8 +57,19 @@ class _Block(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(c_in, c_out, 1, stride, bias=False), norm(c_out))
 
     def forward(self, x):
+        y = self.conv1(x)
+        if _fused_epilogue(y, self.bn1):
+            # the frozen trunk (inference, the forward pass of the reference's action mode): every convolution's batch norm (+ skip)
+            # + ReLU is ONE launch on the convolution's own output (hip.bn_act, in place) instead of 2-3 library launches
+            from . import hip
+            if self.downsample is None:
+                skip = x.contiguous()
+            else:
+                skip = hip.bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+            y = hip.bn_act(y, self.bn1)
+            return hip.bn_act(self.conv2(y), self.bn2, skip=skip)
         skip = x if self.downsample is None else self.downsample(x)
-        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn1(y))
         return F.relu(self.bn2(self.conv2(y)) + skip)
 
 
@@ -123,7 +144,12 @@ class EncoderResnet(Encoder):
 
     def _latents(self, rgb: torch.Tensor):
         m = self.model
-        x = m.relu(m.bn1(m.conv1(rgb)))
+        x = m.conv1(rgb)
+        if _fused_epilogue(x, m.bn1):
+            from . import hip
+            x = hip.bn_act(x, m.bn1)
+        else:
+            x = m.relu(m.bn1(x))
         pyramid = [x]
         if self.num_layers > 1:
             if self.use_first_pool:

@@ -141,6 +141,7 @@ _SIGNATURES = {
     "njf_pack_transformer_backward": ([_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp], C.c_int),
     "njf_transformer_backward": ([_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp], C.c_int),
     "njf_scatter_footprint": ([_vp, C.c_int, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    "njf_bn_act": ([_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp], C.c_int),
     "njf_relu_backward": ([_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "njf_reduce_frame_partials": ([_vp, C.c_int, _vp, _vp], C.c_int),
     "njf_assemble_frame": ([_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp], C.c_int),
@@ -743,6 +744,21 @@ def relu_backward(upstream: torch.Tensor, act: torch.Tensor, residual: Optional[
     _launch("njf_relu_backward", load_library().njf_relu_backward, _ptr(upstream, "upstream"), _ptr(act, "act"), _ptr(residual, "residual"), points,
                                             channels, RELU_BACKWARD_ROWS, _ptr(out, "out"), _ptr(partial, "partial"))
     return out, (partial.sum(0) if want_colsum else None)
+
+
+def bn_act(x: torch.Tensor, bn: "torch.nn.BatchNorm2d", skip: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+    """[relu](batch_norm_eval(x) [+ skip]) IN PLACE on x ([B,C,H,W] contiguous fp32, a convolution's fresh output): the epilogue of
+    a convolution of the frozen encoder trunk as one launch (include/njf_hip.h: njf_bn_act).  ``bn``: an affine BatchNorm2d with
+    running statistics, evaluated on them (eval mode)."""
+    b, c, h, w = x.shape
+    if skip is not None and (skip.shape != x.shape or not skip.is_contiguous() or skip.dtype != torch.float32):
+        raise ValueError("njf_hip: bn_act skip must be a contiguous float32 tensor of x's shape")
+    if not x.is_contiguous() or bn.running_mean is None or bn.weight is None or bn.weight.numel() != c:
+        raise ValueError("njf_hip: bn_act needs a contiguous NCHW tensor and an affine BatchNorm2d with running statistics")
+    _launch("njf_bn_act", load_library().njf_bn_act, _ptr(x, "x"), _ptr(bn.weight.detach(), "gamma"), _ptr(bn.bias.detach(), "beta"),
+            _ptr(bn.running_mean, "running_mean"), _ptr(bn.running_var, "running_var"), float(bn.eps), _ptr(skip, "skip"), int(relu),
+            b, c, h * w, _ptr(x, "out"))
+    return x
 
 
 def frame_partial_groups(total_rays: int) -> int:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in include/njf_hip.h but not exported"
     from neural_jacobian_field_amd import hip
     assert set(hip.EXPORTED_SYMBOLS) == set(declared)
-    assert lib.njf_abi_version() == 19
+    assert lib.njf_abi_version() == 20
 
 
 def test_hoisted_channel_order(built):
@@ -811,7 +811,7 @@ def test_header_is_plain_c(tmp_path, built):
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe), f"-L{lib_dir}",
                     "-l:libnjf_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == len(names) and int(out[1]) == 19
+    assert int(out[0]) == len(names) and int(out[1]) == 20
 
 
 def test_static_isa_properties_of_the_fused_kernels():

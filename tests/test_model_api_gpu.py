@@ -48,6 +48,45 @@ def test_encoder_matches_reference(model_and_golden, margins):
     margins("model_mlp.encoder", "features", model.encoder(g["image"]), g["features"], g["features_f64"], tol=1e-5)  # MIOpen vs CPU
 
 
+def test_fused_trunk_epilogues_equal_the_library_ops(model_and_golden, margins):
+    """The frozen trunk's convolution epilogues as ONE launch each (njf_bn_act: eval-mode batch norm [+ skip] + ReLU, in place on the
+    convolution's output; encoder._Block.forward under no_grad) against the library's batch-norm / add / ReLU kernels on the same
+    convolutions: every latent within 2e-6 (the two evaluate the same expression; the convolutions themselves move by ~5e-7 run to
+    run), for the golden image, a batch of three, and a size whose planes are not a multiple of four floats (scalar path); the
+    concatenated feature map through the fused trunk against the reference's golden features like test_encoder_matches_reference;
+    grad-enabled and train-mode calls never take the fused path."""
+    from neural_jacobian_field_amd import encoder as enc_mod
+    model, g = model_and_golden
+    enc = model.encoder
+    assert enc_mod._FUSED_EPILOGUES, "NJF_ENCODER_FUSED=0 in the test environment"
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    dev = g["image"].device
+    images = [g["image"], torch.rand(3, 3, 64, 96, generator=gen).to(dev), torch.rand(1, 3, 60, 60, generator=gen).to(dev)]
+    calls = []
+    real = enc_mod._fused_epilogue
+    try:
+        enc_mod._fused_epilogue = lambda x, bn: calls.append(real(x, bn)) or calls[-1]
+        for im in images:
+            with torch.no_grad():
+                calls.clear()
+                fused = enc._latents(im)
+                assert calls and all(calls), "the fused path did not run"
+                enc_mod._FUSED_EPILOGUES = False
+                try:
+                    plain = enc._latents(im)
+                finally:
+                    enc_mod._FUSED_EPILOGUES = True
+            for a, b in zip(fused, plain):
+                assert a.shape == b.shape and rel(a, b) <= 2e-6, (tuple(im.shape), rel(a, b))
+        calls.clear()
+        enc._latents(g["image"])                                     # grad mode on: library ops
+        assert calls and not any(calls)
+        with torch.no_grad():
+            margins("model_mlp.encoder[fused epilogues]", "features", enc(g["image"]), g["features"], g["features_f64"], tol=1e-5)
+    finally:
+        enc_mod._fused_epilogue = real
+
+
 def test_frozen_encoder_trunk_as_hip_graph_equals_the_eager_trunk(model_and_golden, margins):
     """EncoderResnet.forward_pyramid of a frozen encoder in eval mode: the first call with a shape runs eagerly, the second captures
     the trunk as one HIP graph, later calls replay it on a copy of the image.  The latents must be what the eager trunk gives for
