@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned encode_e2m3(float v) {
 }
 
 // PREC_F16F6 form of a 128-output layer (mb = 4): one 32 KiB chunk per K-range of 64 (njf_device.h: F6_* offsets).
-__global__ void pack_layer_f16f6_kernel(PackLayer L) {
+__device__ __forceinline__ void pack_layer_f16f6_body(const PackLayer& L) {
   const int chunks = L.kb >> 1;
   _Float16* dst16 = (_Float16*)L.dst;
   // (a) hi fp16 fragments [chunk][t][m][lane][8]
@@ -193,7 +193,9 @@ __global__ void pack_layer_f16f6_kernel(PackLayer L) {
   }
 }
 
-__global__ void pack_layer_kernel(PackLayer L) {
+__global__ void pack_layer_f16f6_kernel(PackLayer L) { pack_layer_f16f6_body(L); }
+
+__device__ __forceinline__ void pack_layer_body(const PackLayer& L) {
   if (L.prec == NJF_PRECISION_F32) {
     const int n = L.kb * 4 * L.mb * 256;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -242,6 +244,25 @@ __global__ void pack_layer_kernel(PackLayer L) {
   if (L.bdst != nullptr && blockIdx.x == 0) {
     for (int f = threadIdx.x; f < 32 * L.mb; f += blockDim.x) L.bdst[f] = pack_bias_entry(L, f);
   }
+}
+
+__global__ void pack_layer_kernel(PackLayer L) { pack_layer_body(L); }
+
+// Several layers in ONE launch (blockIdx.y = layer): a network's pack is 11-22 layers of a few microseconds each, and an optimiser
+// step re-packs every network it touched -- forward blobs and the backward chain's transposed blobs (an action-mode step with the
+// transformer head: 36 pack launches; a perception step: ~70).  The njf_pack_* entry points queue their layers (PackScope) and
+// flush once; every layer writes its own destination, so the order among them does not matter.
+#define NJF_PACK_BATCH 24
+struct PackBatch {
+  PackLayer l[NJF_PACK_BATCH];
+  unsigned char f6[NJF_PACK_BATCH];   // 1: the fp6-corrected chunk form (pack_layer_f16f6_body)
+  int count;
+};
+
+__global__ void pack_batch_kernel(PackBatch B) {
+  const int k = blockIdx.y;
+  if (B.f6[k]) pack_layer_f16f6_body(B.l[k]);
+  else pack_layer_body(B.l[k]);
 }
 
 __global__ void fill_kernel(float* p, int n, float v) {
@@ -300,19 +321,51 @@ __global__ void pack_linz_kernel(const float* w0, const float* w1, const float* 
     }
 }
 
+// The layers an entry point packs, launched together when the scope ends (also on an early error return).  One scope per entry
+// point call, on the calling thread (the C ABI is re-entrant: the queue lives in the scope object, the pointer to it is thread-local).
+struct PackScope;
+static thread_local PackScope* g_pack_scope = nullptr;
+struct PackScope {
+  PackBatch b;
+  hipStream_t s;
+  explicit PackScope(hipStream_t stream) : s(stream) {
+    b.count = 0;
+    g_pack_scope = this;
+  }
+  void flush() {
+    if (b.count > 0) pack_batch_kernel<<<dim3(64, b.count), 256, 0, s>>>(b);
+    b.count = 0;
+  }
+  void add(const PackLayer& L, bool f6) {
+    if (b.count == NJF_PACK_BATCH) flush();
+    b.l[b.count] = L;
+    b.f6[b.count] = f6 ? 1 : 0;
+    ++b.count;
+  }
+  ~PackScope() {
+    flush();
+    g_pack_scope = nullptr;
+  }
+  PackScope(const PackScope&) = delete;
+  PackScope& operator=(const PackScope&) = delete;
+};
+
 static void launch_pack(const float* w, const float* b, int d_out, int d_in, int mb, int kb, int kind, int prec, float* dst,
                         float* bdst, hipStream_t s, int bias_form = 0) {
   PackLayer L{w, b, d_out, d_in, mb, kb, kind, prec, dst, bdst, bias_form};
   const int n = kb * 4 * mb * 256;
+  bool f6 = false;
   if (prec == NJF_PRECISION_F16F6) {
     // the 128-wide layers take the fp6-corrected chunk form; narrow layers keep the F16X2 form (njf_device.h: mma_chunk)
-    if (mb == 4 && (kb & 1) == 0) {
-      pack_layer_f16f6_kernel<<<64, 256, 0, s>>>(L);
-      return;
-    }
-    L.prec = NJF_PRECISION_F16X2;
+    if (mb == 4 && (kb & 1) == 0) f6 = true;
+    else L.prec = NJF_PRECISION_F16X2;
   }
-  pack_layer_kernel<<<(n + 255) / 256, 256, 0, s>>>(L);
+  if (g_pack_scope != nullptr && g_pack_scope->s == s) {
+    g_pack_scope->add(L, f6);
+    return;
+  }
+  if (f6) pack_layer_f16f6_kernel<<<64, 256, 0, s>>>(L);
+  else pack_layer_kernel<<<(n + 255) / 256, 256, 0, s>>>(L);
 }
 
 extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out, float* b_out, float* wz_out, int wz_ld,
@@ -326,6 +379,7 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
     if (!src->fc0_w[i] || !src->fc0_b[i] || !src->fc1_w[i] || !src->fc1_b[i]) return NJF_E_NULL;
   if (P == NJF_PRECISION_F16 && !wz_out) return NJF_E_NULL;  // two of its accumulated biases live in the hoisted map's bias
   hipStream_t s = (hipStream_t)stream;
+  PackScope scope(s);   // the network's 12 layers: one launch
   // chunk 0: lin_in 63(+bias) -> 128
   launch_pack(src->lin_in_w, src->lin_in_b, 128, NJF_PE_DIM, 4, 2, 1, P, w_out, nullptr, s);
   // a 128 x 128 layer is two chunks (K = 64 each), one in the plain-fp16 form: NJF_RESNET_CHUNKS_F16 = 12 of the blob's 22 slots
@@ -351,6 +405,7 @@ extern "C" int njf_pack_resnetfc_ld(const NjfResnetFcWeights* src, float* w_out,
                                          P == NJF_PRECISION_F16 ? src->fc1_b[0] : nullptr,
                                          P == NJF_PRECISION_F16 ? src->fc1_b[1] : nullptr);
   }
+  scope.flush();   // (before the status query: a failed batch launch must be this call's error)
   return launch_status();
 }
 
@@ -376,9 +431,11 @@ extern "C" int njf_pack_color_head(const NjfColorHeadWeights* src, float* w_out,
   if (!src || !w_out || !b_out || !src->w0 || !src->b0 || !src->w1 || !src->b1 || !src->w2 || !src->b2) return NJF_E_NULL;
   if (!valid_base_precision(precision)) return NJF_E_MODE;
   hipStream_t s = (hipStream_t)stream;
+  PackScope scope(s);
   launch_pack(src->w0, src->b0, 64, 31, 2, 1, 2, precision, w_out, nullptr, s);
   launch_pack(src->w1, src->b1, 64, 64, 2, 2, 0, precision, w_out + 2048, b_out, s);
   launch_pack(src->w2, src->b2, 3, 64, 1, 2, 0, precision, w_out + 6144, b_out + 64, s);
+  scope.flush();   // (before the status query: a failed batch launch must be this call's error)
   return launch_status();
 }
 
@@ -2564,6 +2621,7 @@ extern "C" int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* 
     if (!src->fc0_w[i] || !src->fc1_w[i]) return NJF_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   const int P = precision;
+  PackScope scope(s);   // 11 transposed layers: one launch
   // chunk 0: lin_out^T  [128 x d_out -> 32], half a chunk; the other half is never read but is moved by the DMA
   launch_pack(src->lin_out_w, nullptr, 128, src->d_out, 4, 1, 3, P, w_out, nullptr, s);
   fill_kernel<<<16, 256, 0, s>>>(w_out + 4096, 4096, 0.f);
@@ -2571,6 +2629,7 @@ extern "C" int njf_pack_resnetfc_backward(const NjfResnetFcWeights* src, float* 
     launch_pack(src->fc1_w[blk], nullptr, 128, 128, 4, 4, 3, P, w_out + (size_t)c * NJF_CHUNK_FLOATS, nullptr, s);
     launch_pack(src->fc0_w[blk], nullptr, 128, 128, 4, 4, 3, P, w_out + (size_t)(c + 2) * NJF_CHUNK_FLOATS, nullptr, s);
   }
+  scope.flush();   // (before the status query: a failed batch launch must be this call's error)
   return launch_status();
 }
 
@@ -3286,6 +3345,7 @@ extern "C" int njf_pack_transformer_backward(const float* mats, const float* bia
   hipStream_t s = (hipStream_t)stream;
   const int P = precision;
   fill_kernel<<<64, 256, 0, s>>>(w_out, NJF_TRANSFORMER_BACKWARD_CHUNKS * NJF_CHUNK_FLOATS, 0.f);
+  PackScope scope(s);   // 22 matrices: one launch, after the fill
   launch_pack(head_w, nullptr, 64, d_out, 2, 1, 3, P, w_out, nullptr, s);                      // Wj^T: 64 rows, K = d_out (<= 32)
   for (int l = 2, c = 1; l >= 0; --l, c += 4) {
     const float* m = mats + (size_t)l * 4 * 4096;
@@ -3299,6 +3359,7 @@ extern "C" int njf_pack_transformer_backward(const float* mats, const float* bia
     launch_pack(m + 4096, nullptr, 64, 64, 2, 2, 3, P, base + 2 * NJF_CHUNK_FLOATS + 4096, nullptr, s);          // Nov^T
     launch_pack(m, nullptr, 64, 64, 2, 2, 3, P, base + 3 * NJF_CHUNK_FLOATS, nullptr, s);                        // Mqk^T
   }
+  scope.flush();   // (before the status query: a failed batch launch must be this call's error)
   return launch_status();
 }
 
